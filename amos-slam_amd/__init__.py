@@ -1,0 +1,308 @@
+"""amos-slam_amd: MI355X-native front-end hot path of Amos-SLAM (ORB extract + Hamming match +
+mask gate), as a thin Python mirror of the C ABI in include/amos_frontend.h.
+
+The compute is in csrc/libamos_frontend.so (hand-written HIP for gfx950).  There is no CPU
+fallback: importing the binding without the built library raises, and every call goes to the GPU.
+The directory name has a hyphen (it is the project's name); load it with `load_package()` from
+__graft_entry__.py or tests/conftest.py, which registers it as module `amos_slam_amd`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libamos_frontend.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+BEST2_DTYPE = np.dtype([("best_idx", "<i4"), ("best_dist", "<i4"), ("second_idx", "<i4"),
+                        ("second_dist", "<i4")])
+
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # ORBmatcher.cc:49-51
+
+EXPORTS = [
+    "amos_last_error", "amos_device_count", "amos_orb_create", "amos_orb_destroy", "amos_orb_tables",
+    "amos_orb_level_sizes", "amos_orb_detect", "amos_orb_level_count", "amos_orb_level_keypoints",
+    "amos_orb_set_level_keypoints", "amos_orb_gate", "amos_orb_closed_mask", "amos_orb_describe",
+    "amos_orb_extract", "amos_orb_level_image", "amos_orb_blurred_image", "amos_orb_level_candidates",
+    "amos_orb_extract_batch_device", "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
+    "amos_orb_stream", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
+    "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
+    "amos_match_bruteforce_best2_batch_device",
+]
+
+
+class AmosError(RuntimeError):
+    pass
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """The C-ABI library.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AmosError(f"{LIB_PATH} is missing: build it with `make -C amos-slam_amd/csrc` "
+                            "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.amos_last_error.restype = C.c_char_p
+        L.amos_orb_stream.restype = C.c_void_p
+        L.amos_match_stream.restype = C.c_void_p
+        L.amos_orb_destroy.restype = None
+        L.amos_match_destroy.restype = None
+        L.amos_orb_destroy.argtypes = [C.c_void_p]
+        L.amos_match_destroy.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise AmosError(f"{what} failed (rc={rc}): {lib().amos_last_error().decode()}")
+    return rc
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_count():
+    return _check(lib().amos_device_count(), "amos_device_count")
+
+
+class OrbExtractor:
+    """Mirror of ORB_SLAM2::ORBextractor (include/ORBextractor.h:93-168) over the C ABI.
+
+    detect()            = 3-arg operator()      (ORBextractor.cc:1672)
+    gate()              = MovingKeyPoints       (ORBextractor.cc:1688)
+    describe()          = ProcessDesp           (ORBextractor.cc:1747)
+    extract()           = 4-arg operator()      (ORBextractor.cc:1544)
+    """
+
+    def __init__(self, n_features=1000, scale_factor=1.2, n_levels=8, ini_th=20, min_th=7,
+                 max_width=640, max_height=480, max_batch=1, device=0, stream=None):
+        self.L = lib()
+        self.params = OrbParams(n_features, scale_factor, n_levels, ini_th, min_th)
+        self.n_levels, self.n_features = n_levels, n_features
+        self.max_batch = max_batch
+        h = C.c_void_p()
+        _check(self.L.amos_orb_create(C.byref(self.params), C.c_int(max_width), C.c_int(max_height),
+                                      C.c_int(max_batch), C.c_int(device), C.c_void_p(stream), C.byref(h)),
+               "amos_orb_create")
+        self.h = h
+        self.shape = None
+        cap = C.c_int(0)
+        self.L.amos_orb_batch_results_device(self.h, None, None, None, C.byref(cap))
+        self.capacity = cap.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.amos_orb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # -- a1
+    def tables(self):
+        n = self.n_levels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        fpl, umax = np.zeros(n, np.int32), np.zeros(16, np.int32)
+        _check(self.L.amos_orb_tables(self.h, _p(sc), _p(isc), _p(s2), _p(is2), _p(fpl), _p(umax)), "amos_orb_tables")
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, features_per_level=fpl, umax=umax)
+
+    def level_sizes(self, width, height):
+        lw, lh = np.zeros(self.n_levels, np.int32), np.zeros(self.n_levels, np.int32)
+        _check(self.L.amos_orb_level_sizes(self.h, C.c_int(width), C.c_int(height), _p(lw), _p(lh)), "amos_orb_level_sizes")
+        return lw, lh
+
+    # -- a7
+    def detect(self, gray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        self.shape = (h, w)
+        _check(self.L.amos_orb_detect(self.h, _p(gray), C.c_size_t(gray.strides[0]), C.c_int(w), C.c_int(h)), "amos_orb_detect")
+
+    def level_keypoints(self, level, frame=0):
+        n = _check(self.L.amos_orb_level_count(self.h, C.c_int(frame), C.c_int(level)), "amos_orb_level_count")
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        _check(self.L.amos_orb_level_keypoints(self.h, C.c_int(frame), C.c_int(level), _p(out), C.c_int(len(out))),
+               "amos_orb_level_keypoints")
+        return out[:n]
+
+    def set_level_keypoints(self, level, kps, frame=0):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        _check(self.L.amos_orb_set_level_keypoints(self.h, C.c_int(frame), C.c_int(level), _p(kps), C.c_int(len(kps))),
+               "amos_orb_set_level_keypoints")
+
+    def level_candidates(self, level, frame=0, cap=1 << 20):
+        out = np.zeros(cap, KP_DTYPE)
+        n = _check(self.L.amos_orb_level_candidates(self.h, C.c_int(frame), C.c_int(level), _p(out), C.c_int(cap)),
+                   "amos_orb_level_candidates")
+        return out[:n].copy()
+
+    def level_image(self, level, padded=False, frame=0):
+        lw, lh = self.level_sizes(self.shape[1], self.shape[0])
+        w, h = int(lw[level]), int(lh[level])
+        if padded:
+            w, h = w + 38, h + 38
+        out = np.zeros((h, w), np.uint8)
+        _check(self.L.amos_orb_level_image(self.h, C.c_int(frame), C.c_int(level), _p(out), C.c_size_t(w),
+                                           C.c_int(int(padded))), "amos_orb_level_image")
+        return out
+
+    def blurred_image(self, level, frame=0):
+        lw, lh = self.level_sizes(self.shape[1], self.shape[0])
+        out = np.zeros((int(lh[level]), int(lw[level])), np.uint8)
+        _check(self.L.amos_orb_blurred_image(self.h, C.c_int(frame), C.c_int(level), _p(out), C.c_size_t(out.shape[1])),
+               "amos_orb_blurred_image")
+        return out
+
+    # -- a8
+    def gate(self, mask, labels=None, center_ids=None, rm_vector=None):
+        mask = np.ascontiguousarray(mask, np.uint8)
+        removed = np.zeros(self.capacity + 1, KP_DTYPE)
+        nrem = C.c_int(0)
+        if labels is not None:
+            labels = np.ascontiguousarray(labels, np.float64)
+            center_ids = np.ascontiguousarray(center_ids, np.int32)
+            rm_vector = np.ascontiguousarray(rm_vector, np.int32)
+            rc = self.L.amos_orb_gate(self.h, _p(mask), C.c_size_t(mask.strides[0]), _p(labels),
+                                      C.c_size_t(labels.shape[1]), _p(center_ids), C.c_int(len(center_ids)),
+                                      _p(rm_vector), C.c_int(len(rm_vector)), _p(removed), C.c_int(len(removed)),
+                                      C.byref(nrem))
+        else:
+            rc = self.L.amos_orb_gate(self.h, _p(mask), C.c_size_t(mask.strides[0]), None, C.c_size_t(0), None,
+                                      C.c_int(0), None, C.c_int(0), _p(removed), C.c_int(len(removed)), C.byref(nrem))
+        _check(rc, "amos_orb_gate")
+        return removed[:nrem.value].copy()
+
+    def closed_mask(self):
+        out = np.zeros(self.shape, np.uint8)
+        _check(self.L.amos_orb_closed_mask(self.h, _p(out), C.c_size_t(out.shape[1])), "amos_orb_closed_mask")
+        return out
+
+    # -- a9 / a11
+    def describe(self):
+        kps = np.zeros(self.capacity + 1, KP_DTYPE)
+        desc = np.zeros((self.capacity + 1, 32), np.uint8)
+        n = C.c_int(0)
+        _check(self.L.amos_orb_describe(self.h, _p(kps), _p(desc), C.c_int(len(kps)), C.byref(n)), "amos_orb_describe")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract(self, gray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        self.shape = (h, w)
+        kps = np.zeros(self.capacity + 1, KP_DTYPE)
+        desc = np.zeros((self.capacity + 1, 32), np.uint8)
+        n = C.c_int(0)
+        _check(self.L.amos_orb_extract(self.h, _p(gray), C.c_size_t(gray.strides[0]), C.c_int(w), C.c_int(h), _p(kps),
+                                       _p(desc), C.c_int(len(kps)), C.byref(n)), "amos_orb_extract")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    # -- batched, device resident
+    def extract_batch_device(self, d_ptr, frame_stride, row_stride, width, height, n_frames):
+        """d_ptr: integer device address of n_frames gray frames.  Asynchronous on the handle's stream."""
+        self.shape = (height, width)
+        _check(self.L.amos_orb_extract_batch_device(self.h, C.c_void_p(d_ptr), C.c_size_t(frame_stride),
+                                                    C.c_size_t(row_stride), C.c_int(width), C.c_int(height),
+                                                    C.c_int(n_frames)), "amos_orb_extract_batch_device")
+
+    def batch_results_device(self):
+        kps, desc, cnt, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+        _check(self.L.amos_orb_batch_results_device(self.h, C.byref(kps), C.byref(desc), C.byref(cnt), C.byref(cap)),
+               "amos_orb_batch_results_device")
+        return kps.value, desc.value, cnt.value, cap.value
+
+    def batch_fetch(self, frame):
+        kps = np.zeros(self.capacity + 1, KP_DTYPE)
+        desc = np.zeros((self.capacity + 1, 32), np.uint8)
+        n = C.c_int(0)
+        _check(self.L.amos_orb_batch_fetch(self.h, C.c_int(frame), _p(kps), _p(desc), C.c_int(len(kps)), C.byref(n)),
+               "amos_orb_batch_fetch")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def sync(self):
+        _check(self.L.amos_orb_sync(self.h), "amos_orb_sync")
+
+    @property
+    def stream(self):
+        return self.L.amos_orb_stream(self.h)
+
+
+class OrbMatcher:
+    """The distance / best-two primitives every ORBmatcher::Search* inner loop reduces to
+    (ORBmatcher.cc:1913-1933 and the candidate loops at :127-148, :278-304, :560-580, :1644-1690)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = lib()
+        m = C.c_void_p()
+        _check(self.L.amos_match_create(C.c_int(device), C.c_void_p(stream), C.byref(m)), "amos_match_create")
+        self.m = m
+
+    def close(self):
+        if getattr(self, "m", None):
+            self.L.amos_match_destroy(self.m)
+            self.m = None
+
+    def __del__(self):
+        self.close()
+
+    @staticmethod
+    def _sets(q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        return q, t
+
+    def distances(self, q, t):
+        q, t = self._sets(q, t)
+        out = np.zeros((len(q), len(t)), np.uint16)
+        _check(self.L.amos_match_distances(self.m, _p(q), C.c_int(len(q)), _p(t), C.c_int(len(t)), _p(out)),
+               "amos_match_distances")
+        return out
+
+    def list_distances(self, q, t, cand_off, cand_idx):
+        q, t = self._sets(q, t)
+        cand_off, cand_idx = np.ascontiguousarray(cand_off, np.int32), np.ascontiguousarray(cand_idx, np.int32)
+        out = np.zeros(len(cand_idx), np.uint16)
+        _check(self.L.amos_match_list_distances(self.m, _p(q), C.c_int(len(q)), _p(t), C.c_int(len(t)), _p(cand_off),
+                                                _p(cand_idx), _p(out)), "amos_match_list_distances")
+        return out
+
+    def list_best2(self, q, t, cand_off, cand_idx, init_dist=256):
+        q, t = self._sets(q, t)
+        cand_off, cand_idx = np.ascontiguousarray(cand_off, np.int32), np.ascontiguousarray(cand_idx, np.int32)
+        out = np.zeros(len(q), BEST2_DTYPE)
+        _check(self.L.amos_match_list_best2(self.m, _p(q), C.c_int(len(q)), _p(t), C.c_int(len(t)), _p(cand_off),
+                                            _p(cand_idx), C.c_int(init_dist), _p(out)), "amos_match_list_best2")
+        return out
+
+    def bruteforce_best2(self, q, t, init_dist=256):
+        q, t = self._sets(q, t)
+        out = np.zeros(len(q), BEST2_DTYPE)
+        _check(self.L.amos_match_bruteforce_best2(self.m, _p(q), C.c_int(len(q)), _p(t), C.c_int(len(t)),
+                                                  C.c_int(init_dist), _p(out)), "amos_match_bruteforce_best2")
+        return out
+
+    def bruteforce_best2_batch_device(self, d_desc, frame_stride_bytes, d_counts, d_pairs_q, d_pairs_t, n_pairs,
+                                      capacity, init_dist, d_out):
+        _check(self.L.amos_match_bruteforce_best2_batch_device(
+            self.m, C.c_void_p(d_desc), C.c_size_t(frame_stride_bytes), C.c_void_p(d_counts), C.c_void_p(d_pairs_q),
+            C.c_void_p(d_pairs_t), C.c_int(n_pairs), C.c_int(capacity), C.c_int(init_dist), C.c_void_p(d_out)),
+            "amos_match_bruteforce_best2_batch_device")
+
+    def sync(self):
+        _check(self.L.amos_match_sync(self.m), "amos_match_sync")
+
+    @property
+    def stream(self):
+        return self.L.amos_match_stream(self.m)

@@ -1,0 +1,77 @@
+// amos_common.h -- shared host/device declarations of the MI355X front-end library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/amos_frontend.h"
+
+namespace amos {
+
+void set_error(const char *fmt, ...);
+
+#define AMOS_HIP_CHECK(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            amos::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,   \
+                            __LINE__);                                                         \
+            return AMOS_ERR_DEVICE;                                                            \
+        }                                                                                      \
+    } while (0)
+
+constexpr int kEdge = AMOS_EDGE_THRESHOLD;  // 19, ORBextractor.cc:93
+constexpr int kPadLeft = 32;                // device planes keep the ROI origin 32-byte aligned
+constexpr int kHalfPatch = 15;              // ORBextractor.cc:92
+constexpr int kMinBorder = kEdge - 3;       // 16, ORBextractor.cc:1067
+constexpr int kWave = 64;
+
+// Geometry of one pyramid level for the current frame size (host-built, read by every kernel).
+struct LevelGeom {
+    int w, h;          // level image size (ORBextractor.cc:1832-1834)
+    int stride;        // bytes per row of the padded device plane
+    int planeOff;      // byte offset of the plane inside one frame's pyramid
+    int maxBX, maxBY;  // maxBorderX/Y = dim - 16 (ORBextractor.cc:1069-1070)
+    int nCols, nRows, wCell, hCell;  // FAST cell grid (ORBextractor.cc:1078-1086)
+    int cellStart, nCells;           // rows of the cell table that belong to this level
+    int ptsOff, ptsCap;              // compacted candidate array of this level inside one frame
+    int quota;                       // mnFeaturesPerLevel[level]
+    int nIni;                        // root nodes of the quad-tree (ORBextractor.cc:718)
+    int nodeCap;                     // capacity of the node list / of the level's keypoint list
+    int kpOff;                       // offset of the level's keypoint list inside one frame
+    int tabX, tabY;                  // offsets into the resize coefficient tables
+    float scale;                     // mvScaleFactor[level]
+    float patchSize;                 // (float)(int)(31 * scale), ORBextractor.cc:1177
+};
+
+struct Geom {
+    int nLevels;
+    int W, H;
+    int totalCells;      // cells per frame, all levels
+    int slotTotal;       // candidate slots per frame, all cells
+    int ptsTotal;        // compacted candidate capacity per frame, all levels
+    int kpLevelTotal;    // per-level keypoint list capacity per frame (sum of nodeCap)
+    int kpCap;           // capacity of the concatenated result per frame
+    int iniTh, minTh;
+    unsigned long long frameBytes;  // bytes of one frame's pyramid
+    LevelGeom lv[AMOS_MAX_LEVELS];
+};
+
+// One FAST cell: the pixels it tests and where its candidates go.
+struct Cell {
+    short level;
+    short x0, y0;  // first tested pixel (level coordinates) = (iniX + 3, iniY + 3)
+    short tw, th;  // tested region size
+    short pad;
+    int slotOff;   // first candidate slot of the cell inside one frame
+};
+
+// Resize coefficients of one destination column / row (cv::resize fixed point, 11 bits).
+struct ResizeTap {
+    short ofs;     // source index of the first tap
+    short ofs1;    // source index of the second tap (clamped)
+    short a0, a1;  // weights, sum 2048
+};
+
+}  // namespace amos

@@ -1,0 +1,724 @@
+// amos_orb.hip -- host side of the ORB extractor: geometry, device buffers, launches and the
+// C ABI declared in include/amos_frontend.h.  Kernels are in orb_kernels.h.
+//
+// Data layout in HBM (per handle, B = max_batch frames):
+//   pyramid   [B][frameBytes]   per frame: L padded planes, plane l = (h_l+38) rows of stride_l
+//                               bytes (stride multiple of 128, ROI origin at byte 32 of row 19)
+//   blurred   [B][frameBytes]   same geometry, only the ROI is written
+//   slots     [B][slotTotal]    u32 FAST candidates per cell (worst-case capacity per cell)
+//   pts       [B][ptsTotal]     u32 candidates per level, compacted in the reference's order
+//   lvKps     [B][kpLevelTotal] amos_keypoint lists per level (level coordinates)
+//   outKps / outDesc / outCount [B][kpCap] concatenated result (level-0 coordinates, 32 B rows)
+#include "orb_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+
+namespace amos {
+
+static thread_local std::string g_error;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cv_round(float v) { return (int)lrintf(v); }  // round half to even
+
+}  // namespace amos
+
+using namespace amos;
+
+struct amos_orb {
+    amos_orb_params p{};
+    int maxW = 0, maxH = 0, maxB = 0, device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    // a1 tables
+    float scale[AMOS_MAX_LEVELS]{}, invScale[AMOS_MAX_LEVELS]{}, sigma2[AMOS_MAX_LEVELS]{}, invSigma2[AMOS_MAX_LEVELS]{};
+    int quota[AMOS_MAX_LEVELS]{};
+    int umax[16]{};
+    // geometry of the current frame size and of the allocation
+    Geom geom{};
+    std::vector<Cell> cells;
+    std::vector<ResizeTap> taps;
+    std::vector<BlurTile> tiles;
+    int curW = 0, curH = 0;
+    Geom capGeom{};  // geometry at (maxW, maxH): sizes every buffer
+    size_t capCells = 0, capTaps = 0, capTiles = 0;
+    int octNC = 0, octSC = 0;
+    // device buffers
+    Geom *dGeom = nullptr;
+    Cell *dCells = nullptr;
+    ResizeTap *dTaps = nullptr;
+    BlurTile *dTiles = nullptr;
+    uint8_t *dPyr = nullptr, *dBlur = nullptr, *dInput = nullptr;
+    int *dSlotCount = nullptr;
+    uint32_t *dSlots = nullptr, *dPts = nullptr;
+    uint16_t *dNodeOf = nullptr;
+    uint8_t *dQuadOf = nullptr;
+    int *dCandCount = nullptr, *dLvCount = nullptr, *dOutCount = nullptr;
+    amos_keypoint *dLvKps = nullptr, *dOutKps = nullptr, *dRemoved = nullptr, *dScratchKps = nullptr;
+    uint8_t *dOutDesc = nullptr;
+    uint8_t *dMask = nullptr, *dMaskTmp = nullptr, *dMaskClosed = nullptr;
+    double *dLabels = nullptr;
+    int *dCenterIds = nullptr, *dRm = nullptr, *dNRemoved = nullptr, *dErr = nullptr;
+    int capCenters = 0, capRm = 0;
+    int inputPitch = 0, maskPitch = 0;
+    int nFrames = 0;      // frames of the last detect / batch
+    bool detected = false, described = false, gated = false;
+};
+
+// ---------------------------------------------------------------------------------------------
+// a1: ORBextractor::ORBextractor tables, ORBextractor.cc:492-609
+static int build_tables(amos_orb *h)
+{
+    const int L = h->p.n_levels;
+    h->scale[0] = 1.0f;
+    h->sigma2[0] = 1.0f;
+    for (int i = 1; i < L; i++) {
+        h->scale[i] = h->scale[i - 1] * h->p.scale_factor;
+        h->sigma2[i] = h->scale[i] * h->scale[i];
+    }
+    for (int i = 0; i < L; i++) {
+        h->invScale[i] = 1.0f / h->scale[i];
+        h->invSigma2[i] = 1.0f / h->sigma2[i];
+    }
+    const float factor = 1.0f / h->p.scale_factor;
+    float nDesired = (float)h->p.n_features * (1.0f - factor) / (1.0f - (float)std::pow((double)factor, (double)L));
+    int sum = 0;
+    for (int l = 0; l < L - 1; l++) {
+        h->quota[l] = cv_round(nDesired);
+        sum += h->quota[l];
+        nDesired *= factor;
+    }
+    h->quota[L - 1] = std::max(h->p.n_features - sum, 0);
+    // umax of the circular patch
+    const int vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    const int vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (int v = 0; v <= vmax; ++v) h->umax[v] = (int)lrint(std::sqrt(hp2 - v * v));
+    for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+        while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+        h->umax[v] = v0;
+        ++v0;
+    }
+    return AMOS_OK;
+}
+
+// cv::resize coefficient tables for one axis: horizontal taps clamp the fraction,
+// vertical taps only clip the row index.
+static void build_taps(int srcN, int dstN, bool horizontal, ResizeTap *out)
+{
+    const double inv_scale = (double)dstN / srcN;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dstN; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        int s0 = s, s1 = s + 1;
+        if (horizontal) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= srcN - 1) { f = 0; s = srcN - 1; }
+            s0 = s;
+            s1 = std::min(s + 1, srcN - 1);
+        } else {
+            s0 = std::min(std::max(s0, 0), srcN - 1);
+            s1 = std::min(std::max(s1, 0), srcN - 1);
+        }
+        auto sat = [](float v) { int i = cv_round(v); return (short)std::min(std::max(i, -32768), 32767); };
+        out[d].ofs = (short)s0;
+        out[d].ofs1 = (short)s1;
+        out[d].a0 = sat((1.f - f) * 2048);
+        out[d].a1 = sat(f * 2048);
+    }
+}
+
+// Geometry for a w x h frame.  Fails for frames the reference itself cannot process (a level
+// with no FAST cell divides by zero at ORBextractor.cc:1083-1086).
+static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector<Cell> *cells,
+                          std::vector<ResizeTap> *taps, std::vector<BlurTile> *tiles)
+{
+    const int L = h->p.n_levels;
+    std::memset(&g, 0, sizeof(g));
+    g.nLevels = L;
+    g.W = W;
+    g.H = Hh;
+    g.iniTh = h->p.ini_th_fast;
+    g.minTh = h->p.min_th_fast;
+    size_t off = 0;
+    int cellIdx = 0, slotOff = 0, ptsOff = 0, kpOff = 0, tabOff = 0;
+    if (cells) cells->clear();
+    if (taps) taps->clear();
+    if (tiles) tiles->clear();
+    for (int l = 0; l < L; l++) {
+        LevelGeom &lg = g.lv[l];
+        lg.w = cv_round((float)W * h->invScale[l]);
+        lg.h = cv_round((float)Hh * h->invScale[l]);
+        if (lg.w > 4000 || lg.h > 4000) { set_error("level %d too large (%dx%d)", l, lg.w, lg.h); return AMOS_ERR_INVALID; }
+        lg.stride = align_up(kPadLeft + lg.w + kEdge, 128);
+        lg.planeOff = (int)off;
+        off += align_up_sz((size_t)lg.stride * (lg.h + 2 * kEdge), 256);
+        if (off > 0x7fffffffu) { set_error("frame pyramid exceeds 2 GiB"); return AMOS_ERR_INVALID; }
+        lg.maxBX = lg.w - kEdge + 3;
+        lg.maxBY = lg.h - kEdge + 3;
+        const float width = (float)(lg.maxBX - kMinBorder), height = (float)(lg.maxBY - kMinBorder);
+        lg.nCols = (int)(width / 30.f);
+        lg.nRows = (int)(height / 30.f);
+        if (lg.nCols < 1 || lg.nRows < 1 || lg.w <= 2 * kEdge || lg.h <= 2 * kEdge) {
+            set_error("level %d (%dx%d) has no FAST cell: frame too small for %d levels", l, lg.w, lg.h, L);
+            return AMOS_ERR_INVALID;
+        }
+        lg.wCell = (int)std::ceil(width / lg.nCols);
+        lg.hCell = (int)std::ceil(height / lg.nRows);
+        if (lg.wCell > kFastMaxCell || lg.hCell > kFastMaxCell) {
+            set_error("level %d cell %dx%d exceeds %d", l, lg.wCell, lg.hCell, kFastMaxCell);
+            return AMOS_ERR_INVALID;
+        }
+        lg.cellStart = cellIdx;
+        lg.ptsOff = ptsOff;
+        int levelPts = 0;
+        for (int i = 0; i < lg.nRows; i++) {  // ORBextractor.cc:1089-1120
+            const float iniY = (float)(kMinBorder + i * lg.hCell);
+            float maxY = iniY + lg.hCell + 6;
+            if (iniY >= lg.maxBY - 3) continue;
+            if (maxY > lg.maxBY) maxY = (float)lg.maxBY;
+            for (int j = 0; j < lg.nCols; j++) {
+                const float iniX = (float)(kMinBorder + j * lg.wCell);
+                float maxX = iniX + lg.wCell + 6;
+                if (iniX >= lg.maxBX - 6) continue;
+                if (maxX > lg.maxBX) maxX = (float)lg.maxBX;
+                const int tw = (int)maxX - (int)iniX - 6, th = (int)maxY - (int)iniY - 6;
+                if (tw <= 0 || th <= 0) continue;  // FAST tests no pixel of such a sub-image
+                Cell c{};
+                c.level = (short)l;
+                c.x0 = (short)((int)iniX + 3);
+                c.y0 = (short)((int)iniY + 3);
+                c.tw = (short)tw;
+                c.th = (short)th;
+                c.slotOff = slotOff;
+                const int cap = ((tw + 1) / 2) * ((th + 1) / 2);  // 3x3 strict NMS keeps <= 1 per 2x2
+                slotOff += cap;
+                levelPts += cap;
+                if (cells) cells->push_back(c);
+                cellIdx++;
+            }
+        }
+        lg.nCells = cellIdx - lg.cellStart;
+        lg.ptsCap = levelPts;
+        ptsOff += levelPts;
+        if (levelPts > 0xfffff) { set_error("level %d: more than 2^20 candidate slots", l); return AMOS_ERR_INVALID; }
+        lg.quota = h->quota[l];
+        lg.nIni = (int)std::round((float)(lg.maxBX - kMinBorder) / (lg.maxBY - kMinBorder));  // :718
+        if (lg.nIni < 1) { set_error("level %d aspect ratio %dx%d unsupported (nIni = 0)", l, lg.w, lg.h); return AMOS_ERR_INVALID; }
+        lg.nodeCap = std::max(lg.quota, 4 * lg.nIni) + 4;
+        lg.kpOff = kpOff;
+        kpOff += lg.nodeCap;
+        lg.scale = h->scale[l];
+        lg.patchSize = (float)(int)(31 * h->scale[l]);
+        lg.tabX = lg.tabY = 0;
+        if (l > 0) {
+            lg.tabX = tabOff;
+            lg.tabY = tabOff + lg.w;
+            tabOff += lg.w + lg.h;
+            if (taps) {
+                taps->resize(tabOff);
+                build_taps(g.lv[l - 1].w, lg.w, true, taps->data() + lg.tabX);
+                build_taps(g.lv[l - 1].h, lg.h, false, taps->data() + lg.tabY);
+            }
+        }
+        if (tiles)
+            for (int y0 = 0; y0 < lg.h; y0 += 16)
+                for (int x0 = 0; x0 < lg.w; x0 += 64) tiles->push_back(BlurTile{(short)l, (short)x0, (short)y0, 0});
+    }
+    g.frameBytes = align_up_sz(off, 256);
+    g.totalCells = cellIdx;
+    g.slotTotal = slotOff;
+    g.ptsTotal = ptsOff;
+    g.kpLevelTotal = kpOff;
+    g.kpCap = kpOff;
+    return AMOS_OK;
+}
+
+static int set_geometry(amos_orb *h, int W, int Hh)
+{
+    if (W == h->curW && Hh == h->curH) return AMOS_OK;
+    if (W > h->maxW || Hh > h->maxH) { set_error("frame %dx%d exceeds the handle's %dx%d", W, Hh, h->maxW, h->maxH); return AMOS_ERR_CAPACITY; }
+    Geom g;
+    std::vector<Cell> cells;
+    std::vector<ResizeTap> taps;
+    std::vector<BlurTile> tiles;
+    int rc = build_geometry(h, W, Hh, g, &cells, &taps, &tiles);
+    if (rc != AMOS_OK) return rc;
+    const Geom &c = h->capGeom;
+    if (g.frameBytes > c.frameBytes || g.totalCells > (int)h->capCells || g.slotTotal > c.slotTotal ||
+        g.ptsTotal > c.ptsTotal || g.kpLevelTotal > c.kpLevelTotal || taps.size() > h->capTaps ||
+        tiles.size() > h->capTiles) {
+        set_error("frame %dx%d needs more scratch than the handle's %dx%d allocation", W, Hh, h->maxW, h->maxH);
+        return AMOS_ERR_CAPACITY;
+    }
+    int nc = 0, sc = 0;
+    for (int l = 0; l < g.nLevels; l++) { nc = std::max(nc, g.lv[l].nodeCap); sc = std::max(sc, g.lv[l].nCells); }
+    // keep the kpCap (row pitch of the result arrays) of the allocation so batch pointers stay valid
+    g.kpCap = c.kpCap;
+    h->octNC = align_up(nc, 4);
+    h->octSC = align_up(std::max(sc, h->octNC), 4);
+    h->geom = g;
+    h->cells.swap(cells);
+    h->taps.swap(taps);
+    h->tiles.swap(tiles);
+    AMOS_HIP_CHECK(hipMemcpyAsync(h->dGeom, &h->geom, sizeof(Geom), hipMemcpyHostToDevice, h->stream));
+    AMOS_HIP_CHECK(hipMemcpyAsync(h->dCells, h->cells.data(), sizeof(Cell) * h->cells.size(), hipMemcpyHostToDevice, h->stream));
+    if (!h->taps.empty())
+        AMOS_HIP_CHECK(hipMemcpyAsync(h->dTaps, h->taps.data(), sizeof(ResizeTap) * h->taps.size(), hipMemcpyHostToDevice, h->stream));
+    AMOS_HIP_CHECK(hipMemcpyAsync(h->dTiles, h->tiles.data(), sizeof(BlurTile) * h->tiles.size(), hipMemcpyHostToDevice, h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));  // host vectors above are pageable and reused
+    h->curW = W;
+    h->curH = Hh;
+    h->detected = h->described = h->gated = false;
+    return AMOS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, size_t rowStride, int nFrames)
+{
+    const Geom &g = h->geom;
+    for (int l = 0; l < g.nLevels; l++) {
+        const LevelGeom &lg = g.lv[l];
+        const int groups = (kPadLeft + lg.w + kEdge + 3) / 4;
+        dim3 grid((groups + 63) / 64, (lg.h + 2 * kEdge + 3) / 4, nFrames), block(64, 4);
+        if (l == 0)
+            hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, h->dTaps, l);
+        else
+            hipLaunchKernelGGL(k_pyramid_level<false>, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, h->dTaps, l);
+    }
+    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nFrames), dim3(256), 0, h->stream, h->dPyr, h->dGeom, h->dCells,
+                       h->dSlotCount, h->dSlots);
+    const size_t lds = oct_lds_bytes(h->octNC, h->octSC);
+    hipLaunchKernelGGL(k_octree, dim3(nFrames * g.nLevels), dim3(256), lds, h->stream, h->dGeom, h->dCells, h->dSlotCount,
+                       h->dSlots, h->dPts, h->dNodeOf, h->dQuadOf, h->dCandCount, h->dLvKps, h->dLvCount, h->octNC, h->octSC);
+    hipLaunchKernelGGL(k_orient, dim3((g.kpLevelTotal + 3) / 4, nFrames), dim3(256), 0, h->stream, h->dPyr, h->dGeom, h->dLvKps,
+                       h->dLvCount);
+    AMOS_HIP_CHECK(hipGetLastError());
+    h->nFrames = nFrames;
+    h->detected = true;
+    h->described = h->gated = false;
+    return AMOS_OK;
+}
+
+static int launch_describe(amos_orb *h, int nFrames)
+{
+    const Geom &g = h->geom;
+    hipLaunchKernelGGL(k_blur, dim3((unsigned)h->tiles.size(), nFrames), dim3(256), 0, h->stream, h->dPyr, h->dBlur, h->dGeom, h->dTiles);
+    hipLaunchKernelGGL(k_describe, dim3((g.kpLevelTotal + 3) / 4, nFrames), dim3(256), 0, h->stream, h->dBlur, h->dGeom, h->dLvKps,
+                       h->dLvCount, h->dOutKps, h->dOutDesc, h->dOutCount);
+    AMOS_HIP_CHECK(hipGetLastError());
+    h->described = true;
+    return AMOS_OK;
+}
+
+static int fetch_frame(amos_orb *h, int frame, amos_keypoint *kps, uint8_t *desc, int cap, int *n)
+{
+    int count = 0;
+    AMOS_HIP_CHECK(hipMemcpyAsync(&count, h->dOutCount + frame, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (n) *n = count;
+    if (count > cap) { set_error("result holds %d keypoints, caller capacity %d", count, cap); return AMOS_ERR_CAPACITY; }
+    if (count > 0) {
+        const size_t base = (size_t)frame * h->geom.kpCap;
+        if (kps) AMOS_HIP_CHECK(hipMemcpyAsync(kps, h->dOutKps + base, sizeof(amos_keypoint) * count, hipMemcpyDeviceToHost, h->stream));
+        if (desc) AMOS_HIP_CHECK(hipMemcpyAsync(desc, h->dOutDesc + base * 32, (size_t)32 * count, hipMemcpyDeviceToHost, h->stream));
+        AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
+    return AMOS_OK;
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t count)
+{
+    AMOS_HIP_CHECK(hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+    return AMOS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *amos_last_error(void) { return g_error.c_str(); }
+
+int amos_device_count(void)
+{
+    int n = 0;
+    AMOS_HIP_CHECK(hipGetDeviceCount(&n));
+    return n;
+}
+
+int amos_orb_create(const amos_orb_params *params, int max_width, int max_height, int max_batch, int device,
+                    void *stream, amos_orb **out)
+{
+    if (!params || !out || max_width < 1 || max_height < 1 || max_batch < 1 || params->n_levels < 1 ||
+        params->n_levels > AMOS_MAX_LEVELS || params->n_features < 1 || !(params->scale_factor > 1.0f)) {
+        set_error("amos_orb_create: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    AMOS_HIP_CHECK(hipSetDevice(device));
+    amos_orb *h = new amos_orb();
+    h->p = *params;
+    h->maxW = max_width;
+    h->maxH = max_height;
+    h->maxB = max_batch;
+    h->device = device;
+    build_tables(h);
+    static const int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    if (std::memcmp(kUmax, h->umax, sizeof(kUmax)) != 0) { set_error("umax table mismatch"); delete h; return AMOS_ERR_INVALID; }
+    std::vector<Cell> cells;
+    std::vector<ResizeTap> taps;
+    std::vector<BlurTile> tiles;
+    int rc = build_geometry(h, max_width, max_height, h->capGeom, &cells, &taps, &tiles);
+    if (rc != AMOS_OK) { delete h; return rc; }
+    const Geom &c = h->capGeom;
+    h->capCells = cells.size() + 64;
+    h->capTaps = taps.size() + 64;
+    h->capTiles = tiles.size() + 64;
+    if (stream) h->stream = (hipStream_t)stream;
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete h; return AMOS_ERR_DEVICE; }
+        h->ownStream = true;
+    }
+    const size_t B = (size_t)max_batch;
+    const size_t slack = 4096;  // tile loads may run a few bytes past the last row of the last plane
+    h->inputPitch = align_up(max_width, 128);
+    h->maskPitch = align_up(max_width, 128);
+#define ALLOC(ptr, count) do { rc = dev_alloc(&(ptr), (count)); if (rc != AMOS_OK) { amos_orb_destroy(h); return rc; } } while (0)
+    ALLOC(h->dGeom, 1);
+    ALLOC(h->dCells, h->capCells);
+    ALLOC(h->dTaps, h->capTaps);
+    ALLOC(h->dTiles, h->capTiles);
+    ALLOC(h->dPyr, B * c.frameBytes + slack);
+    ALLOC(h->dBlur, B * c.frameBytes + slack);
+    ALLOC(h->dInput, (size_t)h->inputPitch * max_height);
+    ALLOC(h->dSlotCount, B * c.totalCells);
+    ALLOC(h->dSlots, B * c.slotTotal);
+    ALLOC(h->dPts, B * c.ptsTotal);
+    ALLOC(h->dNodeOf, B * c.ptsTotal);
+    ALLOC(h->dQuadOf, B * c.ptsTotal);
+    ALLOC(h->dCandCount, B * c.nLevels);
+    ALLOC(h->dLvCount, B * c.nLevels);
+    ALLOC(h->dOutCount, B);
+    ALLOC(h->dLvKps, B * c.kpLevelTotal);
+    ALLOC(h->dOutKps, B * c.kpCap);
+    ALLOC(h->dOutDesc, B * c.kpCap * 32);
+    ALLOC(h->dRemoved, B * c.kpLevelTotal);
+    ALLOC(h->dScratchKps, (size_t)c.ptsTotal);
+    ALLOC(h->dMask, (size_t)h->maskPitch * max_height);
+    ALLOC(h->dMaskTmp, (size_t)h->maskPitch * max_height);
+    ALLOC(h->dMaskClosed, (size_t)h->maskPitch * max_height);
+    ALLOC(h->dLabels, (size_t)max_width * max_height);
+    ALLOC(h->dNRemoved, B);
+    ALLOC(h->dErr, 1);
+#undef ALLOC
+    (void)hipMemsetAsync(h->dPyr, 0, B * c.frameBytes + slack, h->stream);
+    (void)hipMemsetAsync(h->dBlur, 0, B * c.frameBytes + slack, h->stream);
+    (void)hipMemsetAsync(h->dLvCount, 0, sizeof(int) * B * c.nLevels, h->stream);
+    (void)hipMemsetAsync(h->dOutCount, 0, sizeof(int) * B, h->stream);
+    // constants
+    signed char pat[1024];
+    std::memcpy(pat, amos_orb_pattern, 1024);
+    int dx[31];
+    {  // getStructuringElement(MORPH_ELLIPSE, 31x31), SURVEY A.6
+        const int r = 15, cc = 15;
+        const double inv_r2 = 1. / ((double)r * r);
+        for (int i = 0; i < 31; i++) {
+            const int dy = i - r;
+            dx[i] = (int)lrint(cc * std::sqrt((r * r - dy * dy) * inv_r2));
+        }
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pat, sizeof(pat)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(int) * 16) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(c_ellipse_dx), dx, sizeof(dx)) != hipSuccess) {
+        set_error("hipMemcpyToSymbol failed");
+        amos_orb_destroy(h);
+        return AMOS_ERR_DEVICE;
+    }
+    int maxNC = 0, maxSC = 0;
+    for (int l = 0; l < c.nLevels; l++) { maxNC = std::max(maxNC, c.lv[l].nodeCap); maxSC = std::max(maxSC, c.lv[l].nCells); }
+    const size_t maxLds = oct_lds_bytes(align_up(maxNC, 4), align_up(std::max(maxSC, maxNC), 4));
+    if (maxLds > 160 * 1024) { set_error("quad-tree needs %zu B of LDS (n_features too large)", maxLds); amos_orb_destroy(h); return AMOS_ERR_INVALID; }
+    if (maxLds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); amos_orb_destroy(h); return AMOS_ERR_DEVICE; }
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { set_error("create sync: %s", hipGetErrorString(e)); amos_orb_destroy(h); return AMOS_ERR_DEVICE; }
+    *out = h;
+    return AMOS_OK;
+}
+
+void amos_orb_destroy(amos_orb *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->dGeom, h->dCells, h->dTaps, h->dTiles, h->dPyr, h->dBlur, h->dInput, h->dSlotCount, h->dSlots, h->dPts,
+                    h->dNodeOf, h->dQuadOf, h->dCandCount, h->dLvCount, h->dOutCount, h->dLvKps, h->dOutKps, h->dOutDesc,
+                    h->dRemoved, h->dScratchKps, h->dMask, h->dMaskTmp, h->dMaskClosed, h->dLabels, h->dCenterIds, h->dRm,
+                    h->dNRemoved, h->dErr};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int amos_orb_tables(const amos_orb *h, float *scale_factor, float *inv_scale_factor, float *level_sigma2,
+                    float *inv_level_sigma2, int32_t *features_per_level, int32_t *umax)
+{
+    if (!h) return AMOS_ERR_INVALID;
+    for (int i = 0; i < h->p.n_levels; i++) {
+        if (scale_factor) scale_factor[i] = h->scale[i];
+        if (inv_scale_factor) inv_scale_factor[i] = h->invScale[i];
+        if (level_sigma2) level_sigma2[i] = h->sigma2[i];
+        if (inv_level_sigma2) inv_level_sigma2[i] = h->invSigma2[i];
+        if (features_per_level) features_per_level[i] = h->quota[i];
+    }
+    if (umax) for (int i = 0; i < 16; i++) umax[i] = h->umax[i];
+    return AMOS_OK;
+}
+
+int amos_orb_level_sizes(const amos_orb *h, int width, int height, int32_t *level_w, int32_t *level_h)
+{
+    if (!h) return AMOS_ERR_INVALID;
+    for (int l = 0; l < h->p.n_levels; l++) {
+        if (level_w) level_w[l] = cv_round((float)width * h->invScale[l]);
+        if (level_h) level_h[l] = cv_round((float)height * h->invScale[l]);
+    }
+    return h->p.n_levels;
+}
+
+int amos_orb_detect(amos_orb *h, const uint8_t *gray, size_t stride, int width, int height)
+{
+    if (!h || !gray || width < 1 || height < 1 || stride < (size_t)width) { set_error("amos_orb_detect: invalid argument"); return AMOS_ERR_INVALID; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    int rc = set_geometry(h, width, height);
+    if (rc != AMOS_OK) return rc;
+    AMOS_HIP_CHECK(hipMemcpy2DAsync(h->dInput, h->inputPitch, gray, stride, width, height, hipMemcpyHostToDevice, h->stream));
+    rc = launch_detect(h, h->dInput, 0, h->inputPitch, 1);
+    if (rc != AMOS_OK) return rc;
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return AMOS_OK;
+}
+
+int amos_orb_level_count(amos_orb *h, int frame, int level)
+{
+    if (!h || !h->detected || frame < 0 || frame >= h->nFrames || level < 0 || level >= h->geom.nLevels) { set_error("amos_orb_level_count: invalid argument or state"); return AMOS_ERR_INVALID; }
+    int n = 0;
+    AMOS_HIP_CHECK(hipMemcpyAsync(&n, h->dLvCount + frame * h->geom.nLevels + level, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return n;
+}
+
+int amos_orb_level_keypoints(amos_orb *h, int frame, int level, amos_keypoint *out, int cap)
+{
+    const int n = amos_orb_level_count(h, frame, level);
+    if (n < 0) return n;
+    if (n > cap || (!out && n > 0)) { set_error("level holds %d keypoints, caller capacity %d", n, cap); return AMOS_ERR_CAPACITY; }
+    if (n > 0) {
+        AMOS_HIP_CHECK(hipMemcpyAsync(out, h->dLvKps + (size_t)frame * h->geom.kpLevelTotal + h->geom.lv[level].kpOff,
+                                      sizeof(amos_keypoint) * n, hipMemcpyDeviceToHost, h->stream));
+        AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
+    return n;
+}
+
+int amos_orb_set_level_keypoints(amos_orb *h, int frame, int level, const amos_keypoint *kps, int n)
+{
+    if (!h || !h->detected || frame < 0 || frame >= h->nFrames || level < 0 || level >= h->geom.nLevels || n < 0 || (n > 0 && !kps)) {
+        set_error("amos_orb_set_level_keypoints: invalid argument or state");
+        return AMOS_ERR_INVALID;
+    }
+    if (n > h->geom.lv[level].nodeCap) { set_error("level %d list capacity %d < %d", level, h->geom.lv[level].nodeCap, n); return AMOS_ERR_CAPACITY; }
+    if (n > 0)
+        AMOS_HIP_CHECK(hipMemcpyAsync(h->dLvKps + (size_t)frame * h->geom.kpLevelTotal + h->geom.lv[level].kpOff, kps,
+                                      sizeof(amos_keypoint) * n, hipMemcpyHostToDevice, h->stream));
+    AMOS_HIP_CHECK(hipMemcpyAsync(h->dLvCount + frame * h->geom.nLevels + level, &n, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return AMOS_OK;
+}
+
+int amos_orb_level_candidates(amos_orb *h, int frame, int level, amos_keypoint *out, int cap)
+{
+    if (!h || !h->detected || frame < 0 || frame >= h->nFrames || level < 0 || level >= h->geom.nLevels) { set_error("amos_orb_level_candidates: invalid argument or state"); return AMOS_ERR_INVALID; }
+    int n = 0;
+    AMOS_HIP_CHECK(hipMemcpyAsync(&n, h->dCandCount + frame * h->geom.nLevels + level, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (n > cap) { set_error("level holds %d candidates, caller capacity %d", n, cap); return AMOS_ERR_CAPACITY; }
+    if (n > 0) {
+        hipLaunchKernelGGL(k_unpack_candidates, dim3((n + 255) / 256), dim3(256), 0, h->stream,
+                           h->dPts + (size_t)frame * h->geom.ptsTotal + h->geom.lv[level].ptsOff, n, h->dScratchKps);
+        AMOS_HIP_CHECK(hipMemcpyAsync(out, h->dScratchKps, sizeof(amos_keypoint) * n, hipMemcpyDeviceToHost, h->stream));
+        AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
+    return n;
+}
+
+int amos_orb_gate(amos_orb *h, const uint8_t *mask, size_t mask_stride, const double *labels, size_t lstride,
+                  const int32_t *center_ids, int n_centers, const int32_t *rm_vector, int n_rm, amos_keypoint *removed,
+                  int cap, int *n_removed)
+{
+    if (!h || !mask || !n_removed) { set_error("amos_orb_gate: invalid argument"); return AMOS_ERR_INVALID; }
+    if (!h->detected) { set_error("amos_orb_gate before amos_orb_detect"); return AMOS_ERR_STATE; }
+    if (labels && (!center_ids || !rm_vector || n_centers < 1 || n_rm < 1)) { set_error("amos_orb_gate: label gate needs center ids and rm_vector"); return AMOS_ERR_INVALID; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    const Geom &g = h->geom;
+    AMOS_HIP_CHECK(hipMemcpy2DAsync(h->dMask, h->maskPitch, mask, mask_stride, g.W, g.H, hipMemcpyHostToDevice, h->stream));
+    if (labels) {
+        AMOS_HIP_CHECK(hipMemcpy2DAsync(h->dLabels, sizeof(double) * g.W, labels, sizeof(double) * lstride, sizeof(double) * g.W, g.H,
+                                        hipMemcpyHostToDevice, h->stream));
+        if (n_centers > h->capCenters) {
+            if (h->dCenterIds) (void)hipFree(h->dCenterIds);
+            h->dCenterIds = nullptr;
+            int rc = dev_alloc(&h->dCenterIds, n_centers);
+            if (rc != AMOS_OK) return rc;
+            h->capCenters = n_centers;
+        }
+        if (n_rm > h->capRm) {
+            if (h->dRm) (void)hipFree(h->dRm);
+            h->dRm = nullptr;
+            int rc = dev_alloc(&h->dRm, n_rm);
+            if (rc != AMOS_OK) return rc;
+            h->capRm = n_rm;
+        }
+        AMOS_HIP_CHECK(hipMemcpyAsync(h->dCenterIds, center_ids, sizeof(int) * n_centers, hipMemcpyHostToDevice, h->stream));
+        AMOS_HIP_CHECK(hipMemcpyAsync(h->dRm, rm_vector, sizeof(int) * n_rm, hipMemcpyHostToDevice, h->stream));
+    }
+    AMOS_HIP_CHECK(hipMemsetAsync(h->dErr, 0, sizeof(int), h->stream));
+    dim3 grid((g.W + 63) / 64, (g.H + 15) / 16);
+    hipLaunchKernelGGL(k_morph31<true>, grid, dim3(256), 0, h->stream, h->dMask, h->dMaskTmp, g.W, g.H, h->maskPitch);
+    hipLaunchKernelGGL(k_morph31<false>, grid, dim3(256), 0, h->stream, h->dMaskTmp, h->dMaskClosed, g.W, g.H, h->maskPitch);
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(256), 0, h->stream, h->dGeom, h->dLvKps, h->dLvCount, h->dMaskClosed, h->maskPitch,
+                       labels ? h->dLabels : nullptr, g.W, h->dCenterIds, n_centers, h->dRm, n_rm, h->dRemoved, h->dNRemoved, h->dErr);
+    AMOS_HIP_CHECK(hipGetLastError());
+    int nrem = 0, err = 0;
+    AMOS_HIP_CHECK(hipMemcpyAsync(&nrem, h->dNRemoved, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    AMOS_HIP_CHECK(hipMemcpyAsync(&err, h->dErr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->gated = true;
+    if (err) { set_error("amos_orb_gate: %s", (err & 1) ? "keypoint outside the mask" : "label / cluster id out of range"); return AMOS_ERR_INVALID; }
+    *n_removed = nrem;
+    if (removed) {
+        if (nrem > cap) { set_error("%d keypoints removed, caller capacity %d", nrem, cap); return AMOS_ERR_CAPACITY; }
+        if (nrem > 0) {
+            AMOS_HIP_CHECK(hipMemcpyAsync(removed, h->dRemoved, sizeof(amos_keypoint) * nrem, hipMemcpyDeviceToHost, h->stream));
+            AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+        }
+    }
+    return AMOS_OK;
+}
+
+int amos_orb_closed_mask(amos_orb *h, uint8_t *dst, size_t dst_stride)
+{
+    if (!h || !dst || !h->gated) { set_error("amos_orb_closed_mask: no gate has run"); return AMOS_ERR_STATE; }
+    AMOS_HIP_CHECK(hipMemcpy2DAsync(dst, dst_stride, h->dMaskClosed, h->maskPitch, h->geom.W, h->geom.H, hipMemcpyDeviceToHost, h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return AMOS_OK;
+}
+
+int amos_orb_describe(amos_orb *h, amos_keypoint *kps, uint8_t *desc, int cap, int *n)
+{
+    if (!h || !n) { set_error("amos_orb_describe: invalid argument"); return AMOS_ERR_INVALID; }
+    if (!h->detected) { set_error("amos_orb_describe before amos_orb_detect"); return AMOS_ERR_STATE; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    int rc = launch_describe(h, 1);
+    if (rc != AMOS_OK) return rc;
+    return fetch_frame(h, 0, kps, desc, cap, n);
+}
+
+int amos_orb_extract(amos_orb *h, const uint8_t *gray, size_t stride, int width, int height, amos_keypoint *kps,
+                     uint8_t *desc, int cap, int *n)
+{
+    if (!h || !gray || !n || width < 1 || height < 1 || stride < (size_t)width) { set_error("amos_orb_extract: invalid argument"); return AMOS_ERR_INVALID; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    int rc = set_geometry(h, width, height);
+    if (rc != AMOS_OK) return rc;
+    AMOS_HIP_CHECK(hipMemcpy2DAsync(h->dInput, h->inputPitch, gray, stride, width, height, hipMemcpyHostToDevice, h->stream));
+    rc = launch_detect(h, h->dInput, 0, h->inputPitch, 1);
+    if (rc != AMOS_OK) return rc;
+    rc = launch_describe(h, 1);
+    if (rc != AMOS_OK) return rc;
+    return fetch_frame(h, 0, kps, desc, cap, n);
+}
+
+static int copy_plane(amos_orb *h, const uint8_t *dBase, int frame, int level, uint8_t *dst, size_t dst_stride, int padded)
+{
+    const Geom &g = h->geom;
+    const LevelGeom &lg = g.lv[level];
+    const uint8_t *origin = dBase + (size_t)frame * g.frameBytes + lg.planeOff + (size_t)kEdge * lg.stride + kPadLeft;
+    if (padded)
+        AMOS_HIP_CHECK(hipMemcpy2DAsync(dst, dst_stride, origin - (size_t)kEdge * lg.stride - kEdge, lg.stride, lg.w + 2 * kEdge,
+                                        lg.h + 2 * kEdge, hipMemcpyDeviceToHost, h->stream));
+    else
+        AMOS_HIP_CHECK(hipMemcpy2DAsync(dst, dst_stride, origin, lg.stride, lg.w, lg.h, hipMemcpyDeviceToHost, h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return AMOS_OK;
+}
+
+int amos_orb_level_image(amos_orb *h, int frame, int level, uint8_t *dst, size_t dst_stride, int padded)
+{
+    if (!h || !dst || !h->detected || frame < 0 || frame >= h->nFrames || level < 0 || level >= h->geom.nLevels) { set_error("amos_orb_level_image: invalid argument or state"); return AMOS_ERR_INVALID; }
+    return copy_plane(h, h->dPyr, frame, level, dst, dst_stride, padded);
+}
+
+int amos_orb_blurred_image(amos_orb *h, int frame, int level, uint8_t *dst, size_t dst_stride)
+{
+    if (!h || !dst || !h->described || frame < 0 || frame >= h->nFrames || level < 0 || level >= h->geom.nLevels) { set_error("amos_orb_blurred_image: invalid argument or state"); return AMOS_ERR_INVALID; }
+    return copy_plane(h, h->dBlur, frame, level, dst, dst_stride, 0);
+}
+
+int amos_orb_extract_batch_device(amos_orb *h, const uint8_t *d_gray, size_t frame_stride, size_t row_stride, int width,
+                                  int height, int n_frames)
+{
+    if (!h || !d_gray || n_frames < 1 || width < 1 || height < 1 || row_stride < (size_t)width) { set_error("amos_orb_extract_batch_device: invalid argument"); return AMOS_ERR_INVALID; }
+    if (n_frames > h->maxB) { set_error("batch of %d frames exceeds the handle's max_batch %d", n_frames, h->maxB); return AMOS_ERR_CAPACITY; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    int rc = set_geometry(h, width, height);
+    if (rc != AMOS_OK) return rc;
+    rc = launch_detect(h, d_gray, frame_stride, row_stride, n_frames);
+    if (rc != AMOS_OK) return rc;
+    return launch_describe(h, n_frames);
+}
+
+int amos_orb_batch_results_device(amos_orb *h, const amos_keypoint **d_kps, const uint8_t **d_desc, const int32_t **d_counts,
+                                  int *capacity)
+{
+    if (!h) return AMOS_ERR_INVALID;
+    if (d_kps) *d_kps = h->dOutKps;
+    if (d_desc) *d_desc = h->dOutDesc;
+    if (d_counts) *d_counts = h->dOutCount;
+    if (capacity) *capacity = h->capGeom.kpCap;
+    return AMOS_OK;
+}
+
+int amos_orb_batch_fetch(amos_orb *h, int frame, amos_keypoint *kps, uint8_t *desc, int cap, int *n)
+{
+    if (!h || !h->described || frame < 0 || frame >= h->nFrames) { set_error("amos_orb_batch_fetch: invalid argument or state"); return AMOS_ERR_INVALID; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    return fetch_frame(h, frame, kps, desc, cap, n);
+}
+
+int amos_orb_sync(amos_orb *h)
+{
+    if (!h) return AMOS_ERR_INVALID;
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return AMOS_OK;
+}
+
+void *amos_orb_stream(amos_orb *h) { return h ? (void *)h->stream : nullptr; }
+
+}  // extern "C"

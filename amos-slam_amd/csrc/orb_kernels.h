@@ -1,0 +1,900 @@
+// orb_kernels.h -- CDNA4 (gfx950) device code of the ORB extractor hot path.
+//
+// Integer / bitwise work, HBM- and LDS-bound: no MFMA anywhere.  wave = 64 lanes throughout.
+// Every kernel takes a batch of frames (blockIdx.y or .z = frame) so a launch fills the chip's
+// 256 CUs; a single frame is the batch-of-one case of the same code.
+//
+// Compiled with -ffp-contract=off; the only fused operations are the explicit __fmaf_rn calls in
+// k_describe, which restate the FMA the reference binary executes.
+#pragma once
+#include "amos_common.h"
+#include "../../include/amos_orb_pattern.h"
+
+namespace amos {
+
+__constant__ signed char c_pattern[1024];
+// umax of the 31-px circular patch, ORBextractor.cc:579-608 (recomputed and checked on the host)
+__constant__ int c_umax[16];
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    // single reflection: callers keep |overshoot| <= 19 < n
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+__device__ __forceinline__ const uint8_t *level_origin(const uint8_t *pyr, const Geom *g, int frame, int level)
+{
+    const LevelGeom &lg = g->lv[level];
+    return pyr + (size_t)frame * g->frameBytes + lg.planeOff + (size_t)kEdge * lg.stride + kPadLeft;
+}
+__device__ __forceinline__ uint8_t *level_origin(uint8_t *pyr, const Geom *g, int frame, int level)
+{
+    const LevelGeom &lg = g->lv[level];
+    return pyr + (size_t)frame * g->frameBytes + lg.planeOff + (size_t)kEdge * lg.stride + kPadLeft;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a2  ORBextractor::ComputePyramid, ORBextractor.cc:1826-1886.
+// One launch per level (level l needs level l-1 complete).  A thread produces 4 horizontally
+// adjacent bytes of the PADDED plane -- interior pixels by cv::resize's 11-bit fixed-point
+// bilinear, border pixels by evaluating the same formula at the reflect-101 source
+// coordinate -- and stores them as one aligned dword.
+// grid = (ceil(groups/64), ceil((h+38)/4), frames), block = (64, 4).
+template <bool kLevel0>
+__global__ __launch_bounds__(256) void k_pyramid_level(const uint8_t *__restrict__ src, size_t srcFrameStride,
+                                                      size_t srcRowStride, uint8_t *__restrict__ pyr,
+                                                      const Geom *__restrict__ g,
+                                                      const ResizeTap *__restrict__ taps, int level)
+{
+    const LevelGeom &lg = g->lv[level];
+    const int frame = blockIdx.z;
+    const int gx = blockIdx.x * 64 + threadIdx.x;    // dword column, starts at x = -kPadLeft
+    const int yo = blockIdx.y * 4 + threadIdx.y - kEdge;
+    const int groups = (kPadLeft + lg.w + kEdge + 3) >> 2;
+    if (gx >= groups || yo >= lg.h + kEdge) return;
+    const int yi = reflect101(yo, lg.h);
+    uint8_t *dst = level_origin(pyr, g, frame, level) + (ptrdiff_t)yo * lg.stride + (gx * 4 - kPadLeft);
+    uint32_t packed = 0;
+    if (kLevel0) {
+        const uint8_t *s = src + (size_t)frame * srcFrameStride + (size_t)yi * srcRowStride;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int xo = gx * 4 - kPadLeft + k;
+            xo = xo < -kEdge ? -kEdge : (xo > lg.w + kEdge - 1 ? lg.w + kEdge - 1 : xo);
+            packed |= (uint32_t)s[reflect101(xo, lg.w)] << (8 * k);
+        }
+    } else {
+        const LevelGeom &pg = g->lv[level - 1];
+        const uint8_t *prev = level_origin((const uint8_t *)pyr, g, frame, level - 1);
+        const ResizeTap ty = taps[lg.tabY + yi];
+        const uint8_t *S0 = prev + (ptrdiff_t)ty.ofs * pg.stride;
+        const uint8_t *S1 = prev + (ptrdiff_t)ty.ofs1 * pg.stride;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int xo = gx * 4 - kPadLeft + k;
+            xo = xo < -kEdge ? -kEdge : (xo > lg.w + kEdge - 1 ? lg.w + kEdge - 1 : xo);
+            const ResizeTap tx = taps[lg.tabX + reflect101(xo, lg.w)];
+            const int h0 = S0[tx.ofs] * tx.a0 + S0[tx.ofs1] * tx.a1;
+            const int h1 = S1[tx.ofs] * tx.a0 + S1[tx.ofs1] * tx.a1;
+            const int v = (((ty.a0 * (h0 >> 4)) >> 16) + ((ty.a1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t *>(dst) = packed;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a3  per-cell cv::FAST(…, TYPE_9_16, nonmax) with the iniThFAST -> minThFAST fallback,
+// ORBextractor.cc:1089-1157, SURVEY A.3.
+//
+// For a corner the OpenCV score (cornerScore<16>) does not depend on the threshold:
+//   score = A - 1,  A = max( max_arcs min_k(v - p_k), max_arcs min_k(p_k - v) ),  corner(t) <=> A > t.
+// So one byte map of A (clamped at 0) per cell serves both thresholds; a pixel survives the 3x3
+// non-max suppression at threshold t iff A > t and every in-cell neighbour has A_n <= t or A_n < A
+// (scores outside the cell's tested region are 0 in OpenCV's row buffers).
+__device__ __forceinline__ int fast_arc_value(const uint8_t *c, int s)
+{
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * s];       d[1] = v - c[3 * s + 1];   d[2] = v - c[2 * s + 2];   d[3] = v - c[s + 3];
+    d[4] = v - c[3];           d[5] = v - c[-s + 3];      d[6] = v - c[-2 * s + 2];  d[7] = v - c[-3 * s + 1];
+    d[8] = v - c[-3 * s];      d[9] = v - c[-3 * s - 1];  d[10] = v - c[-2 * s - 2]; d[11] = v - c[-s - 3];
+    d[12] = v - c[-3];         d[13] = v - c[s - 3];      d[14] = v - c[2 * s - 2];  d[15] = v - c[3 * s - 1];
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo2[k] = min(d[k], d[(k + 1) & 15]);
+        hi2[k] = max(d[k], d[(k + 1) & 15]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+        hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+    }
+    int dark = -255, bright = 255;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        // 9 contiguous: 8 from two groups of four, plus the ninth
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        dark = max(dark, lo9);      // max over arcs of min(v - p)
+        bright = min(bright, hi9);  // min over arcs of max(v - p) = -(max over arcs of min(p - v))
+    }
+    return max(max(dark, -bright), 0);
+}
+
+constexpr int kFastTileStride = 68;  // cell + 6 halo <= 65 columns
+constexpr int kFastMapStride = 64;   // cell + 2 halo <= 61 columns
+constexpr int kFastMaxCell = 59;
+
+__device__ __forceinline__ bool fast_keep(const uint8_t *m, int t)
+{
+    const int a = m[0];
+    if (a <= t) return false;
+    const int s = kFastMapStride;
+    int n;
+    n = m[-s - 1]; if (n > t && n >= a) return false;
+    n = m[-s];     if (n > t && n >= a) return false;
+    n = m[-s + 1]; if (n > t && n >= a) return false;
+    n = m[-1];     if (n > t && n >= a) return false;
+    n = m[1];      if (n > t && n >= a) return false;
+    n = m[s - 1];  if (n > t && n >= a) return false;
+    n = m[s];      if (n > t && n >= a) return false;
+    n = m[s + 1];  if (n > t && n >= a) return false;
+    return true;
+}
+
+// grid = (totalCells, frames), block = 256.  Candidates of a cell are written in FAST's order
+// (row-major) to the cell's own slot range: packed x | y << 12 | score << 24, coordinates relative
+// to (minBorderX, minBorderY) as the reference hands them to DistributeOctTree.
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
+                                                   const Cell *__restrict__ cells, int *__restrict__ slotCount,
+                                                   uint32_t *__restrict__ slots)
+{
+    __shared__ uint8_t tile[(kFastMaxCell + 6) * kFastTileStride];
+    __shared__ uint8_t amap[(kFastMaxCell + 2) * kFastMapStride];
+    __shared__ int wcount[4];
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.y;
+    const Cell c = cells[blockIdx.x];
+    const LevelGeom &lg = g->lv[c.level];
+    const uint8_t *img = level_origin(pyr, g, frame, c.level);
+    const int tw = c.tw, th = c.th;
+    const int lw = tw + 6, lh = th + 6;
+    for (int idx = tid; idx < lw * lh; idx += 256) {
+        const int r = idx / lw, cc = idx - r * lw;
+        tile[r * kFastTileStride + cc] = img[(ptrdiff_t)(c.y0 - 3 + r) * lg.stride + (c.x0 - 3 + cc)];
+    }
+    for (int idx = tid; idx < (th + 2) * kFastMapStride; idx += 256) amap[idx] = 0;
+    __syncthreads();
+    const int npix = tw * th;
+    for (int p = tid; p < npix; p += 256) {
+        const int y = p / tw, x = p - y * tw;
+        amap[(y + 1) * kFastMapStride + x + 1] =
+            (uint8_t)fast_arc_value(&tile[(y + 3) * kFastTileStride + x + 3], kFastTileStride);
+    }
+    __syncthreads();
+    const int iniTh = min(max(g->iniTh, 0), 255), minTh = min(max(g->minTh, 0), 255);
+    int any = 0;
+    for (int p = tid; p < npix; p += 256) {
+        const int y = p / tw, x = p - y * tw;
+        any |= fast_keep(&amap[(y + 1) * kFastMapStride + x + 1], iniTh);
+    }
+    const int t = __syncthreads_or(any) ? iniTh : minTh;  // retry only if the cell came back EMPTY
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t *out = slots + (size_t)frame * g->slotTotal + c.slotOff;
+    int base = 0;
+    for (int p0 = 0; p0 < npix; p0 += 256) {
+        const int p = p0 + tid;
+        bool keep = false;
+        int x = 0, y = 0;
+        if (p < npix) {
+            y = p / tw;
+            x = p - y * tw;
+            keep = fast_keep(&amap[(y + 1) * kFastMapStride + x + 1], t);
+        }
+        const unsigned long long ballot = __ballot(keep);
+        if (lane == 0) wcount[wave] = __popcll(ballot);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; w++) off += wcount[w];
+        if (keep) {
+            off += __popcll(ballot & ((1ull << lane) - 1ull));
+            const int score = amap[(y + 1) * kFastMapStride + x + 1] - 1;
+            const int xr = c.x0 + x - kMinBorder, yr = c.y0 + y - kMinBorder;
+            out[off] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)score << 24);
+        }
+        base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    if (tid == 0) slotCount[(size_t)frame * g->totalCells + blockIdx.x] = base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a4 + a5  ORBextractor::DistributeOctTree (ORBextractor.cc:706-1049) and the fix-up at :1175-1190.
+//
+// One work-group per (frame, level).  The reference walks a std::list and moves keypoints between
+// per-node vectors; here every candidate keeps an index into the CURRENT node list and a pass over
+// the candidates counts children per quadrant with LDS atomics.  The list order the reference
+// produces is reproduced analytically:
+//   * a full pass replaces every multi-point node by its non-empty children, push_front'ed in the
+//     order n1..n4 while walking front to back  =>  new list = reverse(creation order) ++ the old
+//     single-point nodes in their old order;
+//   * the final passes (ORBextractor.cc:936-1020) divide nodes in descending (count, address) order
+//     until the list holds N nodes; heap addresses are replaced by creation order.
+// The result keeps, per node, the candidate of maximal response, first in input order on ties.
+struct OctNode {
+    short x0, y0, x1, y1;
+};
+
+__device__ __forceinline__ int block_excl_scan(int *a, int n, int *part)
+{
+    const int tid = threadIdx.x;
+    const int chunk = (n + 255) >> 8;
+    const int b = min(tid * chunk, n), e = min(b + chunk, n);
+    int s = 0;
+    for (int i = b; i < e; i++) s += a[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    const int total = part[255];
+    for (int i = b; i < e; i++) {
+        const int t = a[i];
+        a[i] = run;
+        run += t;
+    }
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ int oct_quadrant(const OctNode &b, int x, int y, int &midx, int &midy)
+{
+    midx = b.x0 + ((b.x1 - b.x0 + 1) >> 1);  // ceil(float(UR.x-UL.x)/2), ORBextractor.cc:641
+    midy = b.y0 + ((b.y1 - b.y0 + 1) >> 1);
+    return (x < midx) ? ((y < midy) ? 0 : 2) : ((y < midy) ? 1 : 3);
+}
+
+__device__ __forceinline__ OctNode oct_child(const OctNode &b, int q, int midx, int midy)
+{
+    OctNode c;
+    c.x0 = (q & 1) ? midx : b.x0;
+    c.x1 = (q & 1) ? b.x1 : midx;
+    c.y0 = (q & 2) ? midy : b.y0;
+    c.y1 = (q & 2) ? b.y1 : midy;
+    return c;
+}
+
+struct OctLds {
+    int *cnt[2];
+    int *seq[2];
+    OctNode *box[2];
+    uint8_t *noMore[2];
+    int *child;   // [4*NC] child counts, then child positions in the new list
+    int *newPos;  // [NC]
+    int *scanA;   // [SC]
+    int *scanB;   // [NC]
+    int *order;   // [NC]
+    unsigned *best;
+    int *part;    // [256]
+    int *vars;    // [16]
+};
+
+__host__ __device__ inline size_t oct_lds_bytes(int NC, int SC)
+{
+    return (size_t)NC * (2 * 4 + 2 * 4 + 2 * 8 + 4 * 4 + 4 + 4 + 4 + 4) + (size_t)((2 * NC + 15) & ~15) +
+           (size_t)SC * 4 + 256 * 4 + 16 * 4 + 64;
+}
+
+__device__ inline OctLds oct_carve(unsigned char *base, int NC, int SC)
+{
+    OctLds L;
+    int *ip = reinterpret_cast<int *>(base);
+    L.cnt[0] = ip; ip += NC;
+    L.cnt[1] = ip; ip += NC;
+    L.seq[0] = ip; ip += NC;
+    L.seq[1] = ip; ip += NC;
+    L.box[0] = reinterpret_cast<OctNode *>(ip); ip += 2 * NC;
+    L.box[1] = reinterpret_cast<OctNode *>(ip); ip += 2 * NC;
+    L.child = ip; ip += 4 * NC;
+    L.newPos = ip; ip += NC;
+    L.scanA = ip; ip += SC;
+    L.scanB = ip; ip += NC;
+    L.order = ip; ip += NC;
+    L.best = reinterpret_cast<unsigned *>(ip); ip += NC;
+    L.part = ip; ip += 256;
+    L.vars = ip; ip += 16;
+    uint8_t *bp = reinterpret_cast<uint8_t *>(ip);
+    L.noMore[0] = bp; bp += NC;
+    L.noMore[1] = bp;
+    return L;
+}
+
+// vars[] slots
+enum { V_SIZE = 0, V_NEXPAND = 1, V_RSTAR = 2, V_NCAND = 3 };
+
+// grid = frames * nLevels, block = 256, dynamic LDS = oct_lds_bytes(NC, SC).
+__global__ __launch_bounds__(256) void k_octree(const Geom *__restrict__ g, const Cell *__restrict__ cells,
+                                               const int *__restrict__ slotCount,
+                                               const uint32_t *__restrict__ slots, uint32_t *__restrict__ pts,
+                                               uint16_t *__restrict__ nodeOf, uint8_t *__restrict__ quadOf,
+                                               int *__restrict__ candCount, amos_keypoint *__restrict__ lvKps,
+                                               int *__restrict__ lvCount, int NC, int SC)
+{
+    extern __shared__ __align__(16) unsigned char oct_smem[];
+    const OctLds L = oct_carve(oct_smem, NC, SC);
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x / g->nLevels, level = blockIdx.x - frame * g->nLevels;
+    const LevelGeom &lg = g->lv[level];
+    const int N = lg.quota;
+
+    // ---- 1. candidates of the level in the reference's order: cells row-major, FAST order inside
+    const int *sc = slotCount + (size_t)frame * g->totalCells + lg.cellStart;
+    for (int c = tid; c < lg.nCells; c += 256) L.scanA[c] = sc[c];
+    __syncthreads();
+    const int n = block_excl_scan(L.scanA, lg.nCells, L.part);
+    uint32_t *P = pts + (size_t)frame * g->ptsTotal + lg.ptsOff;
+    uint16_t *nodeIdx = nodeOf + (size_t)frame * g->ptsTotal + lg.ptsOff;
+    uint8_t *quad = quadOf + (size_t)frame * g->ptsTotal + lg.ptsOff;
+    for (int c = tid; c < lg.nCells; c += 256) {
+        const int cnt = sc[c], off = L.scanA[c];
+        const uint32_t *s = slots + (size_t)frame * g->slotTotal + cells[lg.cellStart + c].slotOff;
+        for (int k = 0; k < cnt; k++) P[off + k] = s[k];
+    }
+    if (tid == 0) candCount[frame * g->nLevels + level] = n;
+
+    // ---- 2. root nodes, ORBextractor.cc:718-786
+    const int spanX = lg.maxBX - kMinBorder, spanY = lg.maxBY - kMinBorder;
+    const int nIni = lg.nIni;
+    const float hX = __fdiv_rn((float)spanX, (float)nIni);
+    for (int i = tid; i < nIni; i += 256) L.cnt[0][i] = 0;
+    __syncthreads();  // also orders the P[] writes above before the reads below (same block)
+    for (int i = tid; i < n; i += 256) {
+        const int x = P[i] & 0xfff;
+        int idx = (int)__fdiv_rn((float)x, hX);
+        idx = min(max(idx, 0), nIni - 1);
+        nodeIdx[i] = (uint16_t)idx;
+        atomicAdd(&L.cnt[0][idx], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int size = 0;
+        for (int i = 0; i < nIni; i++) {
+            const int c = L.cnt[0][i];
+            L.newPos[i] = size;
+            if (c > 0) {
+                OctNode b;
+                b.x0 = (short)(int)__fmul_rn(hX, (float)i);
+                b.x1 = (short)(int)__fmul_rn(hX, (float)(i + 1));
+                b.y0 = 0;
+                b.y1 = (short)spanY;
+                L.box[1][size] = b;
+                L.cnt[1][size] = c;
+                L.seq[1][size] = i;
+                L.noMore[1][size] = (c == 1);
+                size++;
+            }
+        }
+        L.vars[V_SIZE] = size;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) nodeIdx[i] = (uint16_t)L.newPos[nodeIdx[i]];
+    int cur = 1;
+    int size = L.vars[V_SIZE];
+    int seqBase = nIni;
+    __syncthreads();
+
+    // ---- 3. subdivision, ORBextractor.cc:800-1021
+    bool finalPhase = false;
+    for (;;) {
+        const int prevSize = size;
+        const int nxt = cur ^ 1;
+        // children per quadrant of every multi-point node
+        for (int i = tid; i < 4 * size; i += 256) L.child[i] = 0;
+        if (tid == 0) { L.vars[V_NEXPAND] = 0; L.vars[V_RSTAR] = 0x7fffffff; L.vars[V_NCAND] = 0; }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const int nd = nodeIdx[i];
+            if (!L.noMore[cur][nd]) {
+                const uint32_t p = P[i];
+                int mx, my;
+                const int q = oct_quadrant(L.box[cur][nd], p & 0xfff, (p >> 12) & 0xfff, mx, my);
+                quad[i] = (uint8_t)q;
+                atomicAdd(&L.child[nd * 4 + q], 1);
+            }
+        }
+        __syncthreads();
+
+        int nDiv;  // how many candidates get divided in this pass, in processing order
+        if (!finalPhase) {
+            // processing order = list order; every multi-point node is divided
+            for (int i = tid; i < size; i += 256) L.order[i] = i;
+            nDiv = size;  // (single-point nodes contribute no children)
+            __syncthreads();
+        } else {
+            // candidates = multi-point nodes, processed in descending (count, creation order)
+            for (int i = tid; i < size; i += 256) {
+                if (!L.noMore[cur][i]) {
+                    const int ci = L.cnt[cur][i], si = L.seq[cur][i];
+                    int rank = 0;
+                    for (int j = 0; j < size; j++) {
+                        if (L.noMore[cur][j]) continue;
+                        const int cj = L.cnt[cur][j];
+                        rank += (cj > ci) || (cj == ci && L.seq[cur][j] > si);
+                    }
+                    L.order[rank] = i;
+                    atomicAdd(&L.vars[V_NCAND], 1);
+                }
+            }
+            __syncthreads();
+            const int m = L.vars[V_NCAND];
+            // growth of the list along the processing order; stop right after reaching N (:1003)
+            for (int r = tid; r < m; r += 256) {
+                const int *ch = &L.child[L.order[r] * 4];
+                L.scanA[r] = (ch[0] > 0) + (ch[1] > 0) + (ch[2] > 0) + (ch[3] > 0) - 1;
+            }
+            __syncthreads();
+            for (int r = tid; r < m; r += 256) L.scanB[r] = L.scanA[r];
+            __syncthreads();
+            block_excl_scan(L.scanA, m, L.part);
+            for (int r = tid; r < m; r += 256)
+                if (prevSize + L.scanA[r] + L.scanB[r] >= N) atomicMin(&L.vars[V_RSTAR], r);
+            __syncthreads();
+            const int rstar = L.vars[V_RSTAR];
+            nDiv = rstar == 0x7fffffff ? m : rstar + 1;
+        }
+
+        // creation order of the children along the processing order
+        for (int r = tid; r < nDiv; r += 256) {
+            const int i = L.order[r];
+            int nz = 0;
+            if (!L.noMore[cur][i]) {
+                const int *ch = &L.child[i * 4];
+                nz = (ch[0] > 0) + (ch[1] > 0) + (ch[2] > 0) + (ch[3] > 0);
+            }
+            L.scanA[r] = nz;
+        }
+        // survivors (not divided) keep their relative order behind the new children
+        for (int i = tid; i < size; i += 256) L.scanB[i] = 1;
+        __syncthreads();
+        for (int r = tid; r < nDiv; r += 256)
+            if (!L.noMore[cur][L.order[r]]) L.scanB[L.order[r]] = 0;
+        __syncthreads();
+        const int K = block_excl_scan(L.scanA, nDiv, L.part);
+        const int M = block_excl_scan(L.scanB, size, L.part);
+        // build the new list
+        for (int i = tid; i < size; i += 256) {
+            // scanB[i] is exclusive; a survivor is one whose own flag was 1
+            const bool survivor = (i + 1 < size ? L.scanB[i + 1] : M) != L.scanB[i];
+            if (survivor) {
+                const int p = K + L.scanB[i];
+                L.box[nxt][p] = L.box[cur][i];
+                L.cnt[nxt][p] = L.cnt[cur][i];
+                L.seq[nxt][p] = L.seq[cur][i];
+                L.noMore[nxt][p] = L.noMore[cur][i];
+                L.newPos[i] = p;
+            } else {
+                L.newPos[i] = -1;
+            }
+        }
+        for (int r = tid; r < nDiv; r += 256) {
+            const int i = L.order[r];
+            if (L.noMore[cur][i]) continue;
+            int ci = L.scanA[r];
+            const OctNode b = L.box[cur][i];
+            int mx, my;
+            oct_quadrant(b, 0, 0, mx, my);
+            int cc[4] = {L.child[i * 4], L.child[i * 4 + 1], L.child[i * 4 + 2], L.child[i * 4 + 3]};
+            int nex = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (cc[q] > 0) {
+                    const int p = K - 1 - ci;
+                    L.box[nxt][p] = oct_child(b, q, mx, my);
+                    L.cnt[nxt][p] = cc[q];
+                    L.seq[nxt][p] = seqBase + ci;
+                    L.noMore[nxt][p] = (cc[q] == 1);
+                    L.child[i * 4 + q] = p;
+                    nex += cc[q] > 1;
+                    ci++;
+                }
+            }
+            if (nex) atomicAdd(&L.vars[V_NEXPAND], nex);
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const int nd = nodeIdx[i];
+            const int np = L.newPos[nd];
+            nodeIdx[i] = (uint16_t)(np >= 0 ? np : L.child[nd * 4 + quad[i]]);
+        }
+        const int nToExpand = L.vars[V_NEXPAND];
+        size = K + M;
+        seqBase += K;
+        cur = nxt;
+        __syncthreads();
+        if (size >= N || size == prevSize) break;  // :917, :1014
+        if (!finalPhase) {
+            if (size + nToExpand * 3 > N) finalPhase = true;  // :936
+        }
+    }
+
+    // ---- 4. best response per node (first in input order on ties), ORBextractor.cc:1024-1046,
+    //         and the coordinate / octave / size fix-up of :1175-1190
+    for (int i = tid; i < size; i += 256) L.best[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const unsigned key = ((P[i] >> 24) << 20) | (unsigned)(0xfffff - i);
+        atomicMax(&L.best[nodeIdx[i]], key);
+    }
+    __syncthreads();
+    amos_keypoint *out = lvKps + (size_t)frame * g->kpLevelTotal + lg.kpOff;
+    for (int i = tid; i < size; i += 256) {
+        const uint32_t p = P[0xfffff - (L.best[i] & 0xfffff)];
+        amos_keypoint kp;
+        kp.x = (float)((int)(p & 0xfff) + kMinBorder);
+        kp.y = (float)((int)((p >> 12) & 0xfff) + kMinBorder);
+        kp.size = lg.patchSize;
+        kp.angle = -1.f;
+        kp.response = (float)(p >> 24);
+        kp.octave = level;
+        kp.class_id = -1;
+        out[i] = kp;
+    }
+    if (tid == 0) lvCount[frame * g->nLevels + level] = size;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a6  computeOrientation / IC_Angle (ORBextractor.cc:108-161, 618-632) + cv::fastAtan2.
+// One wave per keypoint; lanes 0-31 take row v, lanes 32-63 row v+1; integer moments are reduced
+// across the wave with DPP-style shuffles, lane 0 evaluates the float32 polynomial.
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = __fmul_rn(0.9997878412794807f, scale), p3 = __fmul_rn(-0.3258083974640975f, scale);
+    const float p5 = __fmul_rn(0.1555786518463281f, scale), p7 = __fmul_rn(-0.04432655554792128f, scale);
+    const float eps = 2.2204460492503131e-16f;  // (float)DBL_EPSILON
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+__device__ __forceinline__ int level_of_slot(const Geom *g, int slot)
+{
+    int level = -1;
+    for (int l = 0; l < g->nLevels; l++)
+        if (slot >= g->lv[l].kpOff && slot < g->lv[l].kpOff + g->lv[l].nodeCap) level = l;
+    return level;
+}
+
+// grid = (ceil(kpLevelTotal/4), frames), block = 256 (4 keypoints).
+__global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
+                                               amos_keypoint *__restrict__ lvKps, const int *__restrict__ lvCount)
+{
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int frame = blockIdx.y;
+    if (slot >= g->kpLevelTotal) return;
+    const int level = level_of_slot(g, slot);
+    if (level < 0) return;
+    const LevelGeom &lg = g->lv[level];
+    if (slot - lg.kpOff >= lvCount[frame * g->nLevels + level]) return;
+    amos_keypoint *kp = lvKps + (size_t)frame * g->kpLevelTotal + slot;
+    const int cx = __float2int_rn(kp->x), cy = __float2int_rn(kp->y);
+    const uint8_t *center = level_origin(pyr, g, frame, level) + (ptrdiff_t)cy * lg.stride + cx;
+    const int u = (lane & 31) - kHalfPatch;
+    int m10 = 0, m01 = 0;
+    for (int v0 = -kHalfPatch; v0 <= kHalfPatch; v0 += 2) {
+        const int v = v0 + (lane >> 5);
+        if (v <= kHalfPatch && u <= kHalfPatch) {
+            const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+            if (au <= c_umax[av]) {
+                const int val = center[(ptrdiff_t)v * lg.stride + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    if (lane == 0) kp->angle = fast_atan2_deg((float)m01, (float)m10);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a9 (first half)  cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101), 8-bit fixed-point path
+// (SURVEY A.2): dst = (sum_ij k_i k_j p + 32768) >> 16 with taps {18,34,48,56,48,34,18}/256.
+// The device planes already carry the 19-px reflect-101 border, so the 3-px halo is read directly.
+// One work-group = one 64x16 output tile staged through LDS; grid = (tiles, frames).
+struct BlurTile {
+    short level, x0, y0, pad;
+};
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
+                                             const Geom *__restrict__ g, const BlurTile *__restrict__ tiles)
+{
+    __shared__ uint32_t raw[22][18];      // rows y0-3..y0+18, bytes x0-4..x0+67
+    __shared__ uint16_t hbuf[22][64 + 2];
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.y;
+    const BlurTile t = tiles[blockIdx.x];
+    const LevelGeom &lg = g->lv[t.level];
+    const uint8_t *img = level_origin(pyr, g, frame, t.level);
+    for (int idx = tid; idx < 22 * 18; idx += 256) {
+        const int r = idx / 18, c = idx - r * 18;
+        const int y = min(t.y0 - 3 + r, lg.h + kEdge - 1);
+        raw[r][c] = *reinterpret_cast<const uint32_t *>(img + (ptrdiff_t)y * lg.stride + (t.x0 - 4 + 4 * c));
+    }
+    __syncthreads();
+    const uint8_t *rb = reinterpret_cast<const uint8_t *>(&raw[0][0]);
+    for (int idx = tid; idx < 22 * 64; idx += 256) {
+        const int r = idx >> 6, x = idx & 63;
+        const uint8_t *p = rb + r * 72 + x + 1;  // pixel x0 + x - 3
+        hbuf[r][x] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
+    }
+    __syncthreads();
+    const int tx = (tid & 15) * 4, ty = tid >> 4;
+    const int y = t.y0 + ty;
+    if (y >= lg.h) return;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = tx + k;
+        const uint32_t acc = 18u * (hbuf[ty][x] + hbuf[ty + 6][x]) + 34u * (hbuf[ty + 1][x] + hbuf[ty + 5][x]) +
+                             48u * (hbuf[ty + 2][x] + hbuf[ty + 4][x]) + 56u * hbuf[ty + 3][x];
+        packed |= ((acc + 32768u) >> 16) << (8 * k);
+    }
+    uint8_t *dst = level_origin(blur, g, frame, t.level) + (ptrdiff_t)y * lg.stride + t.x0 + tx;
+    if (t.x0 + tx < lg.w) *reinterpret_cast<uint32_t *>(dst) = packed;  // row stride leaves room past w
+}
+
+// ---------------------------------------------------------------------------------------------
+// sincosf exactly as glibc >= 2.28 evaluates it for |x| < 120 (ARM optimized-routines algorithm:
+// double-precision polynomials, no FMA).  The host oracle holds the same restatement and is
+// compared bit for bit with the host libm over every float in [0, 2*pi].
+__device__ __forceinline__ void glibc_sincosf(float y, float &sinp, float &cosp)
+{
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                 C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    const unsigned top = (__float_as_uint(y) >> 20) & 0x7ff;
+    double x = (double)y;
+    int n = 0;
+    double sgnc = 1.0;  // table[1] negates the cosine coefficients
+    if (top < ((__float_as_uint(0x1.921FB6p-1f) >> 20) & 0x7ff)) {
+        if (top < ((__float_as_uint(0x1p-12f) >> 20) & 0x7ff)) {
+            sinp = y;
+            cosp = 1.0f;
+            return;
+        }
+    } else {
+        const double r = __dmul_rn(x, hpi_inv);
+        n = ((int)r + 0x800000) >> 24;
+        x = __dsub_rn(x, __dmul_rn((double)n, hpi));
+        const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        if (n & 2) sgnc = -1.0;
+        // sincosf_poly(x * s, x * x, ...)
+        const double x2r = __dmul_rn(x, x);
+        x = __dmul_rn(x, s);
+        const double x2 = x2r;
+        const double x4 = __dmul_rn(x2, x2), x3 = __dmul_rn(x2, x);
+        const double c2 = __dadd_rn(sgnc * C3, __dmul_rn(x2, sgnc * C4));
+        const double s1 = __dadd_rn(S2, __dmul_rn(x2, S3));
+        const double c1 = __dadd_rn(sgnc * C0, __dmul_rn(x2, sgnc * C1));
+        const double x5 = __dmul_rn(x3, x2), x6 = __dmul_rn(x4, x2);
+        const double sv = __dadd_rn(x, __dmul_rn(x3, S1));
+        const double cv = __dadd_rn(c1, __dmul_rn(x4, sgnc * C2));
+        const float sres = (float)__dadd_rn(sv, __dmul_rn(x5, s1));
+        const float cres = (float)__dadd_rn(cv, __dmul_rn(x6, c2));
+        if (n & 1) { sinp = cres; cosp = sres; } else { sinp = sres; cosp = cres; }
+        return;
+    }
+    {
+        const double x2 = __dmul_rn(x, x);
+        const double x4 = __dmul_rn(x2, x2), x3 = __dmul_rn(x2, x);
+        const double c2 = __dadd_rn(C3, __dmul_rn(x2, C4));
+        const double s1 = __dadd_rn(S2, __dmul_rn(x2, S3));
+        const double c1 = __dadd_rn(C0, __dmul_rn(x2, C1));
+        const double x5 = __dmul_rn(x3, x2), x6 = __dmul_rn(x4, x2);
+        const double sv = __dadd_rn(x, __dmul_rn(x3, S1));
+        const double cv = __dadd_rn(c1, __dmul_rn(x4, C2));
+        sinp = (float)__dadd_rn(sv, __dmul_rn(x5, s1));
+        cosp = (float)__dadd_rn(cv, __dmul_rn(x6, c2));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a9 (second half) + a10  computeDescriptors / computeOrbDescriptor (ORBextractor.cc:173-227,
+// 1525-1540) and the level-0 rescale + concatenation of ProcessDesp (:1747-1820).
+// One wave per keypoint: lane j evaluates the four point pairs j, j+64, j+128, j+192 and four
+// __ballot()s assemble the 256 descriptor bits as four little-endian 64-bit words.
+__global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ blur, const Geom *__restrict__ g,
+                                                 const amos_keypoint *__restrict__ lvKps,
+                                                 const int *__restrict__ lvCount,
+                                                 amos_keypoint *__restrict__ outKps, uint8_t *__restrict__ outDesc,
+                                                 int *__restrict__ outCount)
+{
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int frame = blockIdx.y;
+    const int *cnt = lvCount + frame * g->nLevels;
+    if (slot == 0 && lane == 0) {
+        int total = 0;
+        for (int l = 0; l < g->nLevels; l++) total += cnt[l];
+        outCount[frame] = total;
+    }
+    if (slot >= g->kpLevelTotal) return;
+    const int level = level_of_slot(g, slot);
+    if (level < 0) return;
+    const LevelGeom &lg = g->lv[level];
+    const int i = slot - lg.kpOff;
+    if (i >= cnt[level]) return;
+    int dstIdx = i;
+    for (int l = 0; l < level; l++) dstIdx += cnt[l];
+    if (dstIdx >= g->kpCap) return;
+    amos_keypoint kp = lvKps[(size_t)frame * g->kpLevelTotal + slot];
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    glibc_sincosf(__fmul_rn(kp.angle, factorPI), b, a);
+    const uint8_t *center =
+        level_origin(blur, g, frame, level) + (ptrdiff_t)__float2int_rn(kp.y) * lg.stride + __float2int_rn(kp.x);
+    unsigned long long word[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const signed char *pt = &c_pattern[(64 * w + lane) * 4];
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int r0 = __float2int_rn(__fmaf_rn(x0, b, __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
+        const int r1 = __float2int_rn(__fmaf_rn(x1, b, __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fmaf_rn(x1, a, -__fmul_rn(y1, b)));
+        const int t0 = center[(ptrdiff_t)r0 * lg.stride + c0];
+        const int t1 = center[(ptrdiff_t)r1 * lg.stride + c1];
+        word[w] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        unsigned long long v = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
+        reinterpret_cast<unsigned long long *>(outDesc + ((size_t)frame * g->kpCap + dstIdx) * 32)[lane] = v;
+    }
+    if (lane == 0) {
+        if (level != 0) {  // keypoint->pt *= scale, ORBextractor.cc:1804-1813
+            kp.x = __fmul_rn(kp.x, lg.scale);
+            kp.y = __fmul_rn(kp.y, lg.scale);
+        }
+        outKps[(size_t)frame * g->kpCap + dstIdx] = kp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a8  ORBextractor::MovingKeyPoints (ORBextractor.cc:1688-1745): dilate then erode of the mask with
+// the 31x31 MORPH_ELLIPSE element, then the per-keypoint gate.
+__constant__ int c_ellipse_dx[31];  // half-width of every element row, host-computed
+
+// grid = (ceil(w/64), ceil(h/16)), block = 256; tile staged in LDS with the neutral value outside.
+template <bool kDilate>
+__global__ __launch_bounds__(256) void k_morph31(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w,
+                                                int h, int stride)
+{
+    __shared__ uint8_t tile[46][96];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    const uint8_t neutral = kDilate ? 0 : 255;
+    for (int idx = tid; idx < 46 * 94; idx += 256) {
+        const int r = idx / 94, c = idx - r * 94;
+        const int y = y0 - 15 + r, x = x0 - 15 + c;
+        tile[r][c] = (y >= 0 && y < h && x >= 0 && x < w) ? src[(size_t)y * stride + x] : neutral;
+    }
+    __syncthreads();
+    const int lx = tid & 63;
+    for (int ly = tid >> 6; ly < 16; ly += 4) {
+        int acc = neutral;
+        for (int i = 0; i < 31; i++) {
+            const int dx = c_ellipse_dx[i];
+            const uint8_t *row = &tile[ly + i][lx + 15];
+            for (int j = -dx; j <= dx; j++) acc = kDilate ? max(acc, (int)row[j]) : min(acc, (int)row[j]);
+        }
+        const int x = x0 + lx, y = y0 + ly;
+        if (x < w && y < h) dst[(size_t)y * stride + x] = (uint8_t)acc;
+    }
+}
+
+// One work-group per frame walks the levels in order; kept keypoints are compacted in place
+// (order preserved), removed ones appended to `removed` in the reference's order.
+__global__ __launch_bounds__(256) void k_gate(const Geom *__restrict__ g, amos_keypoint *__restrict__ lvKps,
+                                             int *__restrict__ lvCount, const uint8_t *__restrict__ closed,
+                                             int maskStride, const double *__restrict__ labels, int labelStride,
+                                             const int *__restrict__ centerIds, int nCenters,
+                                             const int *__restrict__ rm, int nRm,
+                                             amos_keypoint *__restrict__ removed, int *__restrict__ nRemoved,
+                                             int *__restrict__ errFlag)
+{
+    __shared__ int wkeep[4], wrem[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frame = blockIdx.x;
+    int remBase = 0;
+    for (int level = 0; level < g->nLevels; level++) {
+        const LevelGeom &lg = g->lv[level];
+        amos_keypoint *kps = lvKps + (size_t)frame * g->kpLevelTotal + lg.kpOff;
+        const int n = lvCount[frame * g->nLevels + level];
+        const float scale = level != 0 ? lg.scale : 1.f;
+        int keepBase = 0;
+        for (int i0 = 0; i0 < n; i0 += 256) {
+            const int i = i0 + tid;
+            amos_keypoint kp;
+            bool valid = i < n, drop = false;
+            if (valid) {
+                kp = kps[i];
+                const int ix = (int)__fmul_rn(kp.x, scale), iy = (int)__fmul_rn(kp.y, scale);
+                if (ix < 0 || iy < 0 || ix >= g->W || iy >= g->H) {
+                    atomicOr(errFlag, 1);
+                } else {
+                    if (labels) {
+                        const long ci = (long)(labels[(size_t)iy * labelStride + ix] - 1);
+                        if (ci < 0 || ci >= nCenters) atomicOr(errFlag, 2);
+                        else {
+                            const int id = centerIds[ci];
+                            if (id < 0 || id >= nRm) atomicOr(errFlag, 2);
+                            else if (rm[id] == 1) drop = true;
+                        }
+                    }
+                    if (closed[(size_t)iy * maskStride + ix] != 0) drop = true;
+                }
+            }
+            const unsigned long long bk = __ballot(valid && !drop), br = __ballot(valid && drop);
+            if (lane == 0) { wkeep[wave] = __popcll(bk); wrem[wave] = __popcll(br); }
+            __syncthreads();  // every thread has read its keypoint before anyone overwrites the list
+            int ko = keepBase, ro = remBase;
+            for (int w = 0; w < wave; w++) { ko += wkeep[w]; ro += wrem[w]; }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (valid && !drop) kps[ko + __popcll(bk & below)] = kp;
+            if (valid && drop) removed[(size_t)frame * g->kpLevelTotal + ro + __popcll(br & below)] = kp;
+            keepBase += wkeep[0] + wkeep[1] + wkeep[2] + wkeep[3];
+            remBase += wrem[0] + wrem[1] + wrem[2] + wrem[3];
+            __syncthreads();
+        }
+        if (tid == 0) lvCount[frame * g->nLevels + level] = keepBase;
+    }
+    if (tid == 0) nRemoved[frame] = remBase;
+}
+
+// Unpacks the compacted candidates of one level into amos_keypoint records (parity tests only).
+__global__ void k_unpack_candidates(const uint32_t *__restrict__ pts, int n, amos_keypoint *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = pts[i];
+    amos_keypoint kp;
+    kp.x = (float)(p & 0xfff);
+    kp.y = (float)((p >> 12) & 0xfff);
+    kp.size = 7.f;
+    kp.angle = -1.f;
+    kp.response = (float)(p >> 24);
+    kp.octave = 0;
+    kp.class_id = -1;
+    out[i] = kp;
+}
+
+}  // namespace amos

@@ -1,0 +1,196 @@
+/*
+ * amos_frontend.h -- C ABI of the MI355X-native Amos-SLAM front-end hot path.
+ *
+ * This is the drop-in boundary.  Every entry point below replaces one member of the
+ * reference's C++ front-end API (file:line under /root/reference):
+ *
+ *   ORBextractor::ORBextractor        src/ORBextractor.cc:492-609   -> amos_orb_create / amos_orb_tables
+ *   ORBextractor::operator() (3-arg)  src/ORBextractor.cc:1672-1686 -> amos_orb_detect (+ amos_orb_level_keypoints)
+ *   ORBextractor::MovingKeyPoints     src/ORBextractor.cc:1688-1745 -> amos_orb_gate
+ *   ORBextractor::ProcessDesp         src/ORBextractor.cc:1747-1820 -> amos_orb_describe
+ *   ORBextractor::operator() (4-arg)  src/ORBextractor.cc:1544-1668 -> amos_orb_extract
+ *   ORBextractor::mvImagePyramid      include/ORBextractor.h:168    -> amos_orb_level_image
+ *   ORBmatcher::DescriptorDistance    src/ORBmatcher.cc:1913-1933   -> amos_match_distances / amos_match_list_distances
+ *   inner best / second-best loops of ORBmatcher::Search* (src/ORBmatcher.cc:70-175, 230-382,
+ *     515-643, 1569-1728)                                           -> amos_match_list_best2 / amos_match_bruteforce_best2
+ *
+ * The host-side C++ classes with the reference's names (ORB_SLAM2::ORBextractor, ORBmatcher)
+ * live in amos-slam_amd/host/ and are thin wrappers over these functions; INTEGRATION.md shows
+ * the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only, no C++ or torch types.  Every function returns
+ * AMOS_OK (0) or a negative error code; amos_last_error() returns a thread-local description.
+ * Unless a name ends in _device, pointers are HOST pointers and the call is synchronous.
+ * All work of one handle is issued on one HIP stream owned by that handle (or handed in at create).
+ * A handle is stateful exactly like an ORBextractor instance (one frame/batch in flight per handle);
+ * distinct handles may be used from distinct threads concurrently.
+ */
+#ifndef AMOS_FRONTEND_H
+#define AMOS_FRONTEND_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMOS_OK 0
+#define AMOS_ERR_INVALID (-1)   /* bad argument (null, size, range)                              */
+#define AMOS_ERR_DEVICE (-2)    /* HIP runtime error; text in amos_last_error()                  */
+#define AMOS_ERR_CAPACITY (-3)  /* caller buffer too small, or frame larger than the handle's max */
+#define AMOS_ERR_STATE (-4)     /* call order violated (e.g. describe before detect)             */
+
+#define AMOS_EDGE_THRESHOLD 19  /* border of every pyramid plane, ORBextractor.cc:93             */
+#define AMOS_MAX_LEVELS 16
+#define AMOS_TH_HIGH 100        /* ORBmatcher.cc:49 */
+#define AMOS_TH_LOW 50          /* ORBmatcher.cc:50 */
+#define AMOS_HISTO_LENGTH 30    /* ORBmatcher.cc:51 */
+
+/* Same field order and widths as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave,
+ * class_id), so a std::vector<cv::KeyPoint> can be filled with one memcpy. */
+typedef struct amos_keypoint {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} amos_keypoint;
+
+/* The five ORBextractor.* YAML parameters (Tracking.cc:161-177). */
+typedef struct amos_orb_params {
+    int32_t n_features;
+    float scale_factor;
+    int32_t n_levels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+} amos_orb_params;
+
+typedef struct amos_orb amos_orb;
+typedef struct amos_match amos_match;
+
+/* Result of a best / second-best reduction over one query's candidate list, ties resolved as the
+ * reference's sequential `if(dist<best) ... else if(dist<best2)` loop does (first candidate wins). */
+typedef struct amos_best2 {
+    int32_t best_idx;     /* train index, -1 if no candidate beat init_dist */
+    int32_t best_dist;    /* init_dist if none */
+    int32_t second_idx;   /* -1 if none */
+    int32_t second_dist;  /* init_dist if none */
+} amos_best2;
+
+const char *amos_last_error(void);
+/* Number of HIP devices visible, or a negative error code. */
+int amos_device_count(void);
+
+/* ---------------------------------------------------------------- ORB extractor ------------- */
+
+/* Allocates every device buffer for frames up to max_width x max_height and batches of up to
+ * max_batch frames on HIP device `device`.  `stream` is a hipStream_t to issue on, or NULL to
+ * let the handle create its own. */
+int amos_orb_create(const amos_orb_params *params, int max_width, int max_height, int max_batch,
+                    int device, void *stream, amos_orb **out);
+void amos_orb_destroy(amos_orb *h);
+
+/* Constructor tables (a1).  Any pointer may be NULL.  Arrays hold n_levels entries, umax 16. */
+int amos_orb_tables(const amos_orb *h, float *scale_factor, float *inv_scale_factor,
+                    float *level_sigma2, float *inv_level_sigma2, int32_t *features_per_level,
+                    int32_t *umax);
+/* Level geometry for a w x h input: width/height per level.  Returns n_levels. */
+int amos_orb_level_sizes(const amos_orb *h, int width, int height, int32_t *level_w, int32_t *level_h);
+
+/* a7: pyramid + per-cell FAST + quad-tree distribution + orientation for ONE host frame
+ * (8-bit gray, `stride` bytes per row).  Afterwards per-level keypoints (level coordinates,
+ * not rescaled) are available through amos_orb_level_keypoints(frame = 0). */
+int amos_orb_detect(amos_orb *h, const uint8_t *gray, size_t stride, int width, int height);
+
+/* Number of keypoints of (frame, level) after the last detect/gate, or a negative error. */
+int amos_orb_level_count(amos_orb *h, int frame, int level);
+int amos_orb_level_keypoints(amos_orb *h, int frame, int level, amos_keypoint *out, int cap);
+/* Replaces the device-resident list of (frame, level) by the caller's (the reference hands the
+ * per-level vectors back into MovingKeyPoints / ProcessDesp, Frame.cc:491-496,633). */
+int amos_orb_set_level_keypoints(amos_orb *h, int frame, int level, const amos_keypoint *kps, int n);
+
+/* a8: closing (dilate then erode, 31x31 ellipse) of the 8-bit mask of the level-0 frame size and
+ * removal of every keypoint whose scaled position hits a non-zero closed-mask pixel or a removed
+ * cluster.  `labels` (row-major doubles, lstride elements per row), `center_ids`, `rm_vector`
+ * describe the SLIC/k-means label gate and may all be NULL (label gate off).  Removed keypoints
+ * are returned in the reference's order (level by level, list order).  Operates on frame 0. */
+int amos_orb_gate(amos_orb *h, const uint8_t *mask, size_t mask_stride, const double *labels,
+                  size_t lstride, const int32_t *center_ids, int n_centers,
+                  const int32_t *rm_vector, int n_rm, amos_keypoint *removed, int cap,
+                  int *n_removed);
+/* The closed mask of the last amos_orb_gate call (for parity tests). */
+int amos_orb_closed_mask(amos_orb *h, uint8_t *dst, size_t dst_stride);
+
+/* a9: 7x7 sigma-2 blur of every level, 256-bit rBRIEF of the current per-level lists, rescale of
+ * the coordinates to level 0, concatenation in level order.  desc is n x 32 bytes row-major. */
+int amos_orb_describe(amos_orb *h, amos_keypoint *kps, uint8_t *desc, int cap, int *n);
+
+/* a11 = detect + describe without gating. */
+int amos_orb_extract(amos_orb *h, const uint8_t *gray, size_t stride, int width, int height,
+                     amos_keypoint *kps, uint8_t *desc, int cap, int *n);
+
+/* mvImagePyramid[level] of `frame`: the level image (padded != 0: with its 19-px reflect-101
+ * border, i.e. (w+38) x (h+38)) copied to host memory. */
+int amos_orb_level_image(amos_orb *h, int frame, int level, uint8_t *dst, size_t dst_stride,
+                         int padded);
+/* The blurred level used by the last describe (unpadded, w x h). */
+int amos_orb_blurred_image(amos_orb *h, int frame, int level, uint8_t *dst, size_t dst_stride);
+/* FAST candidates of (frame, level) before the quad-tree, in the reference's order
+ * (cell-row-major, then row-major inside the cell): x, y relative to (minBorderX, minBorderY),
+ * response = score.  For parity tests. */
+int amos_orb_level_candidates(amos_orb *h, int frame, int level, amos_keypoint *out, int cap);
+
+/* Batched, device-resident path.  d_gray holds n_frames frames, frame f at
+ * d_gray + f * frame_stride, rows `row_stride` bytes apart.  Runs a11 on every frame; results stay
+ * on the device (amos_orb_batch_results_device) and nothing is copied to the host.  Asynchronous on
+ * the handle's stream; amos_orb_sync() waits. */
+int amos_orb_extract_batch_device(amos_orb *h, const uint8_t *d_gray, size_t frame_stride,
+                                  size_t row_stride, int width, int height, int n_frames);
+/* Device pointers of the batch results: keypoints [max_batch][capacity], descriptors
+ * [max_batch][capacity][32], counts [max_batch].  Valid until destroy. */
+int amos_orb_batch_results_device(amos_orb *h, const amos_keypoint **d_kps, const uint8_t **d_desc,
+                                  const int32_t **d_counts, int *capacity);
+/* Copies frame `frame` of the last batch to host buffers. */
+int amos_orb_batch_fetch(amos_orb *h, int frame, amos_keypoint *kps, uint8_t *desc, int cap, int *n);
+int amos_orb_sync(amos_orb *h);
+/* The hipStream_t the handle issues on. */
+void *amos_orb_stream(amos_orb *h);
+
+/* ---------------------------------------------------------------- matcher ------------------- */
+
+int amos_match_create(int device, void *stream, amos_match **out);
+void amos_match_destroy(amos_match *m);
+int amos_match_sync(amos_match *m);
+void *amos_match_stream(amos_match *m);
+
+/* a12, dense: out[i*nt + j] = Hamming(q_i, t_j), descriptors 32 bytes each, row-major. */
+int amos_match_distances(amos_match *m, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                         uint16_t *out);
+/* a12 over candidate lists (CSR): query i owns cand_idx[cand_off[i] .. cand_off[i+1]);
+ * out[k] = Hamming(q_i, t_{cand_idx[k]}).  This is what the greedy Search* loops consume. */
+int amos_match_list_distances(amos_match *m, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                              const int32_t *cand_off, const int32_t *cand_idx, uint16_t *out);
+/* a13 inner reduction over candidate lists: best and second best in candidate order.
+ * init_dist is the loop's initial bestDist (256 in SearchByProjection, INT_MAX in
+ * SearchForInitialization): only distances < init_dist can win. */
+int amos_match_list_best2(amos_match *m, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                          const int32_t *cand_off, const int32_t *cand_idx, int init_dist,
+                          amos_best2 *out);
+/* The same with every train descriptor as candidate, in index order (N_q x N_t brute force). */
+int amos_match_bruteforce_best2(amos_match *m, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                                int init_dist, amos_best2 *out);
+/* Device-pointer form for the batched pipeline: for each of n_pairs (query frame, train frame)
+ * pairs: descriptors at d_desc + frame * frame_stride_bytes, counts in d_counts[frame]; out is
+ * [n_pairs][capacity] amos_best2 on the device.  Asynchronous on the matcher's stream. */
+int amos_match_bruteforce_best2_batch_device(amos_match *m, const uint8_t *d_desc,
+                                             size_t frame_stride_bytes, const int32_t *d_counts,
+                                             const int32_t *d_pairs_q, const int32_t *d_pairs_t,
+                                             int n_pairs, int capacity, int init_dist,
+                                             amos_best2 *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMOS_FRONTEND_H */

@@ -1,0 +1,95 @@
+/*
+ * orb_oracle.h -- CPU restatement of the Amos-SLAM front-end hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, load or call
+ * this.  The product path (amos-slam_amd/, include/) never does.
+ *
+ * PARITY STATUS: the pixel arithmetic of this path lives in OpenCV (pinned 4.5.1 by the reference,
+ * CMakeLists.txt:31), which is absent from the reference tree and from this image, and the
+ * reference holds no golden vectors for the path.  The stages that restate OpenCV primitives
+ * (resize, copyMakeBorder, FAST, GaussianBlur, fastAtan2, dilate/erode) are therefore
+ * "PARITY UNPINNED": they follow OpenCV 4.5's published algorithms as recorded in SURVEY.md
+ * Appendix A.  Pinned by the reference itself: the rBRIEF pattern (sha256), umax, the per-level
+ * quotas, thresholds, and every line of ORBextractor.cc / ORBmatcher.cc logic restated here.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "../include/amos_frontend.h" /* amos_keypoint, amos_best2, amos_orb_params: shared PODs */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_extractor orc_extractor;
+
+/* ORBextractor::ORBextractor, ORBextractor.cc:492-609 */
+orc_extractor *orc_create(const amos_orb_params *p);
+void orc_destroy(orc_extractor *e);
+void orc_tables(const orc_extractor *e, float *scale, float *inv_scale, float *sigma2,
+                float *inv_sigma2, int32_t *features_per_level, int32_t *umax);
+int orc_level_sizes(const orc_extractor *e, int width, int height, int32_t *lw, int32_t *lh);
+
+/* 3-arg operator(), ORBextractor.cc:1672-1686.  Returns 0 or a negative error. */
+int orc_detect(orc_extractor *e, const uint8_t *gray, size_t stride, int width, int height);
+int orc_level_count(const orc_extractor *e, int level);
+int orc_level_keypoints(const orc_extractor *e, int level, amos_keypoint *out, int cap);
+int orc_set_level_keypoints(orc_extractor *e, int level, const amos_keypoint *kps, int n);
+int orc_level_candidates(const orc_extractor *e, int level, amos_keypoint *out, int cap);
+/* mvImagePyramid[level]; padded != 0 returns the (w+38)x(h+38) buffer. */
+int orc_level_image(const orc_extractor *e, int level, uint8_t *dst, size_t dst_stride, int padded);
+int orc_blurred_image(const orc_extractor *e, int level, uint8_t *dst, size_t dst_stride);
+
+/* MovingKeyPoints, ORBextractor.cc:1688-1745 */
+int orc_gate(orc_extractor *e, const uint8_t *mask, size_t mask_stride, const double *labels,
+             size_t lstride, const int32_t *center_ids, int n_centers, const int32_t *rm_vector,
+             int n_rm, amos_keypoint *removed, int cap, int *n_removed);
+int orc_closed_mask(const orc_extractor *e, uint8_t *dst, size_t dst_stride);
+
+/* ProcessDesp, ORBextractor.cc:1747-1820 */
+int orc_describe(orc_extractor *e, amos_keypoint *kps, uint8_t *desc, int cap, int *n);
+/* 4-arg operator(), ORBextractor.cc:1544-1668 */
+int orc_extract(orc_extractor *e, const uint8_t *gray, size_t stride, int width, int height,
+                amos_keypoint *kps, uint8_t *desc, int cap, int *n);
+
+/* ---- primitives exposed for unit tests ---- */
+/* cv::resize(..., INTER_LINEAR) on 8UC1, SURVEY Appendix A.1 */
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, size_t sstride, uint8_t *dst, int dw,
+                          int dh, size_t dstride);
+/* cv::FAST(img, kps, threshold, true), TYPE_9_16, SURVEY Appendix A.3.  Returns the count. */
+int orc_fast9_16(const uint8_t *img, size_t stride, int w, int h, int threshold,
+                 amos_keypoint *out, int cap);
+/* cv::GaussianBlur(7x7, 2, 2, BORDER_REFLECT_101) on a continuous 8UC1 image, Appendix A.2 */
+void orc_gaussian_blur7(const uint8_t *src, size_t sstride, int w, int h, uint8_t *dst,
+                        size_t dstride);
+/* cv::fastAtan2, Appendix A.4 */
+float orc_fast_atan2(float y, float x);
+/* sincosf as glibc computes it (ARM optimized-routines algorithm, double arithmetic, no FMA) */
+void orc_sincosf(float x, float *s, float *c);
+/* DistributeOctTree, ORBextractor.cc:706-1049.  pts: x,y,response used.  Returns count. */
+int orc_distribute_octree(const amos_keypoint *pts, int n, int minX, int maxX, int minY, int maxY,
+                          int N, amos_keypoint *out, int cap);
+/* dilate then erode with the 31x31 MORPH_ELLIPSE element, Appendix A.6 */
+void orc_close_ellipse31(const uint8_t *src, size_t sstride, int w, int h, uint8_t *dst,
+                         size_t dstride);
+
+/* ---- matcher ---- */
+/* ORBmatcher::DescriptorDistance, ORBmatcher.cc:1913-1933 */
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b);
+void orc_distances(const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *out);
+void orc_list_distances(const uint8_t *q, int nq, const uint8_t *t, const int32_t *cand_off,
+                        const int32_t *cand_idx, uint16_t *out);
+/* The inner loop of ORBmatcher::SearchByProjection (ORBmatcher.cc:127-148) over candidate lists. */
+void orc_list_best2(const uint8_t *q, int nq, const uint8_t *t, const int32_t *cand_off,
+                    const int32_t *cand_idx, int init_dist, amos_best2 *out);
+void orc_bruteforce_best2(const uint8_t *q, int nq, const uint8_t *t, int nt, int init_dist,
+                          amos_best2 *out);
+/* ORBmatcher::ComputeThreeMaxima, ORBmatcher.cc:1866-1908, on bin sizes. */
+void orc_three_maxima(const int32_t *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,285 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs.  Integer / byte / index work => every comparison is bit-exact (tobytes equality)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(640, 480, 1000, 8), (320, 240, 500, 4), (752, 480, 1200, 8), (413, 307, 300, 5)]
+
+
+def _pair(gpu_lib, ob, w, h, nf, nl, **kw):
+    ext = gpu_lib.OrbExtractor(n_features=nf, n_levels=nl, max_width=w, max_height=h, **kw)
+    orc = ob.Oracle(n_features=nf, n_levels=nl)
+    return ext, orc
+
+
+def _same(a, b, what):
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    if a.tobytes() != b.tobytes():
+        if a.dtype.names:
+            bad = [n for n in a.dtype.names if not np.array_equal(a[n], b[n])]
+            idx = np.nonzero(a[bad[0]] != b[bad[0]])[0][:5]
+            raise AssertionError(f"{what}: fields {bad} differ, first at {idx}: {a[idx]} vs {b[idx]}")
+        idx = np.argwhere(a != b)[:5]
+        raise AssertionError(f"{what}: {np.count_nonzero(a != b)} elements differ, first at {idx.tolist()}")
+
+
+def test_tables(gpu_lib, ob):
+    ext, orc = _pair(gpu_lib, ob, 640, 480, 1000, 8)
+    tg, to = ext.tables(), orc.tables()
+    for k in to:
+        _same(tg[k], to[k], k)
+    assert list(tg["features_per_level"]) == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert list(tg["umax"]) == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    lw, lh = ext.level_sizes(640, 480)
+    assert list(lw) == [640, 533, 444, 370, 309, 257, 214, 179]
+    assert list(lh) == [480, 400, 333, 278, 231, 193, 161, 134]
+
+
+@pytest.mark.parametrize("w,h,nf,nl", SIZES)
+def test_stages_bit_exact(gpu_lib, ob, synth, w, h, nf, nl):
+    img = synth.frame(11, 3, h, w)
+    ext, orc = _pair(gpu_lib, ob, w, h, nf, nl)
+    ext.detect(img)
+    orc.detect(img)
+    for l in range(nl):
+        _same(ext.level_image(l, padded=True), orc.level_image(l, padded=True), f"padded level {l}")
+    for l in range(nl):
+        _same(ext.level_candidates(l), orc.level_candidates(l), f"FAST candidates level {l}")
+    for l in range(nl):
+        _same(ext.level_keypoints(l), orc.level_keypoints(l), f"keypoints level {l}")
+    kg, dg = ext.describe()
+    ko, do = orc.describe()
+    for l in range(nl):
+        _same(ext.blurred_image(l), orc.blurred_image(l), f"blurred level {l}")
+    _same(kg, ko, "final keypoints")
+    _same(dg, do, "descriptors")
+    assert len(kg) >= nf * 0.9
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_extract_many_frames(gpu_lib, ob, synth, seed):
+    ext, orc = _pair(gpu_lib, ob, 640, 480, 1000, 8)
+    img = synth.frame(seed, 7 * seed)
+    kg, dg = ext.extract(img)
+    ko, do = orc.extract(img)
+    _same(kg, ko, "keypoints")
+    _same(dg, do, "descriptors")
+
+
+def test_low_texture_uses_min_threshold(gpu_lib, ob):
+    """Cells with no corner at iniThFAST fall back to minThFAST (ORBextractor.cc:1126-1139)."""
+    rng = np.random.default_rng(5)
+    img = np.full((480, 640), 120, np.uint8)
+    img[::16, :] = 128  # faint grid: corners only at the low threshold
+    img[:, ::16] = 128
+    img[100:200, 100:300] = rng.integers(0, 255, (100, 200), dtype=np.uint8)  # one textured patch
+    ext, orc = _pair(gpu_lib, ob, 640, 480, 1000, 8)
+    kg, dg = ext.extract(img)
+    ko, do = orc.extract(img)
+    _same(kg, ko, "keypoints")
+    _same(dg, do, "descriptors")
+    assert len(kg) > 0
+
+
+def test_constant_image_gives_nothing(gpu_lib, ob):
+    """No corner anywhere => zero keypoints, descriptors released (ORBextractor.cc:1590)."""
+    img = np.full((480, 640), 77, np.uint8)
+    ext, orc = _pair(gpu_lib, ob, 640, 480, 1000, 8)
+    kg, dg = ext.extract(img)
+    ko, do = orc.extract(img)
+    assert len(kg) == 0 and len(ko) == 0 and dg.shape == (0, 32)
+
+
+def test_bright_square_corners(gpu_lib, ob):
+    """Hand-checkable micro case: one bright square on black has exactly its corners as FAST
+    maxima at level 0."""
+    img = np.zeros((480, 640), np.uint8)
+    img[200:260, 300:380] = 200
+    ext, orc = _pair(gpu_lib, ob, 640, 480, 1000, 8)
+    ext.detect(img)
+    orc.detect(img)
+    for l in range(8):
+        _same(ext.level_candidates(l), orc.level_candidates(l), f"candidates level {l}")
+        _same(ext.level_keypoints(l), orc.level_keypoints(l), f"keypoints level {l}")
+    k0 = ext.level_keypoints(0)
+    assert len(k0) >= 4
+
+
+def test_frame_too_small_is_rejected(gpu_lib):
+    """A level without a FAST cell divides by zero in the reference (ORBextractor.cc:1083-1086);
+    the C ABI reports AMOS_ERR_INVALID instead."""
+    with pytest.raises(gpu_lib.AmosError):
+        gpu_lib.OrbExtractor(n_features=500, n_levels=8, max_width=160, max_height=120)
+
+
+def test_gate_mask_only(gpu_lib, ob, synth):
+    img = synth.frame(2, 5)
+    mask = synth.person_mask(2, 5)
+    ext, orc = _pair(gpu_lib, ob, 640, 480, 1000, 8)
+    ext.detect(img)
+    orc.detect(img)
+    rg = ext.gate(mask)
+    ro = orc.gate(mask)
+    _same(ext.closed_mask(), orc.closed_mask(), "closed mask")
+    _same(rg, ro, "removed keypoints")
+    for l in range(8):
+        _same(ext.level_keypoints(l), orc.level_keypoints(l), f"kept keypoints level {l}")
+    kg, dg = ext.describe()
+    ko, do = orc.describe()
+    _same(kg, ko, "keypoints after gate")
+    _same(dg, do, "descriptors after gate")
+    assert 0 < len(rg) < 1000
+
+
+def test_gate_with_labels(gpu_lib, ob, synth):
+    img = synth.frame(4, 1)
+    mask = synth.person_mask(4, 1)
+    rng = np.random.default_rng(9)
+    labels = np.kron(rng.integers(1, 16, (480 // 32, 640 // 32)), np.ones((32, 32))).astype(np.float64)
+    center_ids = rng.permutation(15).astype(np.int32)
+    rm = np.zeros(15, np.int32)
+    rm[[2, 7, 11]] = 1
+    ext, orc = _pair(gpu_lib, ob, 640, 480, 1000, 8)
+    ext.detect(img)
+    orc.detect(img)
+    rg = ext.gate(mask, labels, center_ids, rm)
+    ro = orc.gate(mask, labels, center_ids, rm)
+    _same(rg, ro, "removed keypoints")
+    kg, dg = ext.describe()
+    ko, do = orc.describe()
+    _same(kg, ko, "keypoints after gate")
+    _same(dg, do, "descriptors after gate")
+
+
+def test_gate_zero_mask_equals_extract(gpu_lib, synth):
+    """a7 -> a8 (all-zero mask) -> a9 == a11."""
+    img = synth.frame(6, 2)
+    ext = gpu_lib.OrbExtractor()
+    k1, d1 = ext.extract(img)
+    ext.detect(img)
+    removed = ext.gate(np.zeros((480, 640), np.uint8))
+    k2, d2 = ext.describe()
+    assert len(removed) == 0
+    _same(k1, k2, "keypoints")
+    _same(d1, d2, "descriptors")
+
+
+def test_set_level_keypoints_roundtrip(gpu_lib, ob, synth):
+    """The caller hands the per-level vectors back (Frame.cc:491-496): drop every other keypoint
+    on the host and describe."""
+    img = synth.frame(8, 0)
+    ext, orc = _pair(gpu_lib, ob, 640, 480, 1000, 8)
+    ext.detect(img)
+    orc.detect(img)
+    for l in range(8):
+        k = ext.level_keypoints(l)[::2]
+        ext.set_level_keypoints(l, k)
+        orc.set_level_keypoints(l, k)
+    kg, dg = ext.describe()
+    ko, do = orc.describe()
+    _same(kg, ko, "keypoints")
+    _same(dg, do, "descriptors")
+
+
+def test_batch_equals_single(gpu_lib, ob, synth):
+    """The batched device-resident path gives, per frame, what the single-frame path gives."""
+    import torch
+    n = 6
+    frames = synth.frames(1, 0, n)
+    ext = gpu_lib.OrbExtractor(max_batch=n)
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    ext.extract_batch_device(d.data_ptr(), 480 * 640, 640, 640, 480, n)
+    ext.sync()
+    orc = ob.Oracle()
+    for f in range(n):
+        kg, dg = ext.batch_fetch(f)
+        ko, do = orc.extract(frames[f])
+        _same(kg, ko, f"frame {f} keypoints")
+        _same(dg, do, f"frame {f} descriptors")
+
+
+def test_hd_config(gpu_lib, ob, synth):
+    """BASELINE.json configs[4] geometry: 1920x1080, 4000 features, 12 levels."""
+    img = synth.frame(21, 0, 1080, 1920)
+    ext, orc = _pair(gpu_lib, ob, 1920, 1080, 4000, 12)
+    kg, dg = ext.extract(img)
+    ko, do = orc.extract(img)
+    _same(kg, ko, "keypoints")
+    _same(dg, do, "descriptors")
+
+
+# ------------------------------------------------------------------------------- matcher
+
+def _descs(rng, n):
+    return rng.integers(0, 256, (n, 32), dtype=np.uint8)
+
+
+def test_hamming_known_answers(gpu_lib):
+    m = gpu_lib.OrbMatcher()
+    zero, one = np.zeros((1, 32), np.uint8), np.full((1, 32), 255, np.uint8)
+    assert m.distances(zero, one)[0, 0] == 256
+    assert m.distances(zero, zero)[0, 0] == 0
+    flips = np.zeros((256, 32), np.uint8)
+    for b in range(256):
+        flips[b, b // 8] = 1 << (b % 8)
+    assert (m.distances(zero, flips) == 1).all()
+    rng = np.random.default_rng(0)
+    a, b = _descs(rng, 37), _descs(rng, 53)
+    want = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(axis=2)
+    assert np.array_equal(m.distances(a, b), want)
+
+
+def test_dense_distances_vs_oracle(gpu_lib, ob):
+    rng = np.random.default_rng(1)
+    q, t = _descs(rng, 1003), _descs(rng, 997)
+    m = gpu_lib.OrbMatcher()
+    _same(m.distances(q, t), ob.distances(q, t), "dense distances")
+
+
+def _random_lists(rng, nq, nt, maxlen):
+    lens = rng.integers(0, maxlen, nq)
+    off = np.zeros(nq + 1, np.int32)
+    off[1:] = np.cumsum(lens)
+    idx = rng.integers(0, nt, off[-1]).astype(np.int32)
+    return off, idx
+
+
+def test_list_primitives_vs_oracle(gpu_lib, ob):
+    rng = np.random.default_rng(2)
+    q, t = _descs(rng, 700), _descs(rng, 900)
+    t[100:140] = t[100]  # exact duplicates: ties must resolve to the first candidate
+    off, idx = _random_lists(rng, 700, 900, 150)
+    m = gpu_lib.OrbMatcher()
+    _same(m.list_distances(q, t, off, idx), ob.list_distances(q, t, off, idx), "list distances")
+    for init in (256, 2 ** 31 - 1, 100, 120):
+        _same(m.list_best2(q, t, off, idx, init), ob.list_best2(q, t, off, idx, init), f"list best2 init={init}")
+
+
+def test_bruteforce_vs_oracle(gpu_lib, ob):
+    rng = np.random.default_rng(3)
+    q, t = _descs(rng, 1001), _descs(rng, 999)
+    t[500:520] = q[7]  # many equal best distances
+    q[9] = q[7]
+    m = gpu_lib.OrbMatcher()
+    for init in (256, 2 ** 31 - 1, 110):
+        _same(m.bruteforce_best2(q, t, init), ob.bruteforce_best2(q, t, init), f"bf best2 init={init}")
+    # empty / ragged
+    assert len(m.bruteforce_best2(q[:0], t)) == 0
+    r = m.bruteforce_best2(q[:3], t[:0])
+    assert (r["best_idx"] == -1).all() and (r["best_dist"] == 256).all()
+    _same(m.bruteforce_best2(q[:1], t[:1]), ob.bruteforce_best2(q[:1], t[:1]), "1x1")
+
+
+def test_match_consecutive_frames(gpu_lib, ob, synth):
+    """End to end on real descriptors: frame k against frame k-1 (SURVEY 8d match workload)."""
+    ext = gpu_lib.OrbExtractor()
+    k0, d0 = ext.extract(synth.frame(5, 10))
+    k1, d1 = ext.extract(synth.frame(5, 11))
+    m = gpu_lib.OrbMatcher()
+    got = m.bruteforce_best2(d1, d0)
+    _same(got, ob.bruteforce_best2(d1, d0), "consecutive-frame matches")
+    good = (got["best_dist"] <= 50) & (got["best_dist"] < 0.6 * got["second_dist"])
+    assert good.sum() > 100  # the scene moved by (2, 1) px: most corners re-match
