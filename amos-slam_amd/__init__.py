@@ -52,6 +52,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise AmosError(f"{LIB_PATH} is missing: build it with `make -C amos-slam_amd/csrc` "
                             "(or __graft_entry__.build()); there is no CPU fallback")
+        try:
+            # torch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1 under the same sonames as
+            # /opt/rocm.  One process must hold ONE HIP runtime: when torch is used beside this library
+            # (device memory, streams, torch.distributed), load torch's copy first so both share it.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.amos_last_error.restype = C.c_char_p
         L.amos_orb_stream.restype = C.c_void_p
