@@ -27,7 +27,7 @@ EXPORTS = [
     "amos_orb_set_level_keypoints", "amos_orb_gate", "amos_orb_closed_mask", "amos_orb_describe",
     "amos_orb_extract", "amos_orb_level_image", "amos_orb_blurred_image", "amos_orb_level_candidates",
     "amos_orb_extract_batch_device", "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
-    "amos_orb_stream", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
+    "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device",
 ]
@@ -240,6 +240,18 @@ class OrbExtractor:
 
     def sync(self):
         _check(self.L.amos_orb_sync(self.h), "amos_orb_sync")
+
+    STAGES = ("pyramid", "fast", "octree", "orient", "blur", "describe")
+
+    def timing_enable(self, max_records):
+        _check(self.L.amos_orb_timing_enable(self.h, C.c_int(max_records)), "amos_orb_timing_enable")
+
+    def timing_collect(self):
+        """Average milliseconds per stage over the passes recorded since the last collect."""
+        ms = np.zeros(len(self.STAGES), np.float32)
+        n = C.c_int(0)
+        _check(self.L.amos_orb_timing_collect(self.h, _p(ms), C.byref(n)), "amos_orb_timing_collect")
+        return dict(zip(self.STAGES, ms.tolist())), n.value
 
     @property
     def stream(self):

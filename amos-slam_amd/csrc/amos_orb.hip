@@ -75,6 +75,8 @@ struct amos_orb {
     int capCenters = 0, capRm = 0;
     int inputPitch = 0, maskPitch = 0;
     int nFrames = 0;      // frames of the last detect / batch
+    std::vector<hipEvent_t> events;  // [maxRecords][AMOS_ORB_STAGES + 1]
+    int maxRecords = 0, nRecords = 0;
     bool detected = false, described = false, gated = false;
 };
 
@@ -292,6 +294,8 @@ static int set_geometry(amos_orb *h, int W, int Hh)
 static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, size_t rowStride, int nFrames)
 {
     const Geom &g = h->geom;
+    hipEvent_t *ev = (h->maxRecords > 0 && h->nRecords < h->maxRecords) ? &h->events[(size_t)h->nRecords * (AMOS_ORB_STAGES + 1)] : nullptr;
+    if (ev) (void)hipEventRecord(ev[0], h->stream);
     for (int l = 0; l < g.nLevels; l++) {
         const LevelGeom &lg = g.lv[l];
         const int groups = (kPadLeft + lg.w + kEdge + 3) / 4;
@@ -301,13 +305,17 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
         else
             hipLaunchKernelGGL(k_pyramid_level<false>, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, h->dTaps, l);
     }
+    if (ev) (void)hipEventRecord(ev[1], h->stream);
     hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nFrames), dim3(256), 0, h->stream, h->dPyr, h->dGeom, h->dCells,
                        h->dSlotCount, h->dSlots);
+    if (ev) (void)hipEventRecord(ev[2], h->stream);
     const size_t lds = oct_lds_bytes(h->octNC, h->octSC);
     hipLaunchKernelGGL(k_octree, dim3(nFrames * g.nLevels), dim3(256), lds, h->stream, h->dGeom, h->dCells, h->dSlotCount,
                        h->dSlots, h->dPts, h->dNodeOf, h->dQuadOf, h->dCandCount, h->dLvKps, h->dLvCount, h->octNC, h->octSC);
+    if (ev) (void)hipEventRecord(ev[3], h->stream);
     hipLaunchKernelGGL(k_orient, dim3((g.kpLevelTotal + 3) / 4, nFrames), dim3(256), 0, h->stream, h->dPyr, h->dGeom, h->dLvKps,
                        h->dLvCount);
+    if (ev) (void)hipEventRecord(ev[4], h->stream);
     AMOS_HIP_CHECK(hipGetLastError());
     h->nFrames = nFrames;
     h->detected = true;
@@ -318,9 +326,12 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
 static int launch_describe(amos_orb *h, int nFrames)
 {
     const Geom &g = h->geom;
+    hipEvent_t *ev = (h->maxRecords > 0 && h->nRecords < h->maxRecords) ? &h->events[(size_t)h->nRecords * (AMOS_ORB_STAGES + 1)] : nullptr;
     hipLaunchKernelGGL(k_blur, dim3((unsigned)h->tiles.size(), nFrames), dim3(256), 0, h->stream, h->dPyr, h->dBlur, h->dGeom, h->dTiles);
+    if (ev) (void)hipEventRecord(ev[5], h->stream);
     hipLaunchKernelGGL(k_describe, dim3((g.kpLevelTotal + 3) / 4, nFrames), dim3(256), 0, h->stream, h->dBlur, h->dGeom, h->dLvKps,
                        h->dLvCount, h->dOutKps, h->dOutDesc, h->dOutCount);
+    if (ev) { (void)hipEventRecord(ev[6], h->stream); h->nRecords++; }
     AMOS_HIP_CHECK(hipGetLastError());
     h->described = true;
     return AMOS_OK;
@@ -473,6 +484,7 @@ void amos_orb_destroy(amos_orb *h)
                     h->dRemoved, h->dScratchKps, h->dMask, h->dMaskTmp, h->dMaskClosed, h->dLabels, h->dCenterIds, h->dRm,
                     h->dNRemoved, h->dErr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -720,5 +732,41 @@ int amos_orb_sync(amos_orb *h)
 }
 
 void *amos_orb_stream(amos_orb *h) { return h ? (void *)h->stream : nullptr; }
+
+int amos_orb_timing_enable(amos_orb *h, int max_records)
+{
+    if (!h || max_records < 0) return AMOS_ERR_INVALID;
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    h->events.clear();
+    h->maxRecords = h->nRecords = 0;
+    for (int i = 0; i < max_records * (AMOS_ORB_STAGES + 1); i++) {
+        hipEvent_t e;
+        AMOS_HIP_CHECK(hipEventCreate(&e));
+        h->events.push_back(e);
+    }
+    h->maxRecords = max_records;
+    return AMOS_OK;
+}
+
+int amos_orb_timing_collect(amos_orb *h, float *avg_ms, int *n_records)
+{
+    if (!h || !avg_ms) return AMOS_ERR_INVALID;
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (int s = 0; s < AMOS_ORB_STAGES; s++) avg_ms[s] = 0.f;
+    for (int r = 0; r < h->nRecords; r++)
+        for (int s = 0; s < AMOS_ORB_STAGES; s++) {
+            float ms = 0.f;
+            const hipEvent_t *ev = &h->events[(size_t)r * (AMOS_ORB_STAGES + 1)];
+            AMOS_HIP_CHECK(hipEventElapsedTime(&ms, ev[s], ev[s + 1]));
+            avg_ms[s] += ms;
+        }
+    if (h->nRecords > 0)
+        for (int s = 0; s < AMOS_ORB_STAGES; s++) avg_ms[s] /= (float)h->nRecords;
+    if (n_records) *n_records = h->nRecords;
+    h->nRecords = 0;
+    return AMOS_OK;
+}
 
 }  // extern "C"

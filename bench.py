@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- front-end frames/sec (ORB extract + brute-force Hamming match) on MI355X.
+
+A step = one pass of the hot path over one batch of B synthetic 640x480 frames that are already
+resident in HBM: ORB extraction of every frame (pyramid, FAST, quad-tree, orientation, blur, rBRIEF)
+followed by the N x N best-2 Hamming match of frame k against frame k-1.  One process per GPU; rank r
+works on its own synthetic stream r (frames are independent: no data-path collective, weak scaling);
+RCCL is used only for the barrier / max-over-ranks time and the final gather of result digests.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    # BASELINE.json configs[1]: single MI355X, extract + brute-force match, mask disabled
+    "c2": dict(width=640, height=480, n_features=1000, n_levels=8, label="configs[1]: 640x480 L8 N1000 extract+match, mask off"),
+    # BASELINE.json configs[4]: synthetic HD stream
+    "c5": dict(width=1920, height=1080, n_features=4000, n_levels=12, label="configs[4]: 1920x1080 L12 N4000 extract+match"),
+}
+
+
+def algorithmic_bytes(level_w, level_h, n_kp, width, height):
+    """ALGORITHMIC bytes per frame of every kernel (each mandatory pass reads its
+    input once and writes its output once)."""
+    wh = [int(w) * int(h) for w, h in zip(level_w, level_h)]
+    padded = [(int(w) + 38) * (int(h) + 38) for w, h in zip(level_w, level_h)]
+    return {
+        "pyramid": width * height + sum(wh[:-1]) + sum(padded),
+        "fast": sum(wh),
+        "octree": 0,  # selection over the candidate list: negligible bytes, latency-bound
+        "orient": n_kp * 749,
+        "blur": 2 * sum(wh),
+        "describe": n_kp * (512 + 32),
+        "match": 2 * n_kp * 32 + n_kp * 16,
+    }
+
+
+def cpu_baseline(synth, cfg, n_sample):
+    """The oracle (CPU restatement of src/ORBextractor.cc + ORBmatcher.cc, 1 thread) on a bounded
+    sample of the same workload.  Checker only: it is never the thing shipped or measured as GPU."""
+    import oracle_binding as ob
+    orc = ob.Oracle(n_features=cfg["n_features"], n_levels=cfg["n_levels"])
+    frames = [synth.frame(0, k, cfg["height"], cfg["width"]) for k in range(n_sample + 1)]
+    t0 = time.perf_counter()
+    prev = orc.extract(frames[0])[1]
+    for k in range(1, n_sample + 1):
+        _, desc = orc.extract(frames[k])
+        ob.bruteforce_best2(desc, prev)
+        prev = desc
+    dt = time.perf_counter() - t0
+    return {"value": round(n_sample / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n_sample} frames of the same synthetic stream: oracle extract + N x N best-2 match, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--check", action="store_true", help="verify one frame of the batch against the oracle")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    import importlib
+    synth = importlib.import_module("amos_slam_amd.synth")
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = CONFIGS[args.config]
+    W, H, B = cfg["width"], cfg["height"], args.batch
+    frames_np = synth.frames(rank, 0, B, H, W)  # stream = rank: every GPU gets different frames
+    d_frames = torch.from_numpy(frames_np).cuda(local_rank)
+
+    ext = pkg.OrbExtractor(n_features=cfg["n_features"], n_levels=cfg["n_levels"], max_width=W, max_height=H,
+                           max_batch=B, device=local_rank)
+    matcher = pkg.OrbMatcher(device=local_rank, stream=ext.stream)  # same stream: match follows extract
+    d_kps, d_desc, d_counts, cap = ext.batch_results_device()
+    pairs_q = torch.arange(B, dtype=torch.int32, device=f"cuda:{local_rank}")
+    pairs_t = (pairs_q - 1) % B  # frame k against frame k-1 (frame 0 against the last one)
+    d_match = torch.full((B, cap, 4), 1 << 30, dtype=torch.int32, device=f"cuda:{local_rank}")
+    torch.cuda.synchronize()
+
+    ev_stream = torch.cuda.ExternalStream(ext.stream, device=local_rank)
+    match_events = []
+
+    def step(timed):
+        ext.extract_batch_device(d_frames.data_ptr(), H * W, W, W, H, B)
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(ev_stream)
+        matcher.bruteforce_best2_batch_device(d_desc, cap * 32, d_counts, pairs_q.data_ptr(), pairs_t.data_ptr(), B, cap,
+                                              256, d_match.data_ptr())
+        if timed:
+            e1.record(ev_stream)
+            match_events.append((e0, e1))
+
+    def barrier():
+        ext.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    ext.timing_enable(args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stage_ms, n_rec = ext.timing_collect()
+    stage_ms["match"] = float(np.mean([a.elapsed_time(b) for a, b in match_events])) if match_events else 0.0
+    # result digest: keypoint counts + number of matches within TH_LOW (final gather over RCCL)
+    n_kp = [len(ext.batch_fetch(f)[0]) for f in range(min(B, 8))]
+    mean_kp = float(np.mean(n_kp))
+    good = int(((d_match[:, :, 1] <= 50).sum()).item())
+    digest = torch.tensor([float(sum(n_kp)), float(good)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        gathered = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(gathered, digest)  # the one collective of the path: final gather of digests
+        digest_all = [g.tolist() for g in gathered]
+    else:
+        digest_all = [digest.tolist()]
+
+    if args.check and rank == 0:
+        import oracle_binding as ob
+        orc = ob.Oracle(n_features=cfg["n_features"], n_levels=cfg["n_levels"])
+        for f in (0, B - 1):
+            kg, dg = ext.batch_fetch(f)
+            ko, do = orc.extract(frames_np[f])
+            assert kg.tobytes() == ko.tobytes() and dg.tobytes() == do.tobytes(), f"frame {f} differs from the oracle"
+
+    if rank == 0:
+        lw, lh = ext.level_sizes(W, H)
+        alg = algorithmic_bytes(lw, lh, mean_kp, W, H)
+        total_alg = sum(alg.values())
+        dominant = max(stage_ms, key=lambda k: stage_ms[k])
+        dom_bytes = alg[dominant] * B  # bytes one launch (one batch) of the dominant kernel processes
+        dom_ms = stage_ms[dominant]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                ent = tj.get(args.config, {}).get(dominant)
+                if ent and ent.get("batch") == B:
+                    traffic = ent["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        fps = world * B * args.steps / elapsed
+        out = {
+            "metric": "front-end frames/sec (ORB extract+match, mask off) at %dx%d" % (W, H),
+            "value": round(fps, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": cfg["label"], "frames_per_step_per_gpu": B, "width": W, "height": H,
+                       "n_features": cfg["n_features"], "n_levels": cfg["n_levels"], "ini_th_fast": 20, "min_th_fast": 7,
+                       "mean_keypoints_per_frame": round(mean_kp, 1), "match": "frame k vs k-1, N x N best-2",
+                       "synthetic_stream_seed": "stream = rank, frame k seeded 1000*rank+k (amos-slam_amd/synth.py)",
+                       "parallelism": f"frames sharded {world} ways, one process per GPU, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},
+            "pipeline_roofline": {"algorithmic_bytes_per_frame": int(total_alg),
+                                  "achieved_GBs": round(total_alg * fps / world / 1e9, 2),
+                                  "frac": round(total_alg * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
+            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+            "stage_frac_of_hbm_peak": {k: (round(alg[k] * B / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if v > 0 else None)
+                                       for k, v in stage_ms.items()},
+            "digest_per_rank": digest_all,
+        }
+        n_cpu = args.cpu_frames if args.cpu_frames >= 0 else (100 if args.config == "c2" else 12)
+        if world == 1 and n_cpu > 0:
+            out["cpu_baseline"] = cpu_baseline(synth, cfg, n_cpu)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -155,6 +155,16 @@ int amos_orb_batch_results_device(amos_orb *h, const amos_keypoint **d_kps, cons
 /* Copies frame `frame` of the last batch to host buffers. */
 int amos_orb_batch_fetch(amos_orb *h, int frame, amos_keypoint *kps, uint8_t *desc, int cap, int *n);
 int amos_orb_sync(amos_orb *h);
+
+/* Per-kernel timing with HIP events on the handle's stream (measurement, bench.py's roofline).
+ * After amos_orb_timing_enable(h, max_records) every batch / extract pass records one event
+ * between consecutive stages; amos_orb_timing_collect() synchronises, returns the average
+ * duration of each stage in milliseconds over the recorded passes and resets the record count.
+ * Stages: 0 pyramid (all level launches), 1 FAST cells, 2 quad-tree, 3 orientation, 4 blur,
+ * 5 rBRIEF.  max_records = 0 switches timing off. */
+#define AMOS_ORB_STAGES 6
+int amos_orb_timing_enable(amos_orb *h, int max_records);
+int amos_orb_timing_collect(amos_orb *h, float *avg_ms, int *n_records);
 /* The hipStream_t the handle issues on. */
 void *amos_orb_stream(amos_orb *h);
 
