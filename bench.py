@@ -82,20 +82,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
     import torch
-    import torch.distributed as dist
     import __graft_entry__ as entry
     pkg = entry.load_package()
     import importlib
     synth = importlib.import_module("amos_slam_amd.synth")
+    shard = importlib.import_module("amos_slam_amd.shard")
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    shard.init("nccl", torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
 
     cfg = CONFIGS[args.config]
     W, H, B = cfg["width"], cfg["height"], args.batch
-    frames_np = synth.frames(rank, 0, B, H, W)  # stream = rank: every GPU gets different frames
+    frames_np = synth.frames(shard.stream_for_rank(rank), 0, B, H, W)  # one stream per GPU
     d_frames = torch.from_numpy(frames_np).cuda(local_rank)
 
     ext = pkg.OrbExtractor(n_features=cfg["n_features"], n_levels=cfg["n_levels"], max_width=W, max_height=H,
@@ -125,8 +123,7 @@ def main():
     def barrier():
         ext.sync()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        shard.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -138,10 +135,7 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, f"cuda:{local_rank}")
 
     stage_ms, n_rec = ext.timing_collect()
     stage_ms["match"] = float(np.mean([a.elapsed_time(b) for a, b in match_events])) if match_events else 0.0
@@ -149,13 +143,8 @@ def main():
     n_kp = [len(ext.batch_fetch(f)[0]) for f in range(min(B, 8))]
     mean_kp = float(np.mean(n_kp))
     good = int(((d_match[:, :, 1] <= 50).sum()).item())
-    digest = torch.tensor([float(sum(n_kp)), float(good)], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if world > 1:
-        gathered = [torch.zeros_like(digest) for _ in range(world)]
-        dist.all_gather(gathered, digest)  # the one collective of the path: final gather of digests
-        digest_all = [g.tolist() for g in gathered]
-    else:
-        digest_all = [digest.tolist()]
+    # the one collective of the path: final gather of the per-rank digests
+    digest_all = shard.gather_digests([float(sum(n_kp)), float(good)], f"cuda:{local_rank}")
 
     if args.check and rank == 0:
         import oracle_binding as ob
@@ -219,8 +208,7 @@ def main():
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(out), flush=True)
 
-    if world > 1:
-        dist.destroy_process_group()
+    shard.finalize()
 
 
 if __name__ == "__main__":
