@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libamos_frontend.so")
+LIB_PATH = os.environ.get("AMOS_FRONTEND_LIB", os.path.join(_HERE, "csrc", "libamos_frontend.so"))  # override: kernel experiments
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

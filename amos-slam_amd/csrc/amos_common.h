@@ -41,6 +41,8 @@ struct LevelGeom {
     int nodeCap;                     // capacity of the node list / of the level's keypoint list
     int kpOff;                       // offset of the level's keypoint list inside one frame
     int tabX, tabY;                  // offsets into the resize coefficient tables
+    int blurGroups, blurItemStart;   // blur work items: 4-px column groups x 32-row strips
+    int fastMagic;                   // unused (reserved)
     float scale;                     // mvScaleFactor[level]
     float patchSize;                 // (float)(int)(31 * scale), ORBextractor.cc:1177
 };
@@ -54,6 +56,7 @@ struct Geom {
     int kpLevelTotal;    // per-level keypoint list capacity per frame (sum of nodeCap)
     int kpCap;           // capacity of the concatenated result per frame
     int iniTh, minTh;
+    int blurItems;       // blur work items per frame, all levels
     unsigned long long frameBytes;  // bytes of one frame's pyramid
     LevelGeom lv[AMOS_MAX_LEVELS];
 };
@@ -67,7 +70,9 @@ struct Cell {
     int slotOff;   // first candidate slot of the cell inside one frame
 };
 
-// Resize coefficients of one destination column / row (cv::resize fixed point, 11 bits).
+// Resize coefficients of one destination column / row (cv::resize fixed point, 11 bits).  The tables
+// are indexed by PADDED destination coordinate (column -32 .., row -19 ..) with the reflect-101 map
+// of the border already applied, so the kernel treats border and interior alike.
 struct ResizeTap {
     short ofs;     // source index of the first tap
     short ofs1;    // source index of the second tap (clamped)

@@ -51,16 +51,14 @@ struct amos_orb {
     Geom geom{};
     std::vector<Cell> cells;
     std::vector<ResizeTap> taps;
-    std::vector<BlurTile> tiles;
     int curW = 0, curH = 0;
     Geom capGeom{};  // geometry at (maxW, maxH): sizes every buffer
-    size_t capCells = 0, capTaps = 0, capTiles = 0;
+    size_t capCells = 0, capTaps = 0;
     int octNC = 0, octSC = 0;
     // device buffers
     Geom *dGeom = nullptr;
     Cell *dCells = nullptr;
     ResizeTap *dTaps = nullptr;
-    BlurTile *dTiles = nullptr;
     uint8_t *dPyr = nullptr, *dBlur = nullptr, *dInput = nullptr;
     int *dSlotCount = nullptr;
     uint32_t *dSlots = nullptr, *dPts = nullptr;
@@ -148,7 +146,7 @@ static void build_taps(int srcN, int dstN, bool horizontal, ResizeTap *out)
 // Geometry for a w x h frame.  Fails for frames the reference itself cannot process (a level
 // with no FAST cell divides by zero at ORBextractor.cc:1083-1086).
 static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector<Cell> *cells,
-                          std::vector<ResizeTap> *taps, std::vector<BlurTile> *tiles)
+                          std::vector<ResizeTap> *taps)
 {
     const int L = h->p.n_levels;
     std::memset(&g, 0, sizeof(g));
@@ -158,10 +156,9 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
     g.iniTh = h->p.ini_th_fast;
     g.minTh = h->p.min_th_fast;
     size_t off = 0;
-    int cellIdx = 0, slotOff = 0, ptsOff = 0, kpOff = 0, tabOff = 0;
+    int cellIdx = 0, slotOff = 0, ptsOff = 0, kpOff = 0, tabOff = 0, blurOff = 0;
     if (cells) cells->clear();
     if (taps) taps->clear();
-    if (tiles) tiles->clear();
     for (int l = 0; l < L; l++) {
         LevelGeom &lg = g.lv[l];
         lg.w = cv_round((float)W * h->invScale[l]);
@@ -229,18 +226,27 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
         lg.patchSize = (float)(int)(31 * h->scale[l]);
         lg.tabX = lg.tabY = 0;
         if (l > 0) {
-            lg.tabX = tabOff;
-            lg.tabY = tabOff + lg.w;
-            tabOff += lg.w + lg.h;
+            // tables by PADDED destination coordinate (column -32 + i, row -19 + i), reflection folded in
+            const int nX = align_up(((kPadLeft + lg.w + kEdge + 3) / 4) * 4, 4), nY = lg.h + 2 * kEdge;
+            lg.tabX = tabOff;  // multiple of 4 records = 32 B: the kernel loads 4 records as 2 x 16 B
+            lg.tabY = tabOff + nX;
+            tabOff += align_up(nX + nY, 4);
             if (taps) {
                 taps->resize(tabOff);
-                build_taps(g.lv[l - 1].w, lg.w, true, taps->data() + lg.tabX);
-                build_taps(g.lv[l - 1].h, lg.h, false, taps->data() + lg.tabY);
+                std::vector<ResizeTap> tx(lg.w), tyv(lg.h);
+                build_taps(g.lv[l - 1].w, lg.w, true, tx.data());
+                build_taps(g.lv[l - 1].h, lg.h, false, tyv.data());
+                auto refl = [](int i, int n) { if (i < 0) i = -i; if (i >= n) i = 2 * n - 2 - i; return i; };
+                for (int i = 0; i < nX; i++) {
+                    const int xo = std::min(std::max(i - kPadLeft, -kEdge), lg.w + kEdge - 1);
+                    (*taps)[lg.tabX + i] = tx[refl(xo, lg.w)];
+                }
+                for (int i = 0; i < nY; i++) (*taps)[lg.tabY + i] = tyv[refl(i - kEdge, lg.h)];
             }
         }
-        if (tiles)
-            for (int y0 = 0; y0 < lg.h; y0 += 16)
-                for (int x0 = 0; x0 < lg.w; x0 += 64) tiles->push_back(BlurTile{(short)l, (short)x0, (short)y0, 0});
+        lg.blurGroups = (lg.w + 3) / 4;
+        lg.blurItemStart = blurOff;
+        blurOff += lg.blurGroups * ((lg.h + kBlurStrip - 1) / kBlurStrip);
     }
     g.frameBytes = align_up_sz(off, 256);
     g.totalCells = cellIdx;
@@ -248,6 +254,7 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
     g.ptsTotal = ptsOff;
     g.kpLevelTotal = kpOff;
     g.kpCap = kpOff;
+    g.blurItems = blurOff;
     return AMOS_OK;
 }
 
@@ -258,13 +265,11 @@ static int set_geometry(amos_orb *h, int W, int Hh)
     Geom g;
     std::vector<Cell> cells;
     std::vector<ResizeTap> taps;
-    std::vector<BlurTile> tiles;
-    int rc = build_geometry(h, W, Hh, g, &cells, &taps, &tiles);
+    int rc = build_geometry(h, W, Hh, g, &cells, &taps);
     if (rc != AMOS_OK) return rc;
     const Geom &c = h->capGeom;
     if (g.frameBytes > c.frameBytes || g.totalCells > (int)h->capCells || g.slotTotal > c.slotTotal ||
-        g.ptsTotal > c.ptsTotal || g.kpLevelTotal > c.kpLevelTotal || taps.size() > h->capTaps ||
-        tiles.size() > h->capTiles) {
+        g.ptsTotal > c.ptsTotal || g.kpLevelTotal > c.kpLevelTotal || taps.size() > h->capTaps) {
         set_error("frame %dx%d needs more scratch than the handle's %dx%d allocation", W, Hh, h->maxW, h->maxH);
         return AMOS_ERR_CAPACITY;
     }
@@ -277,12 +282,10 @@ static int set_geometry(amos_orb *h, int W, int Hh)
     h->geom = g;
     h->cells.swap(cells);
     h->taps.swap(taps);
-    h->tiles.swap(tiles);
     AMOS_HIP_CHECK(hipMemcpyAsync(h->dGeom, &h->geom, sizeof(Geom), hipMemcpyHostToDevice, h->stream));
     AMOS_HIP_CHECK(hipMemcpyAsync(h->dCells, h->cells.data(), sizeof(Cell) * h->cells.size(), hipMemcpyHostToDevice, h->stream));
     if (!h->taps.empty())
         AMOS_HIP_CHECK(hipMemcpyAsync(h->dTaps, h->taps.data(), sizeof(ResizeTap) * h->taps.size(), hipMemcpyHostToDevice, h->stream));
-    AMOS_HIP_CHECK(hipMemcpyAsync(h->dTiles, h->tiles.data(), sizeof(BlurTile) * h->tiles.size(), hipMemcpyHostToDevice, h->stream));
     AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));  // host vectors above are pageable and reused
     h->curW = W;
     h->curH = Hh;
@@ -301,12 +304,12 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
         const int groups = (kPadLeft + lg.w + kEdge + 3) / 4;
         dim3 grid((groups + 63) / 64, (lg.h + 2 * kEdge + 3) / 4, nFrames), block(64, 4);
         if (l == 0)
-            hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, h->dTaps, l);
+            hipLaunchKernelGGL(k_pyramid_level0, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom);
         else
-            hipLaunchKernelGGL(k_pyramid_level<false>, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, h->dTaps, l);
+            hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);
     }
     if (ev) (void)hipEventRecord(ev[1], h->stream);
-    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nFrames), dim3(256), 0, h->stream, h->dPyr, h->dGeom, h->dCells,
+    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nFrames), dim3(kFastThreads), 0, h->stream, h->dPyr, h->dGeom, h->dCells,
                        h->dSlotCount, h->dSlots);
     if (ev) (void)hipEventRecord(ev[2], h->stream);
     const size_t lds = oct_lds_bytes(h->octNC, h->octSC);
@@ -327,7 +330,7 @@ static int launch_describe(amos_orb *h, int nFrames)
 {
     const Geom &g = h->geom;
     hipEvent_t *ev = (h->maxRecords > 0 && h->nRecords < h->maxRecords) ? &h->events[(size_t)h->nRecords * (AMOS_ORB_STAGES + 1)] : nullptr;
-    hipLaunchKernelGGL(k_blur, dim3((unsigned)h->tiles.size(), nFrames), dim3(256), 0, h->stream, h->dPyr, h->dBlur, h->dGeom, h->dTiles);
+    hipLaunchKernelGGL(k_blur, dim3((g.blurItems + 255) / 256, nFrames), dim3(256), 0, h->stream, h->dPyr, h->dBlur, h->dGeom);
     if (ev) (void)hipEventRecord(ev[5], h->stream);
     hipLaunchKernelGGL(k_describe, dim3((g.kpLevelTotal + 3) / 4, nFrames), dim3(256), 0, h->stream, h->dBlur, h->dGeom, h->dLvKps,
                        h->dLvCount, h->dOutKps, h->dOutDesc, h->dOutCount);
@@ -376,7 +379,8 @@ int amos_orb_create(const amos_orb_params *params, int max_width, int max_height
                     void *stream, amos_orb **out)
 {
     if (!params || !out || max_width < 1 || max_height < 1 || max_batch < 1 || params->n_levels < 1 ||
-        params->n_levels > AMOS_MAX_LEVELS || params->n_features < 1 || !(params->scale_factor > 1.0f)) {
+        params->n_levels > AMOS_MAX_LEVELS || params->n_features < 1 || !(params->scale_factor > 1.0f) ||
+        !(params->scale_factor <= 2.0f)) {  // k_pyramid_level's 12-byte source window needs scaleFactor <= 2
         set_error("amos_orb_create: invalid argument");
         return AMOS_ERR_INVALID;
     }
@@ -392,13 +396,11 @@ int amos_orb_create(const amos_orb_params *params, int max_width, int max_height
     if (std::memcmp(kUmax, h->umax, sizeof(kUmax)) != 0) { set_error("umax table mismatch"); delete h; return AMOS_ERR_INVALID; }
     std::vector<Cell> cells;
     std::vector<ResizeTap> taps;
-    std::vector<BlurTile> tiles;
-    int rc = build_geometry(h, max_width, max_height, h->capGeom, &cells, &taps, &tiles);
+    int rc = build_geometry(h, max_width, max_height, h->capGeom, &cells, &taps);
     if (rc != AMOS_OK) { delete h; return rc; }
     const Geom &c = h->capGeom;
     h->capCells = cells.size() + 64;
     h->capTaps = taps.size() + 64;
-    h->capTiles = tiles.size() + 64;
     if (stream) h->stream = (hipStream_t)stream;
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -413,7 +415,6 @@ int amos_orb_create(const amos_orb_params *params, int max_width, int max_height
     ALLOC(h->dGeom, 1);
     ALLOC(h->dCells, h->capCells);
     ALLOC(h->dTaps, h->capTaps);
-    ALLOC(h->dTiles, h->capTiles);
     ALLOC(h->dPyr, B * c.frameBytes + slack);
     ALLOC(h->dBlur, B * c.frameBytes + slack);
     ALLOC(h->dInput, (size_t)h->inputPitch * max_height);
@@ -479,7 +480,7 @@ void amos_orb_destroy(amos_orb *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->dGeom, h->dCells, h->dTaps, h->dTiles, h->dPyr, h->dBlur, h->dInput, h->dSlotCount, h->dSlots, h->dPts,
+    void *ptrs[] = {h->dGeom, h->dCells, h->dTaps, h->dPyr, h->dBlur, h->dInput, h->dSlotCount, h->dSlots, h->dPts,
                     h->dNodeOf, h->dQuadOf, h->dCandCount, h->dLvCount, h->dOutCount, h->dLvKps, h->dOutKps, h->dOutDesc,
                     h->dRemoved, h->dScratchKps, h->dMask, h->dMaskTmp, h->dMaskClosed, h->dLabels, h->dCenterIds, h->dRm,
                     h->dNRemoved, h->dErr};

@@ -38,50 +38,76 @@ __device__ __forceinline__ uint8_t *level_origin(uint8_t *pyr, const Geom *g, in
 // ---------------------------------------------------------------------------------------------
 // a2  ORBextractor::ComputePyramid, ORBextractor.cc:1826-1886.
 // One launch per level (level l needs level l-1 complete).  A thread produces 4 horizontally
-// adjacent bytes of the PADDED plane -- interior pixels by cv::resize's 11-bit fixed-point
-// bilinear, border pixels by evaluating the same formula at the reflect-101 source
-// coordinate -- and stores them as one aligned dword.
+// adjacent bytes of the PADDED plane and stores them as one aligned dword: interior pixels by
+// cv::resize's 11-bit fixed-point bilinear, border pixels by the same formula at the
+// reflect-101 source coordinate (the host-built tap tables are indexed by padded
+// coordinate with the reflection folded in).
 // grid = (ceil(groups/64), ceil((h+38)/4), frames), block = (64, 4).
-template <bool kLevel0>
-__global__ __launch_bounds__(256) void k_pyramid_level(const uint8_t *__restrict__ src, size_t srcFrameStride,
-                                                      size_t srcRowStride, uint8_t *__restrict__ pyr,
-                                                      const Geom *__restrict__ g,
-                                                      const ResizeTap *__restrict__ taps, int level)
+__global__ __launch_bounds__(256) void k_pyramid_level0(const uint8_t *__restrict__ src, size_t srcFrameStride,
+                                                       size_t srcRowStride, uint8_t *__restrict__ pyr,
+                                                       const Geom *__restrict__ g)
 {
-    const LevelGeom &lg = g->lv[level];
+    const LevelGeom &lg = g->lv[0];
     const int frame = blockIdx.z;
-    const int gx = blockIdx.x * 64 + threadIdx.x;    // dword column, starts at x = -kPadLeft
+    const int gx = blockIdx.x * 64 + threadIdx.x;  // dword column, starts at x = -kPadLeft
     const int yo = blockIdx.y * 4 + threadIdx.y - kEdge;
     const int groups = (kPadLeft + lg.w + kEdge + 3) >> 2;
     if (gx >= groups || yo >= lg.h + kEdge) return;
     const int yi = reflect101(yo, lg.h);
-    uint8_t *dst = level_origin(pyr, g, frame, level) + (ptrdiff_t)yo * lg.stride + (gx * 4 - kPadLeft);
+    uint8_t *dst = level_origin(pyr, g, frame, 0) + (ptrdiff_t)yo * lg.stride + (gx * 4 - kPadLeft);
+    const uint8_t *s = src + (size_t)frame * srcFrameStride + (size_t)yi * srcRowStride;
     uint32_t packed = 0;
-    if (kLevel0) {
-        const uint8_t *s = src + (size_t)frame * srcFrameStride + (size_t)yi * srcRowStride;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int xo = gx * 4 - kPadLeft + k;
-            xo = xo < -kEdge ? -kEdge : (xo > lg.w + kEdge - 1 ? lg.w + kEdge - 1 : xo);
-            packed |= (uint32_t)s[reflect101(xo, lg.w)] << (8 * k);
-        }
-    } else {
-        const LevelGeom &pg = g->lv[level - 1];
-        const uint8_t *prev = level_origin((const uint8_t *)pyr, g, frame, level - 1);
-        const ResizeTap ty = taps[lg.tabY + yi];
-        const uint8_t *S0 = prev + (ptrdiff_t)ty.ofs * pg.stride;
-        const uint8_t *S1 = prev + (ptrdiff_t)ty.ofs1 * pg.stride;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int xo = gx * 4 - kPadLeft + k;
-            xo = xo < -kEdge ? -kEdge : (xo > lg.w + kEdge - 1 ? lg.w + kEdge - 1 : xo);
-            const ResizeTap tx = taps[lg.tabX + reflect101(xo, lg.w)];
-            const int h0 = S0[tx.ofs] * tx.a0 + S0[tx.ofs1] * tx.a1;
-            const int h1 = S1[tx.ofs] * tx.a0 + S1[tx.ofs1] * tx.a1;
-            const int v = (((ty.a0 * (h0 >> 4)) >> 16) + ((ty.a1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xff) << (8 * k);
-        }
+    for (int k = 0; k < 4; k++) {
+        int xo = gx * 4 - kPadLeft + k;
+        xo = xo < -kEdge ? -kEdge : (xo > lg.w + kEdge - 1 ? lg.w + kEdge - 1 : xo);
+        packed |= (uint32_t)s[reflect101(xo, lg.w)] << (8 * k);
     }
+    *reinterpret_cast<uint32_t *>(dst) = packed;
+}
+
+// Levels >= 1.  The (at most 12-byte) source window of the four outputs is fetched as three
+// aligned dwords per source row; each output picks its two taps with v_alignbyte and weighs them
+// with one v_dot2_u32_u16.  Valid while 3 * scaleFactor + 5 <= 12 (host-checked: scaleFactor <= 2).
+__global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
+                                                      const ResizeTap *__restrict__ taps, int level)
+{
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    const LevelGeom &lg = g->lv[level];
+    const int frame = blockIdx.z;
+    const int gx = blockIdx.x * 64 + threadIdx.x;
+    const int row = blockIdx.y * 4 + threadIdx.y;  // padded row, 0 = yo -19
+    const int groups = (kPadLeft + lg.w + kEdge + 3) >> 2;
+    if (gx >= groups || row >= lg.h + 2 * kEdge) return;
+    const LevelGeom &pg = g->lv[level - 1];
+    const uint8_t *prev = level_origin((const uint8_t *)pyr, g, frame, level - 1);
+    const ResizeTap ty = taps[lg.tabY + row];
+    const uint4 *txp = reinterpret_cast<const uint4 *>(taps + lg.tabX + gx * 4);
+    const uint4 t01 = txp[0], t23 = txp[1];  // four ResizeTap records
+    const int ofs[4] = {(int)(short)(t01.x & 0xffff), (int)(short)(t01.z & 0xffff), (int)(short)(t23.x & 0xffff),
+                        (int)(short)(t23.z & 0xffff)};
+    const unsigned wgt[4] = {t01.y, t01.w, t23.y, t23.w};  // a0 | a1 << 16
+    const int base = min(min(ofs[0], ofs[1]), min(ofs[2], ofs[3])) & ~3;
+    const uint32_t *S0 = reinterpret_cast<const uint32_t *>(prev + (ptrdiff_t)ty.ofs * pg.stride + base);
+    const uint32_t *S1 = reinterpret_cast<const uint32_t *>(prev + (ptrdiff_t)ty.ofs1 * pg.stride + base);
+    const unsigned d0 = S0[0], d1 = S0[1], d2 = S0[2];
+    const unsigned e0 = S1[0], e1 = S1[1], e2 = S1[2];
+    const unsigned b0 = (unsigned)ty.a0, b1 = (unsigned)ty.a1;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned o = (unsigned)(ofs[k] - base);
+        const unsigned lo0 = o < 4 ? d0 : (o < 8 ? d1 : d2), hi0 = o < 4 ? d1 : (o < 8 ? d2 : 0u);
+        const unsigned lo1 = o < 4 ? e0 : (o < 8 ? e1 : e2), hi1 = o < 4 ? e1 : (o < 8 ? e2 : 0u);
+        const unsigned w0 = __builtin_amdgcn_alignbyte(hi0, lo0, o & 3u);  // bytes ofs, ofs + 1 of row 0
+        const unsigned w1 = __builtin_amdgcn_alignbyte(hi1, lo1, o & 3u);
+        const ushort2v wk = __builtin_bit_cast(ushort2v, wgt[k]);
+        const unsigned h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, w0, 0x0c010c00u)), wk, 0u, false);
+        const unsigned h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, w1, 0x0c010c00u)), wk, 0u, false);
+        const unsigned v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2u) >> 2;
+        packed |= (v & 0xffu) << (8 * k);
+    }
+    uint8_t *dst = level_origin(pyr, g, frame, level) + (ptrdiff_t)(row - kEdge) * lg.stride + (gx * 4 - kPadLeft);
     *reinterpret_cast<uint32_t *>(dst) = packed;
 }
 
@@ -94,122 +120,179 @@ __global__ __launch_bounds__(256) void k_pyramid_level(const uint8_t *__restrict
 // So one byte map of A (clamped at 0) per cell serves both thresholds; a pixel survives the 3x3
 // non-max suppression at threshold t iff A > t and every in-cell neighbour has A_n <= t or A_n < A
 // (scores outside the cell's tested region are 0 in OpenCV's row buffers).
+//
+// Per cell (one work-group; tile + 3-px halo staged in LDS so that the cell's first tested pixel
+// sits at byte 4 of its row, i.e. 4-pixel groups are dword aligned):
+//   1. a cheap necessary test on every pixel, four pixels per lane with dword LDS reads and packed
+//      16-bit min/max: any 9-arc of the 16-pixel circle contains two compass points 90 degrees
+//      apart, so a corner at threshold t needs  min(max(dS,dN), max(dE,dW)) > t  (both darker) or
+//      the mirrored expression (both brighter); survivors go onto an LDS list;
+//   2. the survivors (dense lanes again) get the exact arc value with v_pk_min_i16 on (d, -d)
+//      pairs: one chain serves the dark and the bright polarity;
+//   3. 3x3 strict non-max suppression over the survivors only; the kept ones are ranked by pixel
+//      index (row-major = FAST's output order) and written to the cell's slots.
+// The cell is processed at iniThFAST first and, only if that leaves it EMPTY, again at minThFAST
+// (ORBextractor.cc:1126-1139) -- a block-uniform retry.
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ short2v pk_min(short2v a, short2v b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ short2v pk_max(short2v a, short2v b) { return __builtin_elementwise_max(a, b); }
+
 __device__ __forceinline__ int fast_arc_value(const uint8_t *c, int s)
 {
     const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * s];       d[1] = v - c[3 * s + 1];   d[2] = v - c[2 * s + 2];   d[3] = v - c[s + 3];
-    d[4] = v - c[3];           d[5] = v - c[-s + 3];      d[6] = v - c[-2 * s + 2];  d[7] = v - c[-3 * s + 1];
-    d[8] = v - c[-3 * s];      d[9] = v - c[-3 * s - 1];  d[10] = v - c[-2 * s - 2]; d[11] = v - c[-s - 3];
-    d[12] = v - c[-3];         d[13] = v - c[s - 3];      d[14] = v - c[2 * s - 2];  d[15] = v - c[3 * s - 1];
-    int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo2[k] = min(d[k], d[(k + 1) & 15]);
-        hi2[k] = max(d[k], d[(k + 1) & 15]);
+    short2v x[16];
+#define AMOS_FAST_D(k, off)                                \
+    {                                                      \
+        const int d = v - (int)c[off];                     \
+        x[k] = short2v{(short)d, (short)-d};               \
     }
+    AMOS_FAST_D(0, 3 * s) AMOS_FAST_D(1, 3 * s + 1) AMOS_FAST_D(2, 2 * s + 2) AMOS_FAST_D(3, s + 3)
+    AMOS_FAST_D(4, 3) AMOS_FAST_D(5, -s + 3) AMOS_FAST_D(6, -2 * s + 2) AMOS_FAST_D(7, -3 * s + 1)
+    AMOS_FAST_D(8, -3 * s) AMOS_FAST_D(9, -3 * s - 1) AMOS_FAST_D(10, -2 * s - 2) AMOS_FAST_D(11, -s - 3)
+    AMOS_FAST_D(12, -3) AMOS_FAST_D(13, s - 3) AMOS_FAST_D(14, 2 * s - 2) AMOS_FAST_D(15, 3 * s - 1)
+#undef AMOS_FAST_D
+    short2v m2[16], m4[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
-        hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
-    }
-    int dark = -255, bright = 255;
+    for (int k = 0; k < 16; k++) m2[k] = pk_min(x[k], x[(k + 1) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        // 9 contiguous: 8 from two groups of four, plus the ninth
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        dark = max(dark, lo9);      // max over arcs of min(v - p)
-        bright = min(bright, hi9);  // min over arcs of max(v - p) = -(max over arcs of min(p - v))
-    }
-    return max(max(dark, -bright), 0);
+    for (int k = 0; k < 16; k++) m4[k] = pk_min(m2[k], m2[(k + 2) & 15]);
+    short2v best = short2v{-256, -256};
+#pragma unroll
+    for (int k = 0; k < 16; k++)  // 9 contiguous = two groups of four + the ninth
+        best = pk_max(best, pk_min(pk_min(m4[k], m4[(k + 4) & 15]), x[(k + 8) & 15]));
+    // .x = max over arcs of min(v - p) (dark), .y = max over arcs of min(p - v) (bright)
+    return max(max((int)best.x, (int)best.y), 0);
 }
 
-constexpr int kFastTileStride = 68;  // cell + 6 halo <= 65 columns
+constexpr int kFastTileStride = 72;  // bytes per LDS tile row = 18 dwords >= 4 + cell + 3 halo
 constexpr int kFastMapStride = 64;   // cell + 2 halo <= 61 columns
 constexpr int kFastMaxCell = 59;
 
-__device__ __forceinline__ bool fast_keep(const uint8_t *m, int t)
+// p / d for p < 2^20 / d (d <= 65, p < 4096 here): (p * ((1 << 20) / d + 1)) >> 20
+__device__ __forceinline__ int div_small(int p, unsigned magic) { return (int)(((unsigned)p * magic) >> 20); }
+
+__device__ __forceinline__ short2v unpack_lo(unsigned x) { return __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, x, 0x0c010c00u)); }
+__device__ __forceinline__ short2v unpack_hi(unsigned x) { return __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, x, 0x0c030c02u)); }
+
+// sign bits (15 and 31) set where the compass test passes at threshold t, for two packed pixels
+__device__ __forceinline__ unsigned fast_compass(short2v c, short2v n, short2v s, short2v e, short2v w, short2v t)
 {
-    const int a = m[0];
-    if (a <= t) return false;
-    const int s = kFastMapStride;
-    int n;
-    n = m[-s - 1]; if (n > t && n >= a) return false;
-    n = m[-s];     if (n > t && n >= a) return false;
-    n = m[-s + 1]; if (n > t && n >= a) return false;
-    n = m[-1];     if (n > t && n >= a) return false;
-    n = m[1];      if (n > t && n >= a) return false;
-    n = m[s - 1];  if (n > t && n >= a) return false;
-    n = m[s];      if (n > t && n >= a) return false;
-    n = m[s + 1];  if (n > t && n >= a) return false;
-    return true;
+    const short2v dN = c - n, dS = c - s, dE = c - e, dW = c - w;
+    const short2v dark = pk_min(pk_max(dS, dN), pk_max(dE, dW));
+    const short2v bright = short2v{0, 0} - pk_max(pk_min(dS, dN), pk_min(dE, dW));
+    const short2v q = pk_max(dark, bright);
+    return __builtin_bit_cast(unsigned, t - q) & 0x80008000u;  // t - q < 0  <=>  q > t
 }
 
 // grid = (totalCells, frames), block = 256.  Candidates of a cell are written in FAST's order
 // (row-major) to the cell's own slot range: packed x | y << 12 | score << 24, coordinates relative
 // to (minBorderX, minBorderY) as the reference hands them to DistributeOctTree.
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
+#ifndef AMOS_FAST_THREADS
+#define AMOS_FAST_THREADS 256
+#endif
+constexpr int kFastThreads = AMOS_FAST_THREADS;
+__global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
                                                    const Cell *__restrict__ cells, int *__restrict__ slotCount,
                                                    uint32_t *__restrict__ slots)
 {
-    __shared__ uint8_t tile[(kFastMaxCell + 6) * kFastTileStride];
+    constexpr int kRowDw = kFastTileStride / 4;
+    __shared__ uint32_t tile32[(kFastMaxCell + 6) * kRowDw];
     __shared__ uint8_t amap[(kFastMaxCell + 2) * kFastMapStride];
-    __shared__ int wcount[4];
+    __shared__ uint16_t cand[kFastMaxCell * kFastMaxCell];
+    __shared__ uint32_t kept[((kFastMaxCell + 1) / 2) * ((kFastMaxCell + 1) / 2)];
+    __shared__ int counters[2];
     const int tid = threadIdx.x;
     const int frame = blockIdx.y;
     const Cell c = cells[blockIdx.x];
     const LevelGeom &lg = g->lv[c.level];
     const uint8_t *img = level_origin(pyr, g, frame, c.level);
     const int tw = c.tw, th = c.th;
-    const int lw = tw + 6, lh = th + 6;
-    for (int idx = tid; idx < lw * lh; idx += 256) {
-        const int r = idx / lw, cc = idx - r * lw;
-        tile[r * kFastTileStride + cc] = img[(ptrdiff_t)(c.y0 - 3 + r) * lg.stride + (c.x0 - 3 + cc)];
+    // LDS row r holds image row y0 - 3 + r; LDS byte b of a row holds image column x0 - 4 + b
+    const int ga = (c.x0 - 4) & ~3, sh = (c.x0 - 4) & 3;
+    const int ndw = (tw + 10) >> 2;  // bytes 0 .. tw + 6 (pixels x0 - 4 .. x0 + tw + 2)
+    const int lh = th + 6;
+    const unsigned magicDw = (1u << 20) / (unsigned)ndw + 1u;
+    for (int idx = tid; idx < lh * ndw; idx += kFastThreads) {
+        const int r = div_small(idx, magicDw), cc = idx - r * ndw;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(img + (ptrdiff_t)(c.y0 - 3 + r) * lg.stride + ga) + cc;
+        tile32[r * kRowDw + cc] = __builtin_amdgcn_alignbyte(src[1], src[0], (unsigned)sh);
     }
-    for (int idx = tid; idx < (th + 2) * kFastMapStride; idx += 256) amap[idx] = 0;
-    __syncthreads();
-    const int npix = tw * th;
-    for (int p = tid; p < npix; p += 256) {
-        const int y = p / tw, x = p - y * tw;
-        amap[(y + 1) * kFastMapStride + x + 1] =
-            (uint8_t)fast_arc_value(&tile[(y + 3) * kFastTileStride + x + 3], kFastTileStride);
-    }
-    __syncthreads();
+    for (int idx = tid; idx < (th + 2) * (kFastMapStride / 4); idx += kFastThreads) reinterpret_cast<uint32_t *>(amap)[idx] = 0;
+    const uint8_t *tile = reinterpret_cast<const uint8_t *>(tile32) + 3 * kFastTileStride + 4;  // pixel (x0, y0)
     const int iniTh = min(max(g->iniTh, 0), 255), minTh = min(max(g->minTh, 0), 255);
-    int any = 0;
-    for (int p = tid; p < npix; p += 256) {
-        const int y = p / tw, x = p - y * tw;
-        any |= fast_keep(&amap[(y + 1) * kFastMapStride + x + 1], iniTh);
-    }
-    const int t = __syncthreads_or(any) ? iniTh : minTh;  // retry only if the cell came back EMPTY
-    const int lane = tid & 63, wave = tid >> 6;
+    const int groups = (tw + 3) >> 2;
+    const unsigned magicG = (1u << 20) / (unsigned)groups + 1u;
+    const int nitems = th * groups;
     uint32_t *out = slots + (size_t)frame * g->slotTotal + c.slotOff;
-    int base = 0;
-    for (int p0 = 0; p0 < npix; p0 += 256) {
-        const int p = p0 + tid;
-        bool keep = false;
-        int x = 0, y = 0;
-        if (p < npix) {
-            y = p / tw;
-            x = p - y * tw;
-            keep = fast_keep(&amap[(y + 1) * kFastMapStride + x + 1], t);
-        }
-        const unsigned long long ballot = __ballot(keep);
-        if (lane == 0) wcount[wave] = __popcll(ballot);
+    int nkept = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const int t = pass == 0 ? iniTh : minTh;
+        if (pass == 1 && minTh >= iniTh) break;  // a second cv::FAST at a higher threshold finds nothing new
+        if (tid < 2) counters[tid] = 0;
         __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; w++) off += wcount[w];
-        if (keep) {
-            off += __popcll(ballot & ((1ull << lane) - 1ull));
-            const int score = amap[(y + 1) * kFastMapStride + x + 1] - 1;
-            const int xr = c.x0 + x - kMinBorder, yr = c.y0 + y - kMinBorder;
-            out[off] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)score << 24);
+        // ---- phase 1: necessary test, 4 pixels per lane
+        const short2v tt = short2v{(short)t, (short)t};
+        for (int item = tid; item < nitems; item += kFastThreads) {
+            const int y = div_small(item, magicG), gx = item - y * groups;
+            const uint32_t *row = tile32 + (y + 3) * kRowDw + gx;  // dword holding pixels x0 + 4gx - 4 ..
+            const unsigned L = row[0], C = row[1], R = row[2];
+            const unsigned N = row[1 - 3 * kRowDw], S = row[1 + 3 * kRowDw];
+            const unsigned W = __builtin_amdgcn_alignbyte(C, L, 1u);  // pixels x-3 .. x
+            const unsigned E = __builtin_amdgcn_alignbyte(R, C, 3u);  // pixels x+3 .. x+6
+            unsigned m = fast_compass(unpack_lo(C), unpack_lo(N), unpack_lo(S), unpack_lo(E), unpack_lo(W), tt) >> 15;
+            unsigned mh = fast_compass(unpack_hi(C), unpack_hi(N), unpack_hi(S), unpack_hi(E), unpack_hi(W), tt) >> 15;
+            // bits: pixel0 = m bit 0, pixel1 = m bit 16, pixel2 = mh bit 0, pixel3 = mh bit 16
+            unsigned bits = (m & 1u) | ((m >> 15) & 2u) | ((mh & 1u) << 2) | ((mh >> 13) & 8u);
+            const int valid = tw - 4 * gx;  // pixels of this group inside the cell
+            if (valid < 4) bits &= (1u << valid) - 1u;
+            if (bits) {
+                int pos = atomicAdd(&counters[0], __popc(bits));
+                const int p0 = (y << 6) | (4 * gx);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (bits & (1u << k)) cand[pos++] = (uint16_t)(p0 + k);
+            }
         }
-        base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
         __syncthreads();
+        // ---- phase 2: exact arc value of the survivors
+        const int nc = counters[0];
+        for (int i = tid; i < nc; i += kFastThreads) {
+            const int p = cand[i];
+            const int y = p >> 6, x = p & 63;
+            const int a = fast_arc_value(tile + y * kFastTileStride + x, kFastTileStride);
+            amap[(y + 1) * kFastMapStride + x + 1] = (uint8_t)(a > t ? a : 0);
+        }
+        __syncthreads();
+        // ---- phase 3: strict 3x3 NMS over the survivors.  For a corner at threshold t (a > t) every
+        // non-corner neighbour is smaller than a anyway, so the test is simply "a > all 8 neighbours".
+        for (int i = tid; i < nc; i += kFastThreads) {
+            const int p = cand[i];
+            const int y = p >> 6, x = p & 63;
+            const uint8_t *m = &amap[(y + 1) * kFastMapStride + x + 1];
+            const int a = m[0];
+            if (a > t) {
+                const int s = kFastMapStride;
+                const int nmax = max(max(max((int)m[-s - 1], (int)m[-s]), max((int)m[-s + 1], (int)m[-1])),
+                                     max(max((int)m[1], (int)m[s - 1]), max((int)m[s], (int)m[s + 1])));
+                if (nmax < a) kept[atomicAdd(&counters[1], 1)] = ((uint32_t)p << 8) | (uint32_t)a;
+            }
+        }
+        __syncthreads();
+        nkept = counters[1];
+        if (nkept > 0) break;  // uniform: the cell is not empty at this threshold
+        __syncthreads();       // counters are reset at the top of the next pass
     }
-    if (tid == 0) slotCount[(size_t)frame * g->totalCells + blockIdx.x] = base;
+    // ---- ordered output: rank by pixel index = row-major order
+    for (int i = tid; i < nkept; i += kFastThreads) {
+        const uint32_t me = kept[i];
+        int rank = 0;
+        for (int j = 0; j < nkept; j++) rank += kept[j] < me;
+        const int p = (int)(me >> 8), a = (int)(me & 0xff);
+        const int xr = c.x0 + (p & 63) - kMinBorder, yr = c.y0 + (p >> 6) - kMinBorder;
+        out[rank] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)(a - 1) << 24);
+    }
+    if (tid == 0) slotCount[(size_t)frame * g->totalCells + blockIdx.x] = nkept;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -592,6 +675,12 @@ __device__ __forceinline__ int level_of_slot(const Geom *g, int slot)
 }
 
 // grid = (ceil(kpLevelTotal/4), frames), block = 256 (4 keypoints).
+__device__ __forceinline__ constexpr int umax_of(int v)
+{
+    constexpr int t[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, -1};
+    return t[v < 0 ? -v : v];
+}
+
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
                                                amos_keypoint *__restrict__ lvKps, const int *__restrict__ lvCount)
 {
@@ -606,18 +695,20 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     amos_keypoint *kp = lvKps + (size_t)frame * g->kpLevelTotal + slot;
     const int cx = __float2int_rn(kp->x), cy = __float2int_rn(kp->y);
     const uint8_t *center = level_origin(pyr, g, frame, level) + (ptrdiff_t)cy * lg.stride + cx;
-    const int u = (lane & 31) - kHalfPatch;
+    const int u = (lane & 31) - kHalfPatch, au = u < 0 ? -u : u;
+    const bool upper = lane >= 32;
     int m10 = 0, m01 = 0;
-    for (int v0 = -kHalfPatch; v0 <= kHalfPatch; v0 += 2) {
-        const int v = v0 + (lane >> 5);
-        if (v <= kHalfPatch && u <= kHalfPatch) {
-            const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-            if (au <= c_umax[av]) {
-                const int val = center[(ptrdiff_t)v * lg.stride + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
-        }
+    // 16 steps, two patch rows per step; loads are unconditional (masked lanes re-read the centre)
+    // so that all 16 are in flight together
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int vA = -kHalfPatch + 2 * i, vB = vA + 1;  // vB = 16 in the last step: umax_of = -1
+        const int v = upper ? vB : vA;
+        const int um = upper ? umax_of(vB) : umax_of(vA);
+        const bool valid = au <= um;
+        const int val = center[valid ? (ptrdiff_t)v * lg.stride + u : 0];
+        m10 += valid ? u * val : 0;
+        m01 += valid ? v * val : 0;
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
@@ -628,47 +719,73 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
 // a9 (first half)  cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101), 8-bit fixed-point path
 // (SURVEY A.2): dst = (sum_ij k_i k_j p + 32768) >> 16 with taps {18,34,48,56,48,34,18}/256.
 // The device planes already carry the 19-px reflect-101 border, so the 3-px halo is read directly.
-// One work-group = one 64x16 output tile staged through LDS; grid = (tiles, frames).
-struct BlurTile {
-    short level, x0, y0, pad;
-};
+//
+// A thread owns a 4-pixel-wide column strip and marches down kBlurStrip rows keeping the last six
+// row pairs of horizontal sums in registers (no LDS).  Per row it loads three aligned dwords
+// (pixels x-4 .. x+7), forms the four 7-tap horizontal sums with v_alignbyte + 2 x v_dot4_u32_u8
+// each, and finishes one output row with 3 x v_dot2_u32_u16 + 1 mad per pixel on (row, row+1)
+// packed pairs.  Work items are linearised as (strip, group) inside a level so that consecutive
+// lanes touch consecutive dwords whatever the level width.  grid = (ceil(items/256), frames).
+constexpr int kBlurStrip = 32;
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
-                                             const Geom *__restrict__ g, const BlurTile *__restrict__ tiles)
+                                             const Geom *__restrict__ g)
 {
-    __shared__ uint32_t raw[22][18];      // rows y0-3..y0+18, bytes x0-4..x0+67
-    __shared__ uint16_t hbuf[22][64 + 2];
-    const int tid = threadIdx.x;
+    const int item = blockIdx.x * 256 + threadIdx.x;
     const int frame = blockIdx.y;
-    const BlurTile t = tiles[blockIdx.x];
-    const LevelGeom &lg = g->lv[t.level];
-    const uint8_t *img = level_origin(pyr, g, frame, t.level);
-    for (int idx = tid; idx < 22 * 18; idx += 256) {
-        const int r = idx / 18, c = idx - r * 18;
-        const int y = min(t.y0 - 3 + r, lg.h + kEdge - 1);
-        raw[r][c] = *reinterpret_cast<const uint32_t *>(img + (ptrdiff_t)y * lg.stride + (t.x0 - 4 + 4 * c));
-    }
-    __syncthreads();
-    const uint8_t *rb = reinterpret_cast<const uint8_t *>(&raw[0][0]);
-    for (int idx = tid; idx < 22 * 64; idx += 256) {
-        const int r = idx >> 6, x = idx & 63;
-        const uint8_t *p = rb + r * 72 + x + 1;  // pixel x0 + x - 3
-        hbuf[r][x] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
-    }
-    __syncthreads();
-    const int tx = (tid & 15) * 4, ty = tid >> 4;
-    const int y = t.y0 + ty;
-    if (y >= lg.h) return;
-    uint32_t packed = 0;
+    if (item >= g->blurItems) return;
+    int level = 0;
+    for (int l = 1; l < g->nLevels; l++)
+        if (item >= g->lv[l].blurItemStart) level = l;
+    const LevelGeom &lg = g->lv[level];
+    const int local = item - lg.blurItemStart;
+    const int strip = local / lg.blurGroups;
+    const int x = (local - strip * lg.blurGroups) * 4, y0 = strip * kBlurStrip;
+    const uint8_t *src = level_origin(pyr, g, frame, level) + x - 4;
+    uint8_t *dst = level_origin(blur, g, frame, level) + x;
+    const int lastRow = lg.h + kEdge - 1;
+    const unsigned KA = 18u | (34u << 8) | (48u << 16) | (56u << 24);  // taps of pixels x-3 .. x
+    const unsigned KB = 48u | (34u << 8) | (18u << 16);                // taps of pixels x+1 .. x+3
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    const ushort2v K01 = {18, 34}, K23 = {48, 56}, K45 = {48, 34};
+    unsigned pairs[4][6];  // pairs[c][r % 6] = h[r] | h[r+1] << 16 for the last six rows
+    unsigned prev[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int x = tx + k;
-        const uint32_t acc = 18u * (hbuf[ty][x] + hbuf[ty + 6][x]) + 34u * (hbuf[ty + 1][x] + hbuf[ty + 5][x]) +
-                             48u * (hbuf[ty + 2][x] + hbuf[ty + 4][x]) + 56u * hbuf[ty + 3][x];
-        packed |= ((acc + 32768u) >> 16) << (8 * k);
+    for (int r = 0; r < kBlurStrip + 6; r++) {
+        const int y = min(y0 + r - 3, lastRow);
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(src + (ptrdiff_t)y * lg.stride);
+        const unsigned d0 = row[0], d1 = row[1], d2 = row[2];
+        unsigned hsum[4];
+        hsum[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, 0u, false), false);
+        hsum[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, 0u, false), false);
+        hsum[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, 0u, false), false);
+        hsum[3] = __builtin_amdgcn_udot4(d1, KA, __builtin_amdgcn_udot4(d2, KB, 0u, false), false);
+        unsigned acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (r >= 1) pairs[c][(r - 1) % 6] = prev[c] | (hsum[c] << 16);
+            prev[c] = hsum[c];
+            if (r >= 6) {  // output row y0 + r - 6: rows r-6 .. r
+                unsigned a = 32768u + hsum[c] * 18u;
+                a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pairs[c][(r - 6) % 6]), K01, a, false);
+                a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pairs[c][(r - 4) % 6]), K23, a, false);
+                a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pairs[c][(r - 2) % 6]), K45, a, false);
+                acc[c] = a;
+            }
+        }
+        if (r >= 6) {
+            const int yo = y0 + r - 6;
+            if (yo < lg.h) {
+                // byte 2 of each accumulator is the pixel
+                const unsigned lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
+                const unsigned hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
+                *reinterpret_cast<uint32_t *>(dst + (ptrdiff_t)yo * lg.stride) = lo | hi;  // row pitch leaves room past w
+            }
+        }
     }
-    uint8_t *dst = level_origin(blur, g, frame, t.level) + (ptrdiff_t)y * lg.stride + t.x0 + tx;
-    if (t.x0 + tx < lg.w) *reinterpret_cast<uint32_t *>(dst) = packed;  // row stride leaves room past w
 }
 
 // ---------------------------------------------------------------------------------------------
