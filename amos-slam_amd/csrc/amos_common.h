@@ -57,6 +57,8 @@ struct Geom {
     int kpCap;           // capacity of the concatenated result per frame
     int iniTh, minTh;
     int blurItems;       // blur work items per frame, all levels
+    // FAST LDS carve (per wave = per cell), sized by the largest cell of the geometry
+    int fastTileStrideDw, fastTileRows, fastMapRows, fastKeptCap, fastWaveBytes;
     unsigned long long frameBytes;  // bytes of one frame's pyramid
     LevelGeom lv[AMOS_MAX_LEVELS];
 };
@@ -66,8 +68,11 @@ struct Cell {
     short level;
     short x0, y0;  // first tested pixel (level coordinates) = (iniX + 3, iniY + 3)
     short tw, th;  // tested region size
-    short pad;
+    short ndw;     // dwords per staged tile row = (tw + 10) / 4
     int slotOff;   // first candidate slot of the cell inside one frame
+    unsigned magicDw, magicG;  // (1 << 20) / d + 1 for d = ndw, groups: division by multiplication
+    short groups;  // 4-pixel groups per row = (tw + 3) / 4
+    short pad[3];
 };
 
 // Resize coefficients of one destination column / row (cv::resize fixed point, 11 bits).  The tables

@@ -156,7 +156,7 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
     g.iniTh = h->p.ini_th_fast;
     g.minTh = h->p.min_th_fast;
     size_t off = 0;
-    int cellIdx = 0, slotOff = 0, ptsOff = 0, kpOff = 0, tabOff = 0, blurOff = 0;
+    int cellIdx = 0, slotOff = 0, ptsOff = 0, kpOff = 0, tabOff = 0, blurOff = 0, maxTw = 1, maxTh = 1;
     if (cells) cells->clear();
     if (taps) taps->clear();
     for (int l = 0; l < L; l++) {
@@ -205,6 +205,12 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
                 c.tw = (short)tw;
                 c.th = (short)th;
                 c.slotOff = slotOff;
+                c.ndw = (short)((tw + 10) >> 2);
+                c.groups = (short)((tw + 3) >> 2);
+                c.magicDw = (1u << 20) / (unsigned)c.ndw + 1u;
+                c.magicG = (1u << 20) / (unsigned)c.groups + 1u;
+                maxTw = std::max(maxTw, tw);
+                maxTh = std::max(maxTh, th);
                 const int cap = ((tw + 1) / 2) * ((th + 1) / 2);  // 3x3 strict NMS keeps <= 1 per 2x2
                 slotOff += cap;
                 levelPts += cap;
@@ -255,6 +261,12 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
     g.kpLevelTotal = kpOff;
     g.kpCap = kpOff;
     g.blurItems = blurOff;
+    g.fastTileStrideDw = (maxTw + 10) >> 2;
+    g.fastTileRows = maxTh + 6;
+    g.fastMapRows = maxTh + 2;
+    g.fastKeptCap = ((maxTw + 1) / 2) * ((maxTh + 1) / 2);
+    g.fastWaveBytes = (int)align_up_sz(align_up_sz((size_t)g.fastTileRows * g.fastTileStrideDw * 4, 16) + (size_t)g.fastMapRows * kFastMapStride +
+                                       kFastCandCap * 2 + (size_t)g.fastKeptCap * 4, 16);
     return AMOS_OK;
 }
 
@@ -309,8 +321,8 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
             hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);
     }
     if (ev) (void)hipEventRecord(ev[1], h->stream);
-    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nFrames), dim3(kFastThreads), 0, h->stream, h->dPyr, h->dGeom, h->dCells,
-                       h->dSlotCount, h->dSlots);
+    hipLaunchKernelGGL(k_fast_cells, dim3((g.totalCells + 3) / 4, nFrames), dim3(256), 4 * (size_t)g.fastWaveBytes, h->stream, h->dPyr,
+                       h->dGeom, h->dCells, h->dSlotCount, h->dSlots);
     if (ev) (void)hipEventRecord(ev[2], h->stream);
     const size_t lds = oct_lds_bytes(h->octNC, h->octSC);
     hipLaunchKernelGGL(k_octree, dim3(nFrames * g.nLevels), dim3(256), lds, h->stream, h->dGeom, h->dCells, h->dSlotCount,

@@ -165,7 +165,6 @@ __device__ __forceinline__ int fast_arc_value(const uint8_t *c, int s)
     return max(max((int)best.x, (int)best.y), 0);
 }
 
-constexpr int kFastTileStride = 72;  // bytes per LDS tile row = 18 dwords >= 4 + cell + 3 halo
 constexpr int kFastMapStride = 64;   // cell + 2 halo <= 61 columns
 constexpr int kFastMaxCell = 59;
 
@@ -185,106 +184,163 @@ __device__ __forceinline__ unsigned fast_compass(short2v c, short2v n, short2v s
     return __builtin_bit_cast(unsigned, t - q) & 0x80008000u;  // t - q < 0  <=>  q > t
 }
 
-// grid = (totalCells, frames), block = 256.  Candidates of a cell are written in FAST's order
-// (row-major) to the cell's own slot range: packed x | y << 12 | score << 24, coordinates relative
-// to (minBorderX, minBorderY) as the reference hands them to DistributeOctTree.
-#ifndef AMOS_FAST_THREADS
-#define AMOS_FAST_THREADS 256
-#endif
-constexpr int kFastThreads = AMOS_FAST_THREADS;
-__global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
+// grid = (ceil(totalCells / 4), frames), block = 256: ONE WAVE PER CELL, four independent cells per
+// work-group and no work-group barrier anywhere (a 30-px cell is ~1000 pixels: one wave's worth of
+// work; four waves per cell spent more scalar and barrier time than vector time).  Counters live
+// in SGPRs (ballot + popcount), LDS is carved per wave and sized by the geometry's largest cell.
+// Candidates of a cell are written in FAST's order (row-major) to the cell's own slot range:
+// packed x | y << 12 | score << 24, coordinates relative to (minBorderX, minBorderY) as the
+// reference hands them to DistributeOctTree.
+constexpr int kFastCandCap = 1024;  // candidate list; a cell with more falls back to scanning the arc map
+
+__device__ __forceinline__ void fast_score_chunk(const uint8_t *tile, int tileStride, uint8_t *amap, const uint16_t *cand,
+                                                 int first, int count, int lane, int t)
+{
+    if (lane < count) {
+        const int p = cand[first + lane];
+        const int y = p >> 6, x = p & 63;
+        const int a = fast_arc_value(tile + y * tileStride + x, tileStride);
+        amap[(y + 1) * kFastMapStride + x + 1] = (uint8_t)(a > t ? a : 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
                                                    const Cell *__restrict__ cells, int *__restrict__ slotCount,
                                                    uint32_t *__restrict__ slots)
 {
-    constexpr int kRowDw = kFastTileStride / 4;
-    __shared__ uint32_t tile32[(kFastMaxCell + 6) * kRowDw];
-    __shared__ uint8_t amap[(kFastMaxCell + 2) * kFastMapStride];
-    __shared__ uint16_t cand[kFastMaxCell * kFastMaxCell];
-    __shared__ uint32_t kept[((kFastMaxCell + 1) / 2) * ((kFastMaxCell + 1) / 2)];
-    __shared__ int counters[2];
-    const int tid = threadIdx.x;
+    extern __shared__ __align__(16) unsigned char fast_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frame = blockIdx.y;
-    const Cell c = cells[blockIdx.x];
+    const int cellIdx = blockIdx.x * 4 + wave;
+    if (cellIdx >= g->totalCells) return;  // wave-uniform; no work-group barrier below
+    const Cell c = cells[cellIdx];
     const LevelGeom &lg = g->lv[c.level];
+    const int rowDw = g->fastTileStrideDw, tileStride = rowDw * 4;
+    unsigned char *base = fast_smem + (size_t)wave * g->fastWaveBytes;
+    uint32_t *tile32 = reinterpret_cast<uint32_t *>(base);
+    uint8_t *amap = base + (((size_t)g->fastTileRows * tileStride + 15) & ~(size_t)15);
+    uint16_t *cand = reinterpret_cast<uint16_t *>(amap + (size_t)g->fastMapRows * kFastMapStride);
+    uint32_t *kept = reinterpret_cast<uint32_t *>(cand + kFastCandCap);
     const uint8_t *img = level_origin(pyr, g, frame, c.level);
     const int tw = c.tw, th = c.th;
     // LDS row r holds image row y0 - 3 + r; LDS byte b of a row holds image column x0 - 4 + b
     const int ga = (c.x0 - 4) & ~3, sh = (c.x0 - 4) & 3;
-    const int ndw = (tw + 10) >> 2;  // bytes 0 .. tw + 6 (pixels x0 - 4 .. x0 + tw + 2)
-    const int lh = th + 6;
-    const unsigned magicDw = (1u << 20) / (unsigned)ndw + 1u;
-    for (int idx = tid; idx < lh * ndw; idx += kFastThreads) {
-        const int r = div_small(idx, magicDw), cc = idx - r * ndw;
+    const int ndw = c.ndw, lh = th + 6;
+    for (int idx = lane; idx < lh * ndw; idx += 64) {
+        const int r = div_small(idx, c.magicDw), cc = idx - r * ndw;
         const uint32_t *src = reinterpret_cast<const uint32_t *>(img + (ptrdiff_t)(c.y0 - 3 + r) * lg.stride + ga) + cc;
-        tile32[r * kRowDw + cc] = __builtin_amdgcn_alignbyte(src[1], src[0], (unsigned)sh);
+        tile32[r * rowDw + cc] = __builtin_amdgcn_alignbyte(src[1], src[0], (unsigned)sh);
     }
-    for (int idx = tid; idx < (th + 2) * (kFastMapStride / 4); idx += kFastThreads) reinterpret_cast<uint32_t *>(amap)[idx] = 0;
-    const uint8_t *tile = reinterpret_cast<const uint8_t *>(tile32) + 3 * kFastTileStride + 4;  // pixel (x0, y0)
+    for (int idx = lane; idx < (th + 2) * (kFastMapStride / 16); idx += 64) reinterpret_cast<uint4 *>(amap)[idx] = uint4{0, 0, 0, 0};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t *tile = reinterpret_cast<const uint8_t *>(tile32) + 3 * tileStride + 4;  // pixel (x0, y0)
     const int iniTh = min(max(g->iniTh, 0), 255), minTh = min(max(g->minTh, 0), 255);
-    const int groups = (tw + 3) >> 2;
-    const unsigned magicG = (1u << 20) / (unsigned)groups + 1u;
-    const int nitems = th * groups;
-    uint32_t *out = slots + (size_t)frame * g->slotTotal + c.slotOff;
+    const int groups = c.groups, nitems = th * groups;
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
     int nkept = 0;
     for (int pass = 0; pass < 2; pass++) {
         const int t = pass == 0 ? iniTh : minTh;
         if (pass == 1 && minTh >= iniTh) break;  // a second cv::FAST at a higher threshold finds nothing new
-        if (tid < 2) counters[tid] = 0;
-        __syncthreads();
-        // ---- phase 1: necessary test, 4 pixels per lane
+        // ---- phase 1 (necessary test, 4 pixels per lane) feeding phase 2 (exact arc value) in dense chunks
         const short2v tt = short2v{(short)t, (short)t};
-        for (int item = tid; item < nitems; item += kFastThreads) {
-            const int y = div_small(item, magicG), gx = item - y * groups;
-            const uint32_t *row = tile32 + (y + 3) * kRowDw + gx;  // dword holding pixels x0 + 4gx - 4 ..
-            const unsigned L = row[0], C = row[1], R = row[2];
-            const unsigned N = row[1 - 3 * kRowDw], S = row[1 + 3 * kRowDw];
-            const unsigned W = __builtin_amdgcn_alignbyte(C, L, 1u);  // pixels x-3 .. x
-            const unsigned E = __builtin_amdgcn_alignbyte(R, C, 3u);  // pixels x+3 .. x+6
-            unsigned m = fast_compass(unpack_lo(C), unpack_lo(N), unpack_lo(S), unpack_lo(E), unpack_lo(W), tt) >> 15;
-            unsigned mh = fast_compass(unpack_hi(C), unpack_hi(N), unpack_hi(S), unpack_hi(E), unpack_hi(W), tt) >> 15;
-            // bits: pixel0 = m bit 0, pixel1 = m bit 16, pixel2 = mh bit 0, pixel3 = mh bit 16
-            unsigned bits = (m & 1u) | ((m >> 15) & 2u) | ((mh & 1u) << 2) | ((mh >> 13) & 8u);
-            const int valid = tw - 4 * gx;  // pixels of this group inside the cell
-            if (valid < 4) bits &= (1u << valid) - 1u;
-            if (bits) {
-                int pos = atomicAdd(&counters[0], __popc(bits));
-                const int p0 = (y << 6) | (4 * gx);
+        int ncand = 0, done = 0;   // list entries [0, done) have their arc value
+        bool overflow = false;     // wave-uniform: the list wrapped, phase 3 must scan the arc map instead
+        for (int item0 = 0; item0 < nitems; item0 += 64) {
+            const int item = item0 + lane;
+            unsigned bits = 0;
+            int p0 = 0;
+            if (item < nitems) {
+                const int y = div_small(item, c.magicG), gx = item - y * groups;
+                const uint32_t *row = tile32 + (y + 3) * rowDw + gx;  // dword holding pixels x0 + 4gx - 4 ..
+                const unsigned L = row[0], C = row[1], R = row[2];
+                const unsigned N = row[1 - 3 * rowDw], S = row[1 + 3 * rowDw];
+                const unsigned W = __builtin_amdgcn_alignbyte(C, L, 1u);  // pixels x-3 .. x
+                const unsigned E = __builtin_amdgcn_alignbyte(R, C, 3u);  // pixels x+3 .. x+6
+                const unsigned m = fast_compass(unpack_lo(C), unpack_lo(N), unpack_lo(S), unpack_lo(E), unpack_lo(W), tt) >> 15;
+                const unsigned mh = fast_compass(unpack_hi(C), unpack_hi(N), unpack_hi(S), unpack_hi(E), unpack_hi(W), tt) >> 15;
+                bits = (m & 1u) | ((m >> 15) & 2u) | ((mh & 1u) << 2) | ((mh >> 13) & 8u);
+                const int valid = tw - 4 * gx;  // pixels of this group inside the cell
+                if (valid < 4) bits &= (1u << valid) - 1u;
+                p0 = (y << 6) | (4 * gx);
+            }
+            if (ncand + 256 > kFastCandCap) {  // wave-uniform: make room, remember that the list is no longer complete
+                fast_score_chunk(tile, tileStride, amap, cand, done, min(ncand - done, 64), lane, t);  // < 64 left over
+                ncand = done = 0;
+                overflow = true;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (bits & (1u << k)) cand[pos++] = (uint16_t)(p0 + k);
+            for (int k = 0; k < 4; k++) {
+                const bool b = (bits >> k) & 1u;
+                const unsigned long long bal = __ballot(b);
+                if (b) cand[ncand + __popcll(bal & ltmask)] = (uint16_t)(p0 + k);
+                ncand += __popcll(bal);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            while (ncand - done >= 64) {  // wave-uniform: dense chunks of 64 survivors
+                fast_score_chunk(tile, tileStride, amap, cand, done, 64, lane, t);
+                done += 64;
             }
         }
-        __syncthreads();
-        // ---- phase 2: exact arc value of the survivors
-        const int nc = counters[0];
-        for (int i = tid; i < nc; i += kFastThreads) {
-            const int p = cand[i];
-            const int y = p >> 6, x = p & 63;
-            const int a = fast_arc_value(tile + y * kFastTileStride + x, kFastTileStride);
-            amap[(y + 1) * kFastMapStride + x + 1] = (uint8_t)(a > t ? a : 0);
-        }
-        __syncthreads();
-        // ---- phase 3: strict 3x3 NMS over the survivors.  For a corner at threshold t (a > t) every
-        // non-corner neighbour is smaller than a anyway, so the test is simply "a > all 8 neighbours".
-        for (int i = tid; i < nc; i += kFastThreads) {
-            const int p = cand[i];
-            const int y = p >> 6, x = p & 63;
-            const uint8_t *m = &amap[(y + 1) * kFastMapStride + x + 1];
-            const int a = m[0];
-            if (a > t) {
-                const int s = kFastMapStride;
-                const int nmax = max(max(max((int)m[-s - 1], (int)m[-s]), max((int)m[-s + 1], (int)m[-1])),
-                                     max(max((int)m[1], (int)m[s - 1]), max((int)m[s], (int)m[s + 1])));
-                if (nmax < a) kept[atomicAdd(&counters[1], 1)] = ((uint32_t)p << 8) | (uint32_t)a;
+        fast_score_chunk(tile, tileStride, amap, cand, done, ncand - done, lane, t);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 3: strict 3x3 NMS.  For a corner at threshold t (a > t) every non-corner neighbour is
+        // smaller than a anyway: keep <=> a > all 8 neighbours.  Over the survivor list, or (list overflowed)
+        // over the non-zero entries of the arc map.
+        if (!overflow) {
+            for (int i0 = 0; i0 < ncand; i0 += 64) {
+                const int i = i0 + lane;
+                bool keep = false;
+                int p = 0, a = 0;
+                if (i < ncand) {
+                    p = cand[i];
+                    const uint8_t *m = amap + ((p >> 6) + 1) * kFastMapStride + (p & 63) + 1;
+                    a = m[0];
+                    if (a) {
+                        const int s = kFastMapStride;
+                        const int nmax = max(max(max((int)m[-s - 1], (int)m[-s]), max((int)m[-s + 1], (int)m[-1])),
+                                             max(max((int)m[1], (int)m[s - 1]), max((int)m[s], (int)m[s + 1])));
+                        keep = nmax < a;
+                    }
+                }
+                const unsigned long long bal = __ballot(keep);
+                if (keep) kept[nkept + __popcll(bal & ltmask)] = ((uint32_t)p << 8) | (uint32_t)a;
+                nkept += __popcll(bal);
+            }
+        } else {
+            const uint32_t *amap32 = reinterpret_cast<const uint32_t *>(amap);
+            for (int idx0 = 0; idx0 < th * 16; idx0 += 64) {
+                const int idx = idx0 + lane;
+                const int y = idx >> 4, dw = idx & 15;
+                const unsigned v = idx < th * 16 ? amap32[(y + 1) * 16 + dw] : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int a = (v >> (8 * k)) & 0xff;
+                    bool keep = false;
+                    if (a) {
+                        const uint8_t *m = amap + (y + 1) * kFastMapStride + 4 * dw + k;
+                        const int s = kFastMapStride;
+                        const int nmax = max(max(max((int)m[-s - 1], (int)m[-s]), max((int)m[-s + 1], (int)m[-1])),
+                                             max(max((int)m[1], (int)m[s - 1]), max((int)m[s], (int)m[s + 1])));
+                        keep = nmax < a;
+                    }
+                    const unsigned long long bal = __ballot(keep);
+                    if (keep) kept[nkept + __popcll(bal & ltmask)] = ((uint32_t)((y << 6) | (4 * dw + k - 1)) << 8) | (uint32_t)a;
+                    nkept += __popcll(bal);
+                }
             }
         }
-        __syncthreads();
-        nkept = counters[1];
-        if (nkept > 0) break;  // uniform: the cell is not empty at this threshold
-        __syncthreads();       // counters are reset at the top of the next pass
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (nkept > 0) break;  // wave-uniform: the cell is not empty at this threshold
     }
     // ---- ordered output: rank by pixel index = row-major order
-    for (int i = tid; i < nkept; i += kFastThreads) {
+    uint32_t *out = slots + (size_t)frame * g->slotTotal + c.slotOff;
+    for (int i = lane; i < nkept; i += 64) {
         const uint32_t me = kept[i];
         int rank = 0;
         for (int j = 0; j < nkept; j++) rank += kept[j] < me;
@@ -292,7 +348,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
         const int xr = c.x0 + (p & 63) - kMinBorder, yr = c.y0 + (p >> 6) - kMinBorder;
         out[rank] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)(a - 1) << 24);
     }
-    if (tid == 0) slotCount[(size_t)frame * g->totalCells + blockIdx.x] = nkept;
+    if (lane == 0) slotCount[(size_t)frame * g->totalCells + cellIdx] = nkept;
 }
 
 // ---------------------------------------------------------------------------------------------

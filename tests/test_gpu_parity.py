@@ -83,6 +83,31 @@ def test_low_texture_uses_min_threshold(gpu_lib, ob):
     assert len(kg) > 0
 
 
+@pytest.mark.parametrize("kind", ["noise", "checker", "salt"])
+def test_dense_corner_images(gpu_lib, ob, kind):
+    """Adversarial corner densities: white noise (most pixels pass the FAST pre-test, the per-cell
+    candidate list overflows), a 2-px checkerboard and isolated salt pixels (maximal NMS survivors)."""
+    rng = np.random.default_rng(12)
+    if kind == "noise":
+        img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    elif kind == "checker":
+        yy, xx = np.mgrid[0:480, 0:640]
+        img = (((yy // 2 + xx // 2) & 1) * 200 + 20).astype(np.uint8)
+    else:
+        img = np.full((480, 640), 30, np.uint8)
+        img[::2, ::2] = rng.integers(100, 255, (240, 320), dtype=np.uint8)
+    ext, orc = _pair(gpu_lib, ob, 640, 480, 1000, 8)
+    ext.detect(img)
+    orc.detect(img)
+    for l in range(8):
+        _same(ext.level_candidates(l), orc.level_candidates(l), f"FAST candidates level {l}")
+        _same(ext.level_keypoints(l), orc.level_keypoints(l), f"keypoints level {l}")
+    kg, dg = ext.describe()
+    ko, do = orc.describe()
+    _same(kg, ko, "keypoints")
+    _same(dg, do, "descriptors")
+
+
 def test_constant_image_gives_nothing(gpu_lib, ob):
     """No corner anywhere => zero keypoints, descriptors released (ORBextractor.cc:1590)."""
     img = np.full((480, 640), 77, np.uint8)

@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Averages rocprofv3 --pmc counter_collection.csv per kernel (helper for profiling runs)."""
+import collections
+import csv
+import glob
+import sys
+f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    if "amos::" in r["Kernel_Name"]:
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in acc.items():
+    print(k, {c: round(sum(x) / len(x) / 1e6, 2) for c, x in v.items()}, "(1e6, avg/launch)")
