@@ -24,6 +24,21 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i;
 }
 
+// XCD-aware work mapping.  Work-groups are dealt round-robin over the 8 XCDs (b and b + 8 share one,
+// each XCD has its own 4 MiB L2), so a 1-D grid is decoded as: XCD = b % 8 owns frames f = 8k + XCD
+// and walks them one after the other, chunk by chunk.  All work-groups that touch one frame's
+// planes (1.4 MB at 640x480) then run on one XCD close together in time and share its L2; with the
+// plain (chunk, frame) grid every XCD fetched every frame.  Placement is a speed matter only.
+__device__ __forceinline__ bool xcd_frame_chunk(int b, int chunksPerFrame, int nFrames, int &frame, int &chunk)
+{
+    const int xcd = b & 7, q = b >> 3;
+    const int fk = q / chunksPerFrame;
+    frame = fk * 8 + xcd;
+    chunk = q - fk * chunksPerFrame;
+    return frame < nFrames;
+}
+__host__ __device__ inline int xcd_grid(int chunksPerFrame, int nFrames) { return ((nFrames + 7) / 8) * 8 * chunksPerFrame; }
+
 __device__ __forceinline__ const uint8_t *level_origin(const uint8_t *pyr, const Geom *g, int frame, int level)
 {
     const LevelGeom &lg = g->lv[level];
@@ -206,12 +221,13 @@ __device__ __forceinline__ void fast_score_chunk(const uint8_t *tile, int tileSt
 
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
                                                    const Cell *__restrict__ cells, int *__restrict__ slotCount,
-                                                   uint32_t *__restrict__ slots)
+                                                   uint32_t *__restrict__ slots, int nFrames)
 {
     extern __shared__ __align__(16) unsigned char fast_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int frame = blockIdx.y;
-    const int cellIdx = blockIdx.x * 4 + wave;
+    int frame, chunk;
+    if (!xcd_frame_chunk(blockIdx.x, (g->totalCells + 3) >> 2, nFrames, frame, chunk)) return;
+    const int cellIdx = chunk * 4 + wave;
     if (cellIdx >= g->totalCells) return;  // wave-uniform; no work-group barrier below
     const Cell c = cells[cellIdx];
     const LevelGeom &lg = g->lv[c.level];
@@ -368,30 +384,33 @@ struct OctNode {
     short x0, y0, x1, y1;
 };
 
+// Exclusive scan of a[0..n) in LDS by the whole 256-thread work-group; returns the total.
+// Per-thread chunk sums, one wave-level shuffle scan, four wave totals through LDS: two barriers.
+// The caller has a barrier between its writes to a[] and this call.
 __device__ __forceinline__ int block_excl_scan(int *a, int n, int *part)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = (n + 255) >> 8;
     const int b = min(tid * chunk, n), e = min(b + chunk, n);
     int s = 0;
     for (int i = b; i < e; i++) s += a[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    int incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    int run = part[tid] - s;
-    const int total = part[255];
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    const int p0 = part[0], p1 = part[1], p2 = part[2], p3 = part[3];
+    int run = incl - s + (wave > 0 ? p0 : 0) + (wave > 1 ? p1 : 0) + (wave > 2 ? p2 : 0);
     for (int i = b; i < e; i++) {
         const int t = a[i];
         a[i] = run;
         run += t;
     }
     __syncthreads();
-    return total;
+    return p0 + p1 + p2 + p3;
 }
 
 __device__ __forceinline__ int oct_quadrant(const OctNode &b, int x, int y, int &midx, int &midy)
@@ -730,45 +749,53 @@ __device__ __forceinline__ int level_of_slot(const Geom *g, int slot)
     return level;
 }
 
-// grid = (ceil(kpLevelTotal/4), frames), block = 256 (4 keypoints).
+// grid = (ceil(kpLevelTotal/16), frames), block = 256 = 16 keypoints: SIXTEEN LANES PER KEYPOINT.
+// Lane j of a group owns patch columns u = 2j-15 and 2j-14 and walks the 31 rows (fully unrolled,
+// loads unconditional so they are all in flight; masked lanes re-read the centre pixel).
 __device__ __forceinline__ constexpr int umax_of(int v)
 {
     constexpr int t[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, -1};
     return t[v < 0 ? -v : v];
 }
 
-__global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
-                                               amos_keypoint *__restrict__ lvKps, const int *__restrict__ lvCount)
+__device__ __forceinline__ int group16_sum(int v)
 {
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int frame = blockIdx.y;
-    if (slot >= g->kpLevelTotal) return;
-    const int level = level_of_slot(g, slot);
-    if (level < 0) return;
-    const LevelGeom &lg = g->lv[level];
-    if (slot - lg.kpOff >= lvCount[frame * g->nLevels + level]) return;
-    amos_keypoint *kp = lvKps + (size_t)frame * g->kpLevelTotal + slot;
-    const int cx = __float2int_rn(kp->x), cy = __float2int_rn(kp->y);
-    const uint8_t *center = level_origin(pyr, g, frame, level) + (ptrdiff_t)cy * lg.stride + cx;
-    const int u = (lane & 31) - kHalfPatch, au = u < 0 ? -u : u;
-    const bool upper = lane >= 32;
-    int m10 = 0, m01 = 0;
-    // 16 steps, two patch rows per step; loads are unconditional (masked lanes re-read the centre)
-    // so that all 16 are in flight together
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int vA = -kHalfPatch + 2 * i, vB = vA + 1;  // vB = 16 in the last step: umax_of = -1
-        const int v = upper ? vB : vA;
-        const int um = upper ? umax_of(vB) : umax_of(vA);
-        const bool valid = au <= um;
-        const int val = center[valid ? (ptrdiff_t)v * lg.stride + u : 0];
-        m10 += valid ? u * val : 0;
-        m01 += valid ? v * val : 0;
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
+                                               amos_keypoint *__restrict__ lvKps, const int *__restrict__ lvCount, int nFrames)
+{
+    const int j = threadIdx.x & 15;
+    int frame, chunk;
+    if (!xcd_frame_chunk(blockIdx.x, (g->kpLevelTotal + 15) >> 4, nFrames, frame, chunk)) return;
+    const int slot = chunk * 16 + (threadIdx.x >> 4);
+    const int level = slot < g->kpLevelTotal ? level_of_slot(g, slot) : -1;
+    bool active = level >= 0;
+    const LevelGeom &lg = g->lv[active ? level : 0];
+    active = active && (slot - lg.kpOff < lvCount[frame * g->nLevels + (active ? level : 0)]);
+    amos_keypoint *kp = lvKps + (size_t)frame * g->kpLevelTotal + (active ? slot : 0);
+    const int cx = active ? __float2int_rn(kp->x) : kEdge, cy = active ? __float2int_rn(kp->y) : kEdge;
+    const int stride = lg.stride;
+    const uint8_t *center = level_origin(pyr, g, frame, active ? level : 0) + (ptrdiff_t)cy * stride + cx;
+    const int u0 = 2 * j - kHalfPatch, u1 = u0 + 1;  // u1 = 16 for j = 15: never valid
+    const int au0 = u0 < 0 ? -u0 : u0, au1 = u1 < 0 ? -u1 : u1;
+    int m10 = 0, m01 = 0;
+#pragma unroll
+    for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
+        const int um = umax_of(v);
+        const bool ok0 = au0 <= um, ok1 = au1 <= um;
+        const int rowOff = v * stride;
+        const int p0 = center[ok0 ? rowOff + u0 : 0], p1 = center[ok1 ? rowOff + u1 : 0];
+        const int s0 = ok0 ? p0 : 0, s1 = ok1 ? p1 : 0;
+        m10 += u0 * s0 + u1 * s1;
+        m01 += v * (s0 + s1);
     }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
-    if (lane == 0) kp->angle = fast_atan2_deg((float)m01, (float)m10);
+    m10 = group16_sum(m10);
+    m01 = group16_sum(m01);
+    if (active && j == 0) kp->angle = fast_atan2_deg((float)m01, (float)m10);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -903,61 +930,71 @@ __device__ __forceinline__ void glibc_sincosf(float y, float &sinp, float &cosp)
 // ---------------------------------------------------------------------------------------------
 // a9 (second half) + a10  computeDescriptors / computeOrbDescriptor (ORBextractor.cc:173-227,
 // 1525-1540) and the level-0 rescale + concatenation of ProcessDesp (:1747-1820).
-// One wave per keypoint: lane j evaluates the four point pairs j, j+64, j+128, j+192 and four
-// __ballot()s assemble the 256 descriptor bits as four little-endian 64-bit words.
+// SIXTEEN LANES PER KEYPOINT (16 keypoints per work-group): in step i lane j evaluates point pair
+// 16 i + j; one __ballot per step yields, for each of the wave's four keypoints, the 16-bit
+// descriptor word i, which lane i of the group keeps and finally stores (16 x 2 B = one 32-byte
+// row).  The pattern sits in LDS as floats (one ds_read_b128 per pair).
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ blur, const Geom *__restrict__ g,
                                                  const amos_keypoint *__restrict__ lvKps,
                                                  const int *__restrict__ lvCount,
                                                  amos_keypoint *__restrict__ outKps, uint8_t *__restrict__ outDesc,
-                                                 int *__restrict__ outCount)
+                                                 int *__restrict__ outCount, int nFrames)
 {
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int frame = blockIdx.y;
+    __shared__ float4 pat[256];
+    int frame, chunk;
+    if (!xcd_frame_chunk(blockIdx.x, (g->kpLevelTotal + 15) >> 4, nFrames, frame, chunk)) return;
+    {
+        const signed char *p = &c_pattern[threadIdx.x * 4];
+        pat[threadIdx.x] = float4{(float)p[0], (float)p[1], (float)p[2], (float)p[3]};
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, j = threadIdx.x & 15, sub = lane >> 4;
+    const int slot = chunk * 16 + (threadIdx.x >> 4);
     const int *cnt = lvCount + frame * g->nLevels;
-    if (slot == 0 && lane == 0) {
+    if (slot == 0 && j == 0) {
         int total = 0;
         for (int l = 0; l < g->nLevels; l++) total += cnt[l];
         outCount[frame] = total;
     }
-    if (slot >= g->kpLevelTotal) return;
-    const int level = level_of_slot(g, slot);
-    if (level < 0) return;
-    const LevelGeom &lg = g->lv[level];
+    const int level = slot < g->kpLevelTotal ? level_of_slot(g, slot) : -1;
+    bool active = level >= 0;
+    const LevelGeom &lg = g->lv[active ? level : 0];
     const int i = slot - lg.kpOff;
-    if (i >= cnt[level]) return;
+    active = active && i < cnt[active ? level : 0];
     int dstIdx = i;
-    for (int l = 0; l < level; l++) dstIdx += cnt[l];
-    if (dstIdx >= g->kpCap) return;
-    amos_keypoint kp = lvKps[(size_t)frame * g->kpLevelTotal + slot];
+    for (int l = 0; l < (active ? level : 0); l++) dstIdx += cnt[l];
+    active = active && dstIdx < g->kpCap;
+    amos_keypoint kp = lvKps[(size_t)frame * g->kpLevelTotal + (active ? slot : 0)];
+    if (!active) { kp.x = kp.y = (float)kEdge; kp.angle = 0.f; }
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a, b;
     glibc_sincosf(__fmul_rn(kp.angle, factorPI), b, a);
+    const int stride = lg.stride;
     const uint8_t *center =
-        level_origin(blur, g, frame, level) + (ptrdiff_t)__float2int_rn(kp.y) * lg.stride + __float2int_rn(kp.x);
-    unsigned long long word[4];
+        level_origin(blur, g, frame, active ? level : 0) + (ptrdiff_t)__float2int_rn(kp.y) * stride + __float2int_rn(kp.x);
+    unsigned myword = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const signed char *pt = &c_pattern[(64 * w + lane) * 4];
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-        const int r0 = __float2int_rn(__fmaf_rn(x0, b, __fmul_rn(y0, a)));
-        const int c0 = __float2int_rn(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fmaf_rn(x1, b, __fmul_rn(y1, a)));
-        const int c1 = __float2int_rn(__fmaf_rn(x1, a, -__fmul_rn(y1, b)));
-        const int t0 = center[(ptrdiff_t)r0 * lg.stride + c0];
-        const int t1 = center[(ptrdiff_t)r1 * lg.stride + c1];
-        word[w] = __ballot(t0 < t1);
+    for (int step = 0; step < 16; step++) {
+        const float4 pt = pat[16 * step + j];
+        const int r0 = __float2int_rn(__fmaf_rn(pt.x, b, __fmul_rn(pt.y, a)));
+        const int c0 = __float2int_rn(__fmaf_rn(pt.x, a, -__fmul_rn(pt.y, b)));
+        const int r1 = __float2int_rn(__fmaf_rn(pt.z, b, __fmul_rn(pt.w, a)));
+        const int c1 = __float2int_rn(__fmaf_rn(pt.z, a, -__fmul_rn(pt.w, b)));
+        const int t0 = center[r0 * stride + c0];
+        const int t1 = center[r1 * stride + c1];
+        const unsigned long long bal = __ballot(t0 < t1);
+        const unsigned word = (unsigned)(bal >> (16 * sub)) & 0xffffu;
+        if (j == step) myword = word;
     }
-    if (lane < 4) {
-        unsigned long long v = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
-        reinterpret_cast<unsigned long long *>(outDesc + ((size_t)frame * g->kpCap + dstIdx) * 32)[lane] = v;
-    }
-    if (lane == 0) {
-        if (level != 0) {  // keypoint->pt *= scale, ORBextractor.cc:1804-1813
-            kp.x = __fmul_rn(kp.x, lg.scale);
-            kp.y = __fmul_rn(kp.y, lg.scale);
+    if (active) {
+        reinterpret_cast<uint16_t *>(outDesc + ((size_t)frame * g->kpCap + dstIdx) * 32)[j] = (uint16_t)myword;
+        if (j == 0) {
+            if (level != 0) {  // keypoint->pt *= scale, ORBextractor.cc:1804-1813
+                kp.x = __fmul_rn(kp.x, lg.scale);
+                kp.y = __fmul_rn(kp.y, lg.scale);
+            }
+            outKps[(size_t)frame * g->kpCap + dstIdx] = kp;
         }
-        outKps[(size_t)frame * g->kpCap + dstIdx] = kp;
     }
 }
 
