@@ -24,7 +24,7 @@ TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # ORBmatcher.cc:49-51
 EXPORTS = [
     "amos_last_error", "amos_device_count", "amos_orb_create", "amos_orb_destroy", "amos_orb_tables",
     "amos_orb_level_sizes", "amos_orb_detect", "amos_orb_level_count", "amos_orb_level_keypoints",
-    "amos_orb_set_level_keypoints", "amos_orb_gate", "amos_orb_closed_mask", "amos_orb_describe",
+    "amos_orb_set_level_keypoints", "amos_orb_level_layout", "amos_orb_fetch_levels", "amos_orb_store_levels", "amos_orb_gate", "amos_orb_closed_mask", "amos_orb_describe",
     "amos_orb_extract", "amos_orb_level_image", "amos_orb_blurred_image", "amos_orb_level_candidates",
     "amos_orb_extract_batch_device", "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",

@@ -599,6 +599,41 @@ int amos_orb_set_level_keypoints(amos_orb *h, int frame, int level, const amos_k
     return AMOS_OK;
 }
 
+int amos_orb_level_layout(amos_orb *h, int32_t *offsets, int32_t *caps, int32_t *total)
+{
+    if (!h || h->curW == 0) { set_error("amos_orb_level_layout: no frame geometry yet"); return AMOS_ERR_STATE; }
+    for (int l = 0; l < h->geom.nLevels; l++) {
+        if (offsets) offsets[l] = h->geom.lv[l].kpOff;
+        if (caps) caps[l] = h->geom.lv[l].nodeCap;
+    }
+    if (total) *total = h->geom.kpLevelTotal;
+    return AMOS_OK;
+}
+
+int amos_orb_fetch_levels(amos_orb *h, int frame, int32_t *counts, amos_keypoint *buf, int buf_len)
+{
+    if (!h || !h->detected || !counts || !buf || frame < 0 || frame >= h->nFrames) { set_error("amos_orb_fetch_levels: invalid argument or state"); return AMOS_ERR_INVALID; }
+    if (buf_len < h->geom.kpLevelTotal) { set_error("amos_orb_fetch_levels: buffer holds %d keypoints, need %d", buf_len, h->geom.kpLevelTotal); return AMOS_ERR_CAPACITY; }
+    AMOS_HIP_CHECK(hipMemcpyAsync(counts, h->dLvCount + frame * h->geom.nLevels, sizeof(int) * h->geom.nLevels, hipMemcpyDeviceToHost, h->stream));
+    AMOS_HIP_CHECK(hipMemcpyAsync(buf, h->dLvKps + (size_t)frame * h->geom.kpLevelTotal, sizeof(amos_keypoint) * h->geom.kpLevelTotal,
+                                  hipMemcpyDeviceToHost, h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return AMOS_OK;
+}
+
+int amos_orb_store_levels(amos_orb *h, int frame, const int32_t *counts, const amos_keypoint *buf, int buf_len)
+{
+    if (!h || !h->detected || !counts || !buf || frame < 0 || frame >= h->nFrames) { set_error("amos_orb_store_levels: invalid argument or state"); return AMOS_ERR_INVALID; }
+    if (buf_len < h->geom.kpLevelTotal) { set_error("amos_orb_store_levels: buffer holds %d keypoints, need %d", buf_len, h->geom.kpLevelTotal); return AMOS_ERR_CAPACITY; }
+    for (int l = 0; l < h->geom.nLevels; l++)
+        if (counts[l] < 0 || counts[l] > h->geom.lv[l].nodeCap) { set_error("level %d: %d keypoints exceed capacity %d", l, counts[l], h->geom.lv[l].nodeCap); return AMOS_ERR_CAPACITY; }
+    AMOS_HIP_CHECK(hipMemcpyAsync(h->dLvCount + frame * h->geom.nLevels, counts, sizeof(int) * h->geom.nLevels, hipMemcpyHostToDevice, h->stream));
+    AMOS_HIP_CHECK(hipMemcpyAsync(h->dLvKps + (size_t)frame * h->geom.kpLevelTotal, buf, sizeof(amos_keypoint) * h->geom.kpLevelTotal,
+                                  hipMemcpyHostToDevice, h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return AMOS_OK;
+}
+
 int amos_orb_level_candidates(amos_orb *h, int frame, int level, amos_keypoint *out, int cap)
 {
     if (!h || !h->detected || frame < 0 || frame >= h->nFrames || level < 0 || level >= h->geom.nLevels) { set_error("amos_orb_level_candidates: invalid argument or state"); return AMOS_ERR_INVALID; }

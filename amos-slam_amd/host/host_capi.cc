@@ -1,0 +1,162 @@
+// host_capi.cc -- C entry points that drive the C++ drop-in classes (ORB_SLAM2::ORBextractor,
+// ORB_SLAM2::ORBmatcher) so that the Python parity tests can exercise the reference-shaped API
+// itself, not only the C ABI underneath it.  Test harness, not part of the drop-in surface.
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "../../include/amos_host_types.h"
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+
+using namespace ORB_SLAM2;
+
+static thread_local std::string g_host_error;
+
+#define AMOS_HOST_TRY try {
+#define AMOS_HOST_CATCH                                        \
+    }                                                          \
+    catch (const std::exception &e) {                          \
+        g_host_error = e.what();                               \
+        return -100;                                           \
+    }
+
+extern "C" {
+
+const char *amos_host_last_error(void) { return g_host_error.c_str(); }
+
+// 4-arg operator(): ORBextractor(...)(image, Mat(), keypoints, descriptors); optionally mvImagePyramid[level]
+int amos_host_extract(const uint8_t *gray, int w, int h, int nfeatures, float scale, int nlevels, int ini, int min, amos_keypoint *kps,
+                      uint8_t *desc, int cap, int *n, int pyr_level, uint8_t *pyr_out /* (w_l+38)*(h_l+38) or NULL */)
+{
+    AMOS_HOST_TRY
+    ORBextractor ext(nfeatures, scale, nlevels, ini, min);
+    cv::Mat image(h, w, CV_8UC1, (void *)gray, (size_t)w), mask, descriptors;
+    std::vector<cv::KeyPoint> keys;
+    ext(image, mask, keys, descriptors);
+    *n = (int)keys.size();
+    if (*n > cap) return -3;
+    if (*n) std::memcpy(kps, keys.data(), sizeof(amos_keypoint) * keys.size());
+    for (int i = 0; i < *n; i++) std::memcpy(desc + 32 * (size_t)i, descriptors.ptr(i), 32);
+    if (descriptors.empty() != (*n == 0)) return -101;
+    if (pyr_out) {
+        // the ROI must sit inside its padded buffer: read through negative offsets like IC_Angle does
+        const cv::Mat &m = ext.mvImagePyramid[pyr_level];
+        const unsigned char *origin = m.data - (size_t)AMOS_EDGE_THRESHOLD * m.step - AMOS_EDGE_THRESHOLD;
+        for (int y = 0; y < m.rows + 2 * AMOS_EDGE_THRESHOLD; y++)
+            std::memcpy(pyr_out + (size_t)y * (m.cols + 2 * AMOS_EDGE_THRESHOLD), origin + (size_t)y * m.step, m.cols + 2 * AMOS_EDGE_THRESHOLD);
+    }
+    return 0;
+    AMOS_HOST_CATCH
+}
+
+// The live RGB-D flow of Frame.cc:480-496,633: 3-arg operator() -> MovingKeyPoints -> ProcessDesp
+int amos_host_amos_flow(const uint8_t *gray, int w, int h, int nfeatures, float scale, int nlevels, int ini, int min, const uint8_t *mask,
+                        const double *labels, const int32_t *center_ids, int ncenters, const int32_t *rm, int nrm, amos_keypoint *removed,
+                        int *nremoved, amos_keypoint *kps, uint8_t *desc, int cap, int *n, amos_keypoint *level_lists_after /* cap */,
+                        int32_t *level_counts_after)
+{
+    AMOS_HOST_TRY
+    ORBextractor ext(nfeatures, scale, nlevels, ini, min);
+    ext.SetPyramidDownload(false);
+    cv::Mat image(h, w, CV_8UC1, (void *)gray, (size_t)w), none;
+    std::vector<std::vector<cv::KeyPoint>> mvKeysTemp;
+    ext(image, none, mvKeysTemp);
+    cv::Mat imS(h, w, CV_8UC1, (void *)mask, (size_t)w);
+    cv::Mat imLS = labels ? cv::Mat(h, w, CV_64FC1, (void *)labels, (size_t)w * 8) : cv::Mat();
+    std::vector<center> centers(ncenters);
+    for (int i = 0; i < ncenters; i++) centers[i].id = center_ids[i];
+    std::vector<int> rmv(rm, rm + nrm);
+    std::vector<cv::KeyPoint> dyn = ext.MovingKeyPoints(image, imS, imLS, centers, rmv, std::vector<bool>(), mvKeysTemp);
+    *nremoved = (int)dyn.size();
+    if (*nremoved > cap) return -3;
+    if (*nremoved) std::memcpy(removed, dyn.data(), sizeof(amos_keypoint) * dyn.size());
+    std::vector<cv::KeyPoint> mvKeys;
+    cv::Mat mDescriptors;
+    ext.ProcessDesp(image, none, mvKeysTemp, mvKeys, mDescriptors);
+    *n = (int)mvKeys.size();
+    if (*n > cap) return -3;
+    if (*n) std::memcpy(kps, mvKeys.data(), sizeof(amos_keypoint) * mvKeys.size());
+    for (int i = 0; i < *n; i++) std::memcpy(desc + 32 * (size_t)i, mDescriptors.ptr(i), 32);
+    int o = 0;
+    for (int l = 0; l < nlevels; l++) {  // the caller's vectors after ProcessDesp (rescaled in place)
+        level_counts_after[l] = (int)mvKeysTemp[l].size();
+        for (const cv::KeyPoint &kp : mvKeysTemp[l]) std::memcpy(&level_lists_after[o++], &kp, sizeof(amos_keypoint));
+    }
+    return 0;
+    AMOS_HOST_CATCH
+}
+
+int amos_host_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    AMOS_HOST_TRY
+    cv::Mat ma(1, 32, CV_8U, (void *)a), mb(1, 32, CV_8U, (void *)b);
+    return ORBmatcher::DescriptorDistance(ma, mb);
+    AMOS_HOST_CATCH
+}
+
+int amos_host_features_in_area(const amos_frame_view *f, float x, float y, float r, int min_level, int max_level, int32_t *out, int cap)
+{
+    AMOS_HOST_TRY
+    FeatureGrid grid(*f);
+    std::vector<size_t> v = grid.GetFeaturesInArea(x, y, r, min_level, max_level);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int32_t)v[i];
+    return (int)v.size();
+    AMOS_HOST_CATCH
+}
+
+int amos_host_search_by_projection_frame(const amos_frame_view *cur, const amos_proj_query *q, int nq, int32_t *cur_match,
+                                         const float *scale_factors, int nsf, float mbf, float th, int forward, int backward, float nnratio,
+                                         int check_orientation)
+{
+    AMOS_HOST_TRY
+    FeatureGrid grid(*cur);
+    ORBmatcher matcher(nnratio, check_orientation != 0);
+    std::vector<amos_proj_query> pts(q, q + nq);
+    std::vector<int> match(cur_match, cur_match + cur->n);
+    std::vector<float> sf(scale_factors, scale_factors + nsf);
+    const int r = matcher.SearchByProjection(grid, pts, match, sf, mbf, th, forward != 0, backward != 0);
+    std::memcpy(cur_match, match.data(), sizeof(int) * cur->n);
+    return r;
+    AMOS_HOST_CATCH
+}
+
+int amos_host_search_by_projection_points(const amos_frame_view *f, const amos_map_query *q, int nq, int32_t *cur_match, uint8_t *cur_has_obs,
+                                          const float *scale_factors, int nsf, float th, float nnratio)
+{
+    AMOS_HOST_TRY
+    FeatureGrid grid(*f);
+    ORBmatcher matcher(nnratio, true);
+    std::vector<amos_map_query> pts(q, q + nq);
+    std::vector<int> match(cur_match, cur_match + f->n);
+    std::vector<bool> obs(f->n);
+    for (int i = 0; i < f->n; i++) obs[i] = cur_has_obs[i] != 0;
+    std::vector<float> sf(scale_factors, scale_factors + nsf);
+    const int r = matcher.SearchByProjection(grid, pts, match, obs, sf, th);
+    std::memcpy(cur_match, match.data(), sizeof(int) * f->n);
+    for (int i = 0; i < f->n; i++) cur_has_obs[i] = obs[i];
+    return r;
+    AMOS_HOST_CATCH
+}
+
+int amos_host_search_for_initialization(const amos_frame_view *f1, const amos_frame_view *f2, float *prev_matched, int32_t *matches12,
+                                        int window_size, float nnratio, int check_orientation)
+{
+    AMOS_HOST_TRY
+    FeatureGrid grid2(*f2);
+    ORBmatcher matcher(nnratio, check_orientation != 0);
+    std::vector<cv::Point2f> prev(f1->n);
+    for (int i = 0; i < f1->n; i++) prev[i] = cv::Point2f(prev_matched[2 * i], prev_matched[2 * i + 1]);
+    std::vector<int> m12;
+    const int r = matcher.SearchForInitialization(*f1, grid2, prev, m12, window_size);
+    for (int i = 0; i < f1->n; i++) {
+        matches12[i] = m12[i];
+        prev_matched[2 * i] = prev[i].x;
+        prev_matched[2 * i + 1] = prev[i].y;
+    }
+    return r;
+    AMOS_HOST_CATCH
+}
+
+}  // extern "C"

@@ -111,6 +111,13 @@ int amos_orb_level_keypoints(amos_orb *h, int frame, int level, amos_keypoint *o
  * per-level vectors back into MovingKeyPoints / ProcessDesp, Frame.cc:491-496,633). */
 int amos_orb_set_level_keypoints(amos_orb *h, int frame, int level, const amos_keypoint *kps, int n);
 
+/* Bulk forms of the two calls above for the C++ drop-in classes: one transfer for all levels.
+ * Layout: the list of level l occupies buf[offsets[l] .. offsets[l] + counts[l]), capacity
+ * caps[l]; total = buffer length in keypoints.  offsets/caps depend on the frame size only. */
+int amos_orb_level_layout(amos_orb *h, int32_t *offsets, int32_t *caps, int32_t *total);
+int amos_orb_fetch_levels(amos_orb *h, int frame, int32_t *counts, amos_keypoint *buf, int buf_len);
+int amos_orb_store_levels(amos_orb *h, int frame, const int32_t *counts, const amos_keypoint *buf, int buf_len);
+
 /* a8: closing (dilate then erode, 31x31 ellipse) of the 8-bit mask of the level-0 frame size and
  * removal of every keypoint whose scaled position hits a non-zero closed-mask pixel or a removed
  * cluster.  `labels` (row-major doubles, lstride elements per row), `center_ids`, `rm_vector`

@@ -1044,3 +1044,249 @@ void orc_three_maxima(const int32_t *histo, int L, int *ind1, int *ind2, int *in
     if (max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
     else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Frame grid (Frame.cc:431-461, 1007-1030) and Frame::GetFeaturesInArea (Frame.cc:894-1003).   */
+typedef struct {
+    int *cell_start; /* [COLS*ROWS + 1] */
+    int *items;      /* feature indices, insertion order inside a cell */
+    float winv, hinv;
+} ogrid;
+
+static ogrid grid_build(const amos_frame_view *f)
+{
+    ogrid g;
+    const int nc = AMOS_FRAME_GRID_COLS * AMOS_FRAME_GRID_ROWS;
+    g.winv = (float)AMOS_FRAME_GRID_COLS / (float)(f->max_x - f->min_x);
+    g.hinv = (float)AMOS_FRAME_GRID_ROWS / (float)(f->max_y - f->min_y);
+    int *cell = (int *)malloc(sizeof(int) * (f->n > 0 ? f->n : 1));
+    g.cell_start = (int *)calloc(nc + 1, sizeof(int));
+    for (int i = 0; i < f->n; i++) {
+        int px = (int)roundf((f->keys_un[i].x - f->min_x) * g.winv);
+        int py = (int)roundf((f->keys_un[i].y - f->min_y) * g.hinv);
+        if (px < 0 || px >= AMOS_FRAME_GRID_COLS || py < 0 || py >= AMOS_FRAME_GRID_ROWS) { cell[i] = -1; continue; }
+        cell[i] = px * AMOS_FRAME_GRID_ROWS + py;
+        g.cell_start[cell[i] + 1]++;
+    }
+    for (int c = 0; c < nc; c++) g.cell_start[c + 1] += g.cell_start[c];
+    g.items = (int *)malloc(sizeof(int) * (f->n > 0 ? f->n : 1));
+    int *fill = (int *)calloc(nc, sizeof(int));
+    for (int i = 0; i < f->n; i++)
+        if (cell[i] >= 0) g.items[g.cell_start[cell[i]] + fill[cell[i]]++] = i;
+    free(fill); free(cell);
+    return g;
+}
+static void grid_free(ogrid *g) { free(g->cell_start); free(g->items); }
+
+static int grid_area(const ogrid *g, const amos_frame_view *f, float x, float y, float r, int minLevel, int maxLevel,
+                     int32_t *out, int cap)
+{
+    int n = 0;
+    int nMinCellX = (int)floorf((x - f->min_x - r) * g->winv); if (nMinCellX < 0) nMinCellX = 0;
+    if (nMinCellX >= AMOS_FRAME_GRID_COLS) return 0;
+    int nMaxCellX = (int)ceilf((x - f->min_x + r) * g->winv); if (nMaxCellX > AMOS_FRAME_GRID_COLS - 1) nMaxCellX = AMOS_FRAME_GRID_COLS - 1;
+    if (nMaxCellX < 0) return 0;
+    int nMinCellY = (int)floorf((y - f->min_y - r) * g->hinv); if (nMinCellY < 0) nMinCellY = 0;
+    if (nMinCellY >= AMOS_FRAME_GRID_ROWS) return 0;
+    int nMaxCellY = (int)ceilf((y - f->min_y + r) * g->hinv); if (nMaxCellY > AMOS_FRAME_GRID_ROWS - 1) nMaxCellY = AMOS_FRAME_GRID_ROWS - 1;
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * AMOS_FRAME_GRID_ROWS + iy;
+            for (int j = g->cell_start[c]; j < g->cell_start[c + 1]; j++) {
+                const amos_keypoint *kp = &f->keys_un[g->items[j]];
+                if (bCheckLevels) {
+                    if (kp->octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp->octave > maxLevel) continue;
+                }
+                const float distx = kp->x - x, disty = kp->y - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) {
+                    if (n < cap) out[n] = g->items[j];
+                    n++;
+                }
+            }
+        }
+    return n;
+}
+
+int orc_features_in_area(const amos_frame_view *f, float x, float y, float r, int min_level, int max_level,
+                         int32_t *out, int cap)
+{
+    ogrid g = grid_build(f);
+    int n = grid_area(&g, f, x, y, r, min_level, max_level, out, cap);
+    grid_free(&g);
+    return n;
+}
+
+static void prune_histogram(int **hist, int *hn, int32_t *match, int *nmatches, int by_value)
+{
+    int32_t sizes[AMOS_HISTO_LENGTH];
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) sizes[i] = hn[i];
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    orc_three_maxima(sizes, AMOS_HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) {
+        if (i == ind1 || i == ind2 || i == ind3) continue;
+        for (int j = 0; j < hn[i]; j++) {
+            if (by_value) { /* SearchForInitialization: only still-matched entries count (:626-630) */
+                if (match[hist[i][j]] >= 0) { match[hist[i][j]] = -1; (*nmatches)--; }
+            } else {        /* SearchByProjection(F,F): unconditional (:1716-1717) */
+                match[hist[i][j]] = -1; (*nmatches)--;
+            }
+        }
+    }
+}
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono), :1569-1728 */
+int orc_search_by_projection_frame(const amos_frame_view *cur, const amos_proj_query *q, int nq, int32_t *cur_match,
+                                   const float *scale_factors, float mbf, float th, int forward, int backward,
+                                   int check_orientation)
+{
+    ogrid g = grid_build(cur);
+    int nmatches = 0;
+    int *hist[AMOS_HISTO_LENGTH], hn[AMOS_HISTO_LENGTH];
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) { hist[i] = (int *)malloc(sizeof(int) * (nq + 1)); hn[i] = 0; }
+    const float factor = AMOS_HISTO_LENGTH / 360.0f;
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (cur->n + 1));
+    for (int i = 0; i < nq; i++) {
+        const amos_proj_query *p = &q[i];
+        const int nLastOctave = p->octave;
+        const float radius = th * scale_factors[nLastOctave];
+        int nc;
+        if (forward) nc = grid_area(&g, cur, p->u, p->v, radius, nLastOctave, -1, cand, cur->n);
+        else if (backward) nc = grid_area(&g, cur, p->u, p->v, radius, 0, nLastOctave, cand, cur->n);
+        else nc = grid_area(&g, cur, p->u, p->v, radius, nLastOctave - 1, nLastOctave + 1, cand, cur->n);
+        if (nc == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < nc; k++) {
+            const int i2 = cand[k];
+            if (cur_match[i2] >= 0 && q[cur_match[i2]].has_obs) continue;
+            if (cur->u_right && cur->u_right[i2] > 0) {
+                const float ur = p->u - mbf * p->invz;
+                const float er = fabsf(ur - cur->u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = orc_descriptor_distance(p->desc, cur->descriptors + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= AMOS_TH_HIGH) {
+            cur_match[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                float rot = p->angle - cur->keys_un[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == AMOS_HISTO_LENGTH) bin = 0;
+                hist[bin][hn[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_orientation) prune_histogram(hist, hn, cur_match, &nmatches, 0);
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) free(hist[i]);
+    free(cand);
+    grid_free(&g);
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th), :70-175 */
+int orc_search_by_projection_points(const amos_frame_view *f, const amos_map_query *q, int nq, int32_t *cur_match,
+                                    uint8_t *cur_has_obs, const float *scale_factors, float th, float nn_ratio)
+{
+    ogrid g = grid_build(f);
+    int nmatches = 0;
+    const int bFactor = th != 1.0;
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (f->n + 1));
+    for (int iMP = 0; iMP < nq; iMP++) {
+        const amos_map_query *mp = &q[iMP];
+        const int nPredictedLevel = mp->level;
+        float r = mp->view_cos > 0.998 ? 2.5f : 4.0f; /* RadiusByViewingCos, :176-182 */
+        if (bFactor) r *= th;
+        const int nc = grid_area(&g, f, mp->proj_x, mp->proj_y, r * scale_factors[nPredictedLevel], nPredictedLevel - 1,
+                                 nPredictedLevel, cand, f->n);
+        if (nc == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            if (cur_has_obs[idx]) continue;
+            if (f->u_right && f->u_right[idx] > 0) {
+                const float er = fabsf(mp->proj_xr - f->u_right[idx]);
+                if (er > r * scale_factors[nPredictedLevel]) continue;
+            }
+            const int dist = orc_descriptor_distance(mp->desc, f->descriptors + 32 * (size_t)idx);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = f->keys_un[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = f->keys_un[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= AMOS_TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nn_ratio * bestDist2) continue;
+            cur_match[bestIdx] = iMP;
+            cur_has_obs[bestIdx] = mp->has_obs != 0;
+            nmatches++;
+        }
+    }
+    free(cand);
+    grid_free(&g);
+    return nmatches;
+}
+
+/* ORBmatcher::SearchForInitialization, :515-643 */
+int orc_search_for_initialization(const amos_frame_view *f1, const amos_frame_view *f2, float *prev_matched,
+                                  int32_t *matches12, int window_size, float nn_ratio, int check_orientation)
+{
+    ogrid g = grid_build(f2);
+    int nmatches = 0;
+    for (int i = 0; i < f1->n; i++) matches12[i] = -1;
+    int *hist[AMOS_HISTO_LENGTH], hn[AMOS_HISTO_LENGTH];
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) { hist[i] = (int *)malloc(sizeof(int) * (f1->n + 1)); hn[i] = 0; }
+    const float factor = AMOS_HISTO_LENGTH / 360.0f;
+    int *vMatchedDistance = (int *)malloc(sizeof(int) * (f2->n + 1));
+    int *vnMatches21 = (int *)malloc(sizeof(int) * (f2->n + 1));
+    for (int i = 0; i < f2->n; i++) { vMatchedDistance[i] = INT_MAX; vnMatches21[i] = -1; }
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (f2->n + 1));
+    for (int i1 = 0; i1 < f1->n; i1++) {
+        const amos_keypoint *kp1 = &f1->keys_un[i1];
+        const int level1 = kp1->octave;
+        if (level1 > 0) continue;
+        const int nc = grid_area(&g, f2, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window_size, level1, level1, cand, f2->n);
+        if (nc == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int k = 0; k < nc; k++) {
+            const int i2 = cand[k];
+            const int dist = orc_descriptor_distance(f1->descriptors + 32 * (size_t)i1, f2->descriptors + 32 * (size_t)i2);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= AMOS_TH_LOW) {
+            if (bestDist < (float)bestDist2 * nn_ratio) {
+                if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) {
+                    float rot = f1->keys_un[i1].angle - f2->keys_un[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == AMOS_HISTO_LENGTH) bin = 0;
+                    hist[bin][hn[bin]++] = i1;
+                }
+            }
+        }
+    }
+    if (check_orientation) prune_histogram(hist, hn, matches12, &nmatches, 1);
+    for (int i1 = 0; i1 < f1->n; i1++)
+        if (matches12[i1] >= 0) {
+            prev_matched[2 * i1] = f2->keys_un[matches12[i1]].x;
+            prev_matched[2 * i1 + 1] = f2->keys_un[matches12[i1]].y;
+        }
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) free(hist[i]);
+    free(vMatchedDistance); free(vnMatches21); free(cand);
+    grid_free(&g);
+    return nmatches;
+}

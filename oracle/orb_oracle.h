@@ -18,6 +18,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "../include/amos_frontend.h" /* amos_keypoint, amos_best2, amos_orb_params: shared PODs */
+#include "../include/amos_host_types.h" /* amos_frame_view, amos_proj_query, amos_map_query */
 
 #ifdef __cplusplus
 extern "C" {
@@ -88,6 +89,22 @@ void orc_bruteforce_best2(const uint8_t *q, int nq, const uint8_t *t, int nt, in
                           amos_best2 *out);
 /* ORBmatcher::ComputeThreeMaxima, ORBmatcher.cc:1866-1908, on bin sizes. */
 void orc_three_maxima(const int32_t *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
+
+/* ---- gated searches of the tracking thread, over plain frame views ---- */
+/* Frame::GetFeaturesInArea (Frame.cc:894-1003) on a grid built as Frame::AssignFeaturesToGrid does
+ * (Frame.cc:431-461).  Returns the number of indices written. */
+int orc_features_in_area(const amos_frame_view *f, float x, float y, float r, int min_level, int max_level,
+                         int32_t *out, int cap);
+/* ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), ORBmatcher.cc:1569-1728 */
+int orc_search_by_projection_frame(const amos_frame_view *cur, const amos_proj_query *q, int nq, int32_t *cur_match,
+                                   const float *scale_factors, float mbf, float th, int forward, int backward,
+                                   int check_orientation);
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), ORBmatcher.cc:70-175 */
+int orc_search_by_projection_points(const amos_frame_view *f, const amos_map_query *q, int nq, int32_t *cur_match,
+                                    uint8_t *cur_has_obs, const float *scale_factors, float th, float nn_ratio);
+/* ORBmatcher::SearchForInitialization, ORBmatcher.cc:515-643.  prev_matched: n1 x 2 floats, in/out. */
+int orc_search_for_initialization(const amos_frame_view *f1, const amos_frame_view *f2, float *prev_matched,
+                                  int32_t *matches12, int window_size, float nn_ratio, int check_orientation);
 
 #ifdef __cplusplus
 }

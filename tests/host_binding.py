@@ -1,0 +1,146 @@
+"""ctypes binding of amos-slam_amd/host/libamos_host.so (the C++ drop-in classes' test hooks) and
+of the oracle's gated-search restatements."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import oracle_binding as ob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_SO = os.path.join(ROOT, "amos-slam_amd", "host", "libamos_host.so")
+
+KP = ob.KP_DTYPE
+PROJ_QUERY = np.dtype([("u", "<f4"), ("v", "<f4"), ("invz", "<f4"), ("octave", "<i4"), ("angle", "<f4"), ("has_obs", "<i4"),
+                       ("desc", "u1", (32,))])
+MAP_QUERY = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
+                      ("has_obs", "<i4"), ("desc", "u1", (32,))])
+
+
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("keys_un", C.c_void_p), ("descriptors", C.c_void_p), ("u_right", C.c_void_p),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
+
+
+def frame_view(kps, desc, u_right=None, bounds=(0.0, 640.0, 0.0, 480.0)):
+    """Returns (view, keepalive) for numpy arrays."""
+    kps = np.ascontiguousarray(kps, KP)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    v = FrameView(len(kps), kps.ctypes.data, desc.ctypes.data, ur.ctypes.data if ur is not None else None, *bounds)
+    return v, (kps, desc, ur)
+
+
+_host = None
+
+
+def host():
+    global _host
+    if _host is None:
+        import __graft_entry__ as entry
+        entry.load_package().lib()  # loads torch's HIP runtime first, then libamos_frontend.so
+        _host = C.CDLL(HOST_SO)
+        _host.amos_host_last_error.restype = C.c_char_p
+    return _host
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _chk(rc):
+    if rc < 0:
+        raise RuntimeError(f"host call failed rc={rc}: {host().amos_host_last_error().decode()}")
+    return rc
+
+
+def host_extract(gray, nf=1000, sf=1.2, nl=8, ini=20, mn=7, pyr_level=None):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    cap = nf * 2 + 64 * nl
+    kps, desc, n = np.zeros(cap, KP), np.zeros((cap, 32), np.uint8), C.c_int(0)
+    pyr = None
+    if pyr_level is not None:
+        lw, lh = ob.Oracle(nf, sf, nl).level_sizes(w, h)
+        pyr = np.zeros((int(lh[pyr_level]) + 38, int(lw[pyr_level]) + 38), np.uint8)
+    _chk(host().amos_host_extract(_p(gray), C.c_int(w), C.c_int(h), C.c_int(nf), C.c_float(sf), C.c_int(nl), C.c_int(ini), C.c_int(mn),
+                                  _p(kps), _p(desc), C.c_int(cap), C.byref(n), C.c_int(pyr_level or 0), _p(pyr)))
+    return kps[:n.value].copy(), desc[:n.value].copy(), pyr
+
+
+def host_amos_flow(gray, mask, labels=None, center_ids=None, rm=None, nf=1000, sf=1.2, nl=8, ini=20, mn=7):
+    gray, mask = np.ascontiguousarray(gray, np.uint8), np.ascontiguousarray(mask, np.uint8)
+    h, w = gray.shape
+    cap = nf * 2 + 64 * nl
+    kps, desc, n = np.zeros(cap, KP), np.zeros((cap, 32), np.uint8), C.c_int(0)
+    removed, nrem = np.zeros(cap, KP), C.c_int(0)
+    lists, counts = np.zeros(cap, KP), np.zeros(nl, np.int32)
+    if labels is not None:
+        labels = np.ascontiguousarray(labels, np.float64)
+        center_ids = np.ascontiguousarray(center_ids, np.int32)
+        rm = np.ascontiguousarray(rm, np.int32)
+    _chk(host().amos_host_amos_flow(_p(gray), C.c_int(w), C.c_int(h), C.c_int(nf), C.c_float(sf), C.c_int(nl), C.c_int(ini), C.c_int(mn),
+                                    _p(mask), _p(labels), _p(center_ids), C.c_int(0 if center_ids is None else len(center_ids)), _p(rm),
+                                    C.c_int(0 if rm is None else len(rm)), _p(removed), C.byref(nrem), _p(kps), _p(desc), C.c_int(cap),
+                                    C.byref(n), _p(lists), _p(counts)))
+    return removed[:nrem.value].copy(), kps[:n.value].copy(), desc[:n.value].copy(), lists[:counts.sum()].copy(), counts
+
+
+def host_descriptor_distance(a, b):
+    a, b = np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)
+    return _chk(host().amos_host_descriptor_distance(_p(a), _p(b)))
+
+
+def _area(fn, view, x, y, r, lo, hi):
+    out = np.zeros(view.n + 1, np.int32)
+    n = fn(C.byref(view), C.c_float(x), C.c_float(y), C.c_float(r), C.c_int(lo), C.c_int(hi), _p(out), C.c_int(len(out)))
+    assert n >= 0
+    return out[:n].copy()
+
+
+def host_features_in_area(view, x, y, r, lo=-1, hi=-1):
+    return _area(host().amos_host_features_in_area, view, x, y, r, lo, hi)
+
+
+def oracle_features_in_area(view, x, y, r, lo=-1, hi=-1):
+    return _area(ob.lib().orc_features_in_area, view, x, y, r, lo, hi)
+
+
+def search_frame(which, view, queries, cur_match, scale_factors, mbf, th, forward, backward, nnratio=0.9, check_ori=True):
+    queries = np.ascontiguousarray(queries, PROJ_QUERY)
+    match = np.ascontiguousarray(cur_match, np.int32).copy()
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    if which == "host":
+        r = _chk(host().amos_host_search_by_projection_frame(C.byref(view), _p(queries), C.c_int(len(queries)), _p(match), _p(sf),
+                                                             C.c_int(len(sf)), C.c_float(mbf), C.c_float(th), C.c_int(forward),
+                                                             C.c_int(backward), C.c_float(nnratio), C.c_int(check_ori)))
+    else:
+        r = ob.lib().orc_search_by_projection_frame(C.byref(view), _p(queries), C.c_int(len(queries)), _p(match), _p(sf), C.c_float(mbf),
+                                                    C.c_float(th), C.c_int(forward), C.c_int(backward), C.c_int(check_ori))
+    return r, match
+
+
+def search_points(which, view, queries, cur_match, cur_has_obs, scale_factors, th, nnratio=0.8):
+    queries = np.ascontiguousarray(queries, MAP_QUERY)
+    match = np.ascontiguousarray(cur_match, np.int32).copy()
+    obs = np.ascontiguousarray(cur_has_obs, np.uint8).copy()
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    if which == "host":
+        r = _chk(host().amos_host_search_by_projection_points(C.byref(view), _p(queries), C.c_int(len(queries)), _p(match), _p(obs), _p(sf),
+                                                              C.c_int(len(sf)), C.c_float(th), C.c_float(nnratio)))
+    else:
+        r = ob.lib().orc_search_by_projection_points(C.byref(view), _p(queries), C.c_int(len(queries)), _p(match), _p(obs), _p(sf),
+                                                     C.c_float(th), C.c_float(nnratio))
+    return r, match, obs
+
+
+def search_init(which, view1, view2, prev_matched, window=100, nnratio=0.9, check_ori=True):
+    prev = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.zeros(view1.n, np.int32)
+    if which == "host":
+        r = _chk(host().amos_host_search_for_initialization(C.byref(view1), C.byref(view2), _p(prev), _p(m12), C.c_int(window),
+                                                            C.c_float(nnratio), C.c_int(check_ori)))
+    else:
+        r = ob.lib().orc_search_for_initialization(C.byref(view1), C.byref(view2), _p(prev), _p(m12), C.c_int(window), C.c_float(nnratio),
+                                                   C.c_int(check_ori))
+    return r, m12, prev

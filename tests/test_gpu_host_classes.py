@@ -1,0 +1,154 @@
+"""GPU: the C++ drop-in classes (ORB_SLAM2::ORBextractor / ORBmatcher in amos-slam_amd/host) driven
+through their reference-shaped methods, against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hb(gpu_lib):
+    import host_binding
+    host_binding.host()
+    return host_binding
+
+
+def _same(a, b, what):
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    assert a.tobytes() == b.tobytes(), f"{what} differs"
+
+
+def test_extractor_call_operator(hb, ob, synth):
+    """ORBextractor::operator()(image, mask, keypoints, descriptors) + mvImagePyramid ROI."""
+    img = synth.frame(13, 4)
+    kps, desc, pyr = hb.host_extract(img, pyr_level=2)
+    orc = ob.Oracle()
+    ko, do = orc.extract(img)
+    _same(kps, ko, "keypoints")
+    _same(desc, do, "descriptors")
+    _same(pyr, orc.level_image(2, padded=True), "mvImagePyramid[2] incl. border")
+
+
+def test_extractor_other_params(hb, ob, synth):
+    img = synth.frame(14, 0, 360, 480)
+    kps, desc, _ = hb.host_extract(img, nf=600, sf=1.3, nl=5, ini=25, mn=9)
+    ko, do = ob.Oracle(600, 1.3, 5, 25, 9).extract(img)
+    _same(kps, ko, "keypoints")
+    _same(desc, do, "descriptors")
+
+
+@pytest.mark.parametrize("with_labels", [False, True])
+def test_amos_rgbd_flow(hb, ob, synth, with_labels):
+    """operator()(3-arg) -> MovingKeyPoints -> ProcessDesp, as Frame.cc:480-496,633 calls them."""
+    img, mask = synth.frame(15, 2), synth.person_mask(15, 2)
+    labels = ids = rm = None
+    if with_labels:
+        rng = np.random.default_rng(3)
+        labels = np.kron(rng.integers(1, 16, (15, 20)), np.ones((32, 32))).astype(np.float64)
+        ids = rng.permutation(15).astype(np.int32)
+        rm = np.zeros(15, np.int32)
+        rm[[1, 5, 9]] = 1
+    removed, kps, desc, lists, counts = hb.host_amos_flow(img, mask, labels, ids, rm)
+    orc = ob.Oracle()
+    orc.detect(img)
+    ro = orc.gate(mask, labels, ids, rm)
+    ko, do = orc.describe()
+    _same(removed, ro, "DynaPt")
+    _same(kps, ko, "mvKeys")
+    _same(desc, do, "mDescriptors")
+    # the caller's per-level vectors come back rescaled in place (ORBextractor.cc:1804-1813)
+    assert [int(c) for c in counts] == [len(orc.level_keypoints(l)) for l in range(8)]
+    _same(lists, ko, "mvKeysTemp after ProcessDesp")
+    assert len(removed) > 0
+
+
+def test_descriptor_distance_static(hb, ob):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        a, b = rng.integers(0, 256, 32, dtype=np.uint8), rng.integers(0, 256, 32, dtype=np.uint8)
+        assert hb.host_descriptor_distance(a, b) == ob.descriptor_distance(a, b)
+    assert hb.host_descriptor_distance(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+
+
+def _two_frames(ob, synth, stream=16):
+    orc = ob.Oracle()
+    k0, d0 = orc.extract(synth.frame(stream, 20))
+    k1, d1 = orc.extract(synth.frame(stream, 21))
+    return k0, d0, k1, d1, orc.tables()["scale"]
+
+
+def test_features_in_area(hb, ob, synth):
+    k0, d0, _, _, _ = _two_frames(ob, synth)
+    view, keep = hb.frame_view(k0, d0)
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        x, y = float(rng.uniform(-30, 670)), float(rng.uniform(-30, 510))
+        r = float(rng.uniform(1, 60))
+        lo, hi = (int(rng.integers(-1, 6)), int(rng.integers(-1, 8)))
+        got = hb.host_features_in_area(view, x, y, r, lo, hi)
+        want = hb.oracle_features_in_area(view, x, y, r, lo, hi)
+        assert np.array_equal(got, want)
+        if lo < 0 and hi < 0:  # brute force cross-check of the grid
+            inside = np.nonzero((np.abs(k0["x"] - np.float32(x)) < np.float32(r)) & (np.abs(k0["y"] - np.float32(y)) < np.float32(r)))[0]
+            assert set(inside.tolist()) >= set(got.tolist())
+
+
+@pytest.mark.parametrize("forward,backward", [(0, 0), (1, 0), (0, 1)])
+def test_search_by_projection_frame(hb, ob, synth, forward, backward):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) incl. the greedy
+    already-matched skip, right-coordinate gate and rotation histogram."""
+    k0, d0, k1, d1, sf = _two_frames(ob, synth)
+    rng = np.random.default_rng(2)
+    ur = np.where(rng.random(len(k1)) < 0.7, k1["x"] - rng.uniform(5, 40, len(k1)).astype(np.float32), np.float32(-1)).astype(np.float32)
+    view, keep = hb.frame_view(k1, d1, ur)
+    q = np.zeros(len(k0), hb.PROJ_QUERY)
+    q["u"] = k0["x"] - 2 + rng.normal(0, 1.5, len(k0)).astype(np.float32)
+    q["v"] = k0["y"] - 1 + rng.normal(0, 1.5, len(k0)).astype(np.float32)
+    q["invz"] = rng.uniform(0.2, 2.0, len(k0)).astype(np.float32)
+    q["octave"], q["angle"], q["desc"] = k0["octave"], k0["angle"], d0
+    q["has_obs"] = rng.random(len(k0)) < 0.6
+    match0 = np.full(len(k1), -1, np.int32)
+    for th in (7.0, 15.0):
+        rh, mh = hb.search_frame("host", view, q, match0, sf, 40.0, th, forward, backward)
+        ro, mo = hb.search_frame("oracle", view, q, match0, sf, 40.0, th, forward, backward)
+        assert rh == ro and np.array_equal(mh, mo)
+        assert rh > 50
+    rh, mh = hb.search_frame("host", view, q, match0, sf, 40.0, 15.0, forward, backward, check_ori=False)
+    ro, mo = hb.search_frame("oracle", view, q, match0, sf, 40.0, 15.0, forward, backward, check_ori=False)
+    assert rh == ro and np.array_equal(mh, mo)
+
+
+def test_search_by_projection_points(hb, ob, synth):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th): best / second best with the same-level
+    ratio rule (ORBmatcher.cc:163-167)."""
+    k0, d0, k1, d1, sf = _two_frames(ob, synth, stream=17)
+    rng = np.random.default_rng(4)
+    ur = np.where(rng.random(len(k1)) < 0.5, k1["x"] - 20, -1).astype(np.float32)
+    view, keep = hb.frame_view(k1, d1, ur)
+    q = np.zeros(len(k0), hb.MAP_QUERY)
+    q["proj_x"], q["proj_y"] = k0["x"] - 2, k0["y"] - 1
+    q["proj_xr"] = q["proj_x"] - 20 + rng.normal(0, 3, len(k0)).astype(np.float32)
+    q["view_cos"] = rng.choice([0.9, 0.999], len(k0)).astype(np.float32)
+    q["level"] = np.maximum(k0["octave"], 0)
+    q["has_obs"] = rng.random(len(k0)) < 0.5
+    q["desc"] = d0
+    match0 = np.full(len(k1), -1, np.int32)
+    obs0 = (rng.random(len(k1)) < 0.1).astype(np.uint8)
+    for th in (1.0, 3.0, 5.0):
+        rh, mh, oh = hb.search_points("host", view, q, match0, obs0, sf, th)
+        ro, mo, oo = hb.search_points("oracle", view, q, match0, obs0, sf, th)
+        assert rh == ro and np.array_equal(mh, mo) and np.array_equal(oh, oo)
+    assert rh > 50
+
+
+def test_search_for_initialization(hb, ob, synth):
+    k0, d0, k1, d1, sf = _two_frames(ob, synth, stream=18)
+    v1, keep1 = hb.frame_view(k0, d0)
+    v2, keep2 = hb.frame_view(k1, d1)
+    prev = np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32)
+    for window in (20, 100):
+        rh, mh, ph = hb.search_init("host", v1, v2, prev, window)
+        ro, mo, po = hb.search_init("oracle", v1, v2, prev, window)
+        assert rh == ro and np.array_equal(mh, mo) and np.array_equal(ph, po)
+    assert rh > 30
+    assert (mh[k0["octave"] > 0] == -1).all()  # only level-0 features take part
