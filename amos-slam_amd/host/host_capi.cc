@@ -9,6 +9,7 @@
 #include "../../include/amos_host_types.h"
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
+#include "yolact.h"
 
 using namespace ORB_SLAM2;
 
@@ -156,6 +157,29 @@ int amos_host_search_for_initialization(const amos_frame_view *f1, const amos_fr
         prev_matched[2 * i + 1] = prev[i].y;
     }
     return r;
+    AMOS_HOST_CATCH
+}
+
+// ORB_SLAM2::yolact: construct once per (py file, weights), evaluate one BGR frame
+int amos_host_yolact_eval(const char *py_file, const char *weights, const uint8_t *bgr, int w, int h, uint8_t *mask_out, int *mask_w,
+                          int *mask_h)
+{
+    AMOS_HOST_TRY
+    static yolact *seg = nullptr;
+    static std::string key;
+    const std::string want = std::string(py_file) + "|" + weights;
+    if (!seg || key != want) {
+        delete seg;
+        seg = new yolact(py_file, weights, 20);
+        key = want;
+    }
+    if (!seg->isInitializedResult()) { g_host_error = seg->getErrorDescriptionString(); return -102; }
+    cv::Mat frame(h, w * 3, CV_8UC1, (void *)bgr, (size_t)w * 3), mask;
+    if (!seg->evalImage(frame, mask)) { g_host_error = seg->getErrorDescriptionString(); return -103; }
+    *mask_w = mask.cols;
+    *mask_h = mask.rows;
+    for (int y = 0; y < mask.rows; y++) std::memcpy(mask_out + (size_t)y * mask.cols, mask.ptr(y), mask.cols);
+    return 0;
     AMOS_HOST_CATCH
 }
 

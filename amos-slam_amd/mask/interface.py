@@ -1,0 +1,50 @@
+"""MaskEngine: the Python side of the reference's `yolact` C++ class (yolact_interface.py:834-884).
+
+`eval_chw(image)` takes what the reference's C++ sends (CHW float32 in [0,1], 3 x 640 x 480) and
+returns the 8-bit person mask (480 x 640, values 0 / 255, overlaps wrapping modulo 256);
+`eval_bgr(frame)` takes the raw BGR frame and performs the C++ marshalling on the GPU as well.
+"""
+import torch
+
+from .detect import detect
+from .net import YolactR50
+from .post import person_mask
+from .pre import cxx_marshalling, fast_base_transform, resize_f32_cv
+
+
+class MaskEngine:
+    def __init__(self, weight_path=None, device=None, seed=0):
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("MaskEngine needs a GPU (PyTorch-ROCm); pass device='cpu' explicitly for CPU tests")
+            device = "cuda:0"
+        self.device = torch.device(device)
+        torch.manual_seed(seed)
+        self.net = YolactR50()
+        self.has_weights = False
+        if weight_path:
+            self.net.load_weights(weight_path)
+            self.has_weights = True
+        self.net.eval().to(self.device)
+
+    @torch.no_grad()
+    def network_outputs(self, image_chw):
+        """The raw network outputs for a CHW [0,1] float input (for tests and profiling)."""
+        x = torch.as_tensor(image_chw, dtype=torch.float32, device=self.device)
+        img = x.permute(1, 2, 0) * 255            # image.transpose((1, 2, 0)) * 255
+        img = resize_f32_cv(img, 640, 480)        # cv2.resize(image, (640, 480))
+        return self.net(fast_base_transform(img)), img
+
+    @torch.no_grad()
+    def eval_chw(self, image_chw):
+        pred, img = self.network_outputs(image_chw)
+        h, w = img.shape[:2]
+        mask = person_mask(detect(pred), w, h)
+        if mask is None:  # the reference raises here; its caller keeps the pre-zeroed mask (Tracking.cc:305)
+            return None
+        return mask
+
+    @torch.no_grad()
+    def eval_bgr(self, bgr_u8):
+        frame = torch.as_tensor(bgr_u8, dtype=torch.uint8, device=self.device)
+        return self.eval_chw(cxx_marshalling(frame))

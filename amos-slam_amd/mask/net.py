@@ -1,0 +1,184 @@
+"""YOLACT-ResNet50-FPN (the reference's `yolact_resnet50` configuration, data/config.py:741-812)
+as one plain nn.Module, inference only.
+
+Architecture: ResNet-50 trunk -> C3,C4,C5 -> FPN with 256 features and two
+stride-2 conv downsamples (P3..P7) -> protonet on P3 (3x conv3x3, bilinear x2, conv3x3, conv1x1 ->
+32 prototypes at 138x138, ReLU) and ONE prediction head shared by the five levels (conv3x3 "upfeature"
+then 3x3 convs for 3 anchors x {4 box, 81 class, 32 coefficient} values; tanh on coefficients).
+Module and parameter names follow the reference's state dict (backbone.layers.N.M.convK,
+fpn.lat_layers.N, proto_net.{0,2,4,8,10}, prediction_layers.0.{upfeature.0,bbox_layer,conf_layer,
+mask_layer}, semantic_seg_conv) so `yolact_resnet50_54_800000.pth` loads unchanged.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+NUM_CLASSES = 81        # 80 COCO classes + background, data/config.py:660
+MASK_DIM = 32           # prototypes, config mask_proto_net last entry
+FPN_FEATURES = 256      # fpn_base.num_features
+MAX_SIZE = 550          # yolact_base_config.max_size
+PRED_SCALES = (24, 48, 96, 192, 384)   # one scale per pyramid level
+ASPECT_RATIOS = (1.0, 0.5, 2.0)        # pred_aspect_ratios; anchors are squares (use_square_anchors)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, project=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class ResNet50Trunk(nn.Module):
+    """backbone.py:60-125 with args ([3, 4, 6, 3],); returns the four stage outputs."""
+
+    def __init__(self, blocks=(3, 4, 6, 3)):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layers = nn.ModuleList()
+        self.channels = []
+        inplanes = 64
+        for stage, (planes, n) in enumerate(zip((64, 128, 256, 512), blocks)):
+            stride = 1 if stage == 0 else 2
+            seq = [Bottleneck(inplanes, planes, stride, project=True)]
+            inplanes = planes * 4
+            seq += [Bottleneck(inplanes, planes) for _ in range(n - 1)]
+            self.layers.append(nn.Sequential(*seq))
+            self.channels.append(inplanes)
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
+        outs = []
+        for layer in self.layers:
+            x = layer(x)
+            outs.append(x)
+        return outs
+
+
+class FeaturePyramid(nn.Module):
+    """yolact.py:265-355 with fpn = {256 features, bilinear, 2 conv downsamples, pad, relu on pred layers}."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.lat_layers = nn.ModuleList([nn.Conv2d(c, FPN_FEATURES, 1) for c in reversed(in_channels)])
+        self.pred_layers = nn.ModuleList([nn.Conv2d(FPN_FEATURES, FPN_FEATURES, 3, padding=1) for _ in in_channels])
+        self.downsample_layers = nn.ModuleList([nn.Conv2d(FPN_FEATURES, FPN_FEATURES, 3, padding=1, stride=2) for _ in range(2)])
+
+    def forward(self, feats):
+        n = len(feats)
+        merged = [None] * n
+        top = None
+        for k, lat in enumerate(self.lat_layers):  # deepest level first
+            j = n - 1 - k
+            x = lat(feats[j])
+            if top is not None:
+                x = x + F.interpolate(top, size=feats[j].shape[2:], mode="bilinear", align_corners=False)
+            merged[j] = top = x
+        outs = [None] * n
+        for k, pred in enumerate(self.pred_layers):
+            j = n - 1 - k
+            outs[j] = F.relu(pred(merged[j]))
+        for down in self.downsample_layers:
+            outs.append(down(outs[-1]))
+        return outs
+
+
+class SharedHead(nn.Module):
+    """prediction_layers.0 of the reference (yolact.py:47-201): every level runs these weights."""
+
+    def __init__(self, num_priors=len(ASPECT_RATIOS)):
+        super().__init__()
+        self.upfeature = nn.Sequential(nn.Conv2d(FPN_FEATURES, FPN_FEATURES, 3, padding=1), nn.ReLU(inplace=True))
+        self.bbox_layer = nn.Conv2d(FPN_FEATURES, num_priors * 4, 3, padding=1)
+        self.conf_layer = nn.Conv2d(FPN_FEATURES, num_priors * NUM_CLASSES, 3, padding=1)
+        self.mask_layer = nn.Conv2d(FPN_FEATURES, num_priors * MASK_DIM, 3, padding=1)
+
+    def forward(self, x):
+        b = x.shape[0]
+        x = self.upfeature(x)
+        loc = self.bbox_layer(x).permute(0, 2, 3, 1).reshape(b, -1, 4)
+        conf = self.conf_layer(x).permute(0, 2, 3, 1).reshape(b, -1, NUM_CLASSES)
+        coef = torch.tanh(self.mask_layer(x).permute(0, 2, 3, 1).reshape(b, -1, MASK_DIM))
+        return loc, conf, coef
+
+
+class _NoParams(nn.Module):
+    """Levels 1..4 own no weights (they point at level 0): keeps the ModuleList length of the reference."""
+
+
+class _Upsample2x(nn.Module):
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+
+
+def build_priors(conv_sizes, device="cpu"):
+    """Anchor boxes [cx, cy, w, h] (relative), yolact.py:203-247: for every cell (row-major), every
+    aspect ratio: w = scale * sqrt(ar) / 550, h = w (square anchors kept for weight compatibility)."""
+    rows = []
+    for (h, w), scale in zip(conv_sizes, PRED_SCALES):
+        for j in range(h):
+            for i in range(w):
+                x, y = (i + 0.5) / w, (j + 0.5) / h
+                for ar in ASPECT_RATIOS:
+                    side = scale * math.sqrt(ar) / MAX_SIZE
+                    rows.append((x, y, side, side))
+    return torch.tensor(rows, dtype=torch.float32, device=device)
+
+
+class YolactR50(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.backbone = ResNet50Trunk()
+        self.fpn = FeaturePyramid(self.backbone.channels[1:])
+        c = FPN_FEATURES
+        self.proto_net = nn.Sequential(
+            nn.Conv2d(c, c, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(c, c, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(c, c, 3, padding=1), nn.ReLU(inplace=True), _Upsample2x(), nn.ReLU(inplace=True),
+            nn.Conv2d(c, c, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(c, MASK_DIM, 1))
+        self.prediction_layers = nn.ModuleList([SharedHead()] + [_NoParams() for _ in range(4)])
+        self.semantic_seg_conv = nn.Conv2d(c, NUM_CLASSES - 1, 1)  # training-only head; kept so the .pth loads strictly
+        self._prior_cache = {}
+
+    def load_weights(self, path, map_location="cpu"):
+        """Accepts the reference's checkpoints (yolact.py:477-490: legacy `backbone.layer*` and surplus
+        `fpn.downsample_layers.N` entries are dropped)."""
+        sd = torch.load(path, map_location=map_location)
+        for key in list(sd.keys()):
+            if key.startswith("backbone.layer") and not key.startswith("backbone.layers"):
+                del sd[key]
+            elif key.startswith("fpn.downsample_layers.") and int(key.split(".")[2]) >= 2:
+                del sd[key]
+        return self.load_state_dict(sd, strict=False)
+
+    def forward(self, x):
+        """x: [B, 3, 550, 550] normalised RGB.  Returns raw network outputs (before Detect):
+        loc [B, P, 4], conf [B, P, 81] (softmax), mask [B, P, 32] (tanh), priors [P, 4], proto [B, 138, 138, 32] (ReLU)."""
+        feats = self.backbone(x)[1:]
+        pyramid = self.fpn(feats)
+        proto = F.relu(self.proto_net(pyramid[0])).permute(0, 2, 3, 1).contiguous()
+        head = self.prediction_layers[0]
+        locs, confs, coefs = zip(*(head(p) for p in pyramid))
+        sizes = tuple(tuple(p.shape[2:]) for p in pyramid)
+        key = (sizes, str(x.device))
+        if key not in self._prior_cache:
+            self._prior_cache[key] = build_priors(sizes, x.device)
+        return {"loc": torch.cat(locs, 1), "conf": F.softmax(torch.cat(confs, 1), -1), "mask": torch.cat(coefs, 1),
+                "priors": self._prior_cache[key], "proto": proto}

@@ -144,3 +144,15 @@ def search_init(which, view1, view2, prev_matched, window=100, nnratio=0.9, chec
         r = ob.lib().orc_search_for_initialization(C.byref(view1), C.byref(view2), _p(prev), _p(m12), C.c_int(window), C.c_float(nnratio),
                                                    C.c_int(check_ori))
     return r, m12, prev
+
+
+def host_yolact_eval(py_file, weights, bgr):
+    """ORB_SLAM2::yolact(py_file, weights, 20).evalImage(bgr) -> mask or raises RuntimeError."""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w = bgr.shape[:2]
+    out = np.zeros((h, w), np.uint8)
+    mw, mh = C.c_int(0), C.c_int(0)
+    _chk(host().amos_host_yolact_eval(py_file.encode(), weights.encode(), _p(bgr), C.c_int(w), C.c_int(h), _p(out), C.byref(mw),
+                                      C.byref(mh)))
+    assert (mh.value, mw.value) == (h, w)
+    return out
