@@ -26,7 +26,8 @@ EXPORTS = [
     "amos_orb_level_sizes", "amos_orb_detect", "amos_orb_level_count", "amos_orb_level_keypoints",
     "amos_orb_set_level_keypoints", "amos_orb_level_layout", "amos_orb_fetch_levels", "amos_orb_store_levels", "amos_orb_gate", "amos_orb_closed_mask", "amos_orb_describe",
     "amos_orb_extract", "amos_orb_level_image", "amos_orb_blurred_image", "amos_orb_level_candidates",
-    "amos_orb_extract_batch_device", "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
+    "amos_orb_extract_batch_device", "amos_orb_detect_batch_device", "amos_orb_gate_batch_device",
+    "amos_orb_describe_batch_device", "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device",
@@ -223,6 +224,18 @@ class OrbExtractor:
         _check(self.L.amos_orb_extract_batch_device(self.h, C.c_void_p(d_ptr), C.c_size_t(frame_stride),
                                                     C.c_size_t(row_stride), C.c_int(width), C.c_int(height),
                                                     C.c_int(n_frames)), "amos_orb_extract_batch_device")
+
+    def detect_batch_device(self, d_ptr, frame_stride, row_stride, width, height, n_frames):
+        self.shape = (height, width)
+        _check(self.L.amos_orb_detect_batch_device(self.h, C.c_void_p(d_ptr), C.c_size_t(frame_stride), C.c_size_t(row_stride),
+                                                   C.c_int(width), C.c_int(height), C.c_int(n_frames)), "amos_orb_detect_batch_device")
+
+    def gate_batch_device(self, d_masks, mask_frame_stride, mask_row_stride):
+        _check(self.L.amos_orb_gate_batch_device(self.h, C.c_void_p(d_masks), C.c_size_t(mask_frame_stride),
+                                                 C.c_size_t(mask_row_stride)), "amos_orb_gate_batch_device")
+
+    def describe_batch_device(self):
+        _check(self.L.amos_orb_describe_batch_device(self.h), "amos_orb_describe_batch_device")
 
     def batch_results_device(self):
         kps, desc, cnt, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)

@@ -464,8 +464,8 @@ int amos_orb_create(const amos_orb_params *params, int max_width, int max_height
     ALLOC(h->dRemoved, B * c.kpLevelTotal);
     ALLOC(h->dScratchKps, (size_t)c.ptsTotal);
     ALLOC(h->dMask, (size_t)h->maskPitch * max_height);
-    ALLOC(h->dMaskTmp, (size_t)h->maskPitch * max_height);
-    ALLOC(h->dMaskClosed, (size_t)h->maskPitch * max_height);
+    ALLOC(h->dMaskTmp, B * (size_t)h->maskPitch * max_height);
+    ALLOC(h->dMaskClosed, B * (size_t)h->maskPitch * max_height);
     ALLOC(h->dLabels, (size_t)max_width * max_height);
     ALLOC(h->dNRemoved, B);
     ALLOC(h->dErr, 1);
@@ -682,9 +682,9 @@ int amos_orb_gate(amos_orb *h, const uint8_t *mask, size_t mask_stride, const do
     }
     AMOS_HIP_CHECK(hipMemsetAsync(h->dErr, 0, sizeof(int), h->stream));
     dim3 grid((g.W + 63) / 64, (g.H + 15) / 16);
-    hipLaunchKernelGGL(k_morph31<true>, grid, dim3(256), 0, h->stream, h->dMask, h->dMaskTmp, g.W, g.H, h->maskPitch);
-    hipLaunchKernelGGL(k_morph31<false>, grid, dim3(256), 0, h->stream, h->dMaskTmp, h->dMaskClosed, g.W, g.H, h->maskPitch);
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(256), 0, h->stream, h->dGeom, h->dLvKps, h->dLvCount, h->dMaskClosed, h->maskPitch,
+    hipLaunchKernelGGL(k_morph31<true>, grid, dim3(256), 0, h->stream, h->dMask, (size_t)0, h->maskPitch, h->dMaskTmp, (size_t)0, h->maskPitch, g.W, g.H);
+    hipLaunchKernelGGL(k_morph31<false>, grid, dim3(256), 0, h->stream, h->dMaskTmp, (size_t)0, h->maskPitch, h->dMaskClosed, (size_t)0, h->maskPitch, g.W, g.H);
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(256), 0, h->stream, h->dGeom, h->dLvKps, h->dLvCount, h->dMaskClosed, (size_t)0, h->maskPitch,
                        labels ? h->dLabels : nullptr, g.W, h->dCenterIds, n_centers, h->dRm, n_rm, h->dRemoved, h->dNRemoved, h->dErr);
     AMOS_HIP_CHECK(hipGetLastError());
     int nrem = 0, err = 0;
@@ -774,6 +774,44 @@ int amos_orb_extract_batch_device(amos_orb *h, const uint8_t *d_gray, size_t fra
     rc = launch_detect(h, d_gray, frame_stride, row_stride, n_frames);
     if (rc != AMOS_OK) return rc;
     return launch_describe(h, n_frames);
+}
+
+int amos_orb_detect_batch_device(amos_orb *h, const uint8_t *d_gray, size_t frame_stride, size_t row_stride, int width,
+                                 int height, int n_frames)
+{
+    if (!h || !d_gray || n_frames < 1 || width < 1 || height < 1 || row_stride < (size_t)width) { set_error("amos_orb_detect_batch_device: invalid argument"); return AMOS_ERR_INVALID; }
+    if (n_frames > h->maxB) { set_error("batch of %d frames exceeds the handle's max_batch %d", n_frames, h->maxB); return AMOS_ERR_CAPACITY; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    int rc = set_geometry(h, width, height);
+    if (rc != AMOS_OK) return rc;
+    return launch_detect(h, d_gray, frame_stride, row_stride, n_frames);
+}
+
+int amos_orb_gate_batch_device(amos_orb *h, const uint8_t *d_masks, size_t mask_frame_stride, size_t mask_row_stride)
+{
+    if (!h || !d_masks || mask_row_stride < 1) { set_error("amos_orb_gate_batch_device: invalid argument"); return AMOS_ERR_INVALID; }
+    if (!h->detected) { set_error("amos_orb_gate_batch_device before detect"); return AMOS_ERR_STATE; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    const Geom &g = h->geom;
+    const size_t planeStride = (size_t)h->maskPitch * h->maxH;
+    dim3 grid((g.W + 63) / 64, (g.H + 15) / 16, h->nFrames);
+    AMOS_HIP_CHECK(hipMemsetAsync(h->dErr, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_morph31<true>, grid, dim3(256), 0, h->stream, d_masks, mask_frame_stride, (int)mask_row_stride, h->dMaskTmp, planeStride,
+                       h->maskPitch, g.W, g.H);
+    hipLaunchKernelGGL(k_morph31<false>, grid, dim3(256), 0, h->stream, h->dMaskTmp, planeStride, h->maskPitch, h->dMaskClosed, planeStride,
+                       h->maskPitch, g.W, g.H);
+    hipLaunchKernelGGL(k_gate, dim3(h->nFrames), dim3(256), 0, h->stream, h->dGeom, h->dLvKps, h->dLvCount, h->dMaskClosed, planeStride, h->maskPitch,
+                       (const double *)nullptr, 0, (const int *)nullptr, 0, (const int *)nullptr, 0, h->dRemoved, h->dNRemoved, h->dErr);
+    AMOS_HIP_CHECK(hipGetLastError());
+    h->gated = true;
+    return AMOS_OK;
+}
+
+int amos_orb_describe_batch_device(amos_orb *h)
+{
+    if (!h || !h->detected) { set_error("amos_orb_describe_batch_device before detect"); return AMOS_ERR_STATE; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    return launch_describe(h, h->nFrames);
 }
 
 int amos_orb_batch_results_device(amos_orb *h, const amos_keypoint **d_kps, const uint8_t **d_desc, const int32_t **d_counts,

@@ -1005,17 +1005,19 @@ __constant__ int c_ellipse_dx[31];  // half-width of every element row, host-com
 
 // grid = (ceil(w/64), ceil(h/16)), block = 256; tile staged in LDS with the neutral value outside.
 template <bool kDilate>
-__global__ __launch_bounds__(256) void k_morph31(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w,
-                                                int h, int stride)
+__global__ __launch_bounds__(256) void k_morph31(const uint8_t *__restrict__ src, size_t srcFrameStride, int srcStride,
+                                                uint8_t *__restrict__ dst, size_t dstFrameStride, int stride, int w, int h)
 {
     __shared__ uint8_t tile[46][96];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    src += (size_t)blockIdx.z * srcFrameStride;
+    dst += (size_t)blockIdx.z * dstFrameStride;
     const uint8_t neutral = kDilate ? 0 : 255;
     for (int idx = tid; idx < 46 * 94; idx += 256) {
         const int r = idx / 94, c = idx - r * 94;
         const int y = y0 - 15 + r, x = x0 - 15 + c;
-        tile[r][c] = (y >= 0 && y < h && x >= 0 && x < w) ? src[(size_t)y * stride + x] : neutral;
+        tile[r][c] = (y >= 0 && y < h && x >= 0 && x < w) ? src[(size_t)y * srcStride + x] : neutral;
     }
     __syncthreads();
     const int lx = tid & 63;
@@ -1034,8 +1036,9 @@ __global__ __launch_bounds__(256) void k_morph31(const uint8_t *__restrict__ src
 // One work-group per frame walks the levels in order; kept keypoints are compacted in place
 // (order preserved), removed ones appended to `removed` in the reference's order.
 __global__ __launch_bounds__(256) void k_gate(const Geom *__restrict__ g, amos_keypoint *__restrict__ lvKps,
-                                             int *__restrict__ lvCount, const uint8_t *__restrict__ closed,
-                                             int maskStride, const double *__restrict__ labels, int labelStride,
+                                             int *__restrict__ lvCount, const uint8_t *__restrict__ closedBase,
+                                             size_t closedFrameStride, int maskStride, const double *__restrict__ labels,
+                                             int labelStride,
                                              const int *__restrict__ centerIds, int nCenters,
                                              const int *__restrict__ rm, int nRm,
                                              amos_keypoint *__restrict__ removed, int *__restrict__ nRemoved,
@@ -1044,6 +1047,7 @@ __global__ __launch_bounds__(256) void k_gate(const Geom *__restrict__ g, amos_k
     __shared__ int wkeep[4], wrem[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frame = blockIdx.x;
+    const uint8_t *closed = closedBase + (size_t)frame * closedFrameStride;
     int remBase = 0;
     for (int level = 0; level < g->nLevels; level++) {
         const LevelGeom &lg = g->lv[level];

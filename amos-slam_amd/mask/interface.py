@@ -48,3 +48,21 @@ class MaskEngine:
     def eval_bgr(self, bgr_u8):
         frame = torch.as_tensor(bgr_u8, dtype=torch.uint8, device=self.device)
         return self.eval_chw(cxx_marshalling(frame))
+
+    @torch.no_grad()
+    def eval_bgr_batch(self, frames_u8, chunk=16):
+        """frames_u8: [B, H, W, 3] uint8 on the engine's device.  Returns [B, H, W] uint8 masks (zeros where
+        the network finds nothing, which is what the reference's caller ends up using, Tracking.cc:305).
+        The network runs on `chunk` frames at a time; pre- and post-processing are per frame."""
+        frames = torch.as_tensor(frames_u8, dtype=torch.uint8, device=self.device)
+        B, H, W = frames.shape[:3]
+        out = torch.zeros((B, H, W), dtype=torch.uint8, device=self.device)
+        for b0 in range(0, B, chunk):
+            chw = cxx_marshalling(frames[b0:b0 + chunk])                      # [b, 3, 640, 480]
+            imgs = resize_f32_cv(chw.permute(0, 2, 3, 1) * 255, 640, 480)     # [b, 480, 640, 3]
+            pred = self.net(fast_base_transform(imgs))
+            for k in range(imgs.shape[0]):
+                m = person_mask(detect(pred, k), imgs.shape[2], imgs.shape[1])
+                if m is not None:
+                    out[b0 + k] = m
+        return out

@@ -26,6 +26,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 CONFIGS = {
     # BASELINE.json configs[1]: single MI355X, extract + brute-force match, mask disabled
     "c2": dict(width=640, height=480, n_features=1000, n_levels=8, label="configs[1]: 640x480 L8 N1000 extract+match, mask off"),
+    # BASELINE.json configs[2]: full front-end incl. the YOLACT mask (network on PyTorch-ROCm, random weights
+    # with a biased class head so that ~100 detections exercise the whole post-processing chain)
+    "c3": dict(width=640, height=480, n_features=1000, n_levels=8, mask=True, default_batch=32,
+               label="configs[2]: 640x480 L8 N1000 YOLACT-R50 mask + extract + gate + match"),
     # BASELINE.json configs[4]: synthetic HD stream
     "c5": dict(width=1920, height=1080, n_features=4000, n_levels=12, label="configs[4]: 1920x1080 L12 N4000 extract+match"),
 }
@@ -44,6 +48,7 @@ def algorithmic_bytes(level_w, level_h, n_kp, width, height):
         "blur": 2 * sum(wh),
         "describe": n_kp * (512 + 32),
         "match": 2 * n_kp * 32 + n_kp * 16,
+        "mask_net": 0,  # MFMA-bound convolutions on PyTorch: timed, not part of the HBM roofline
     }
 
 
@@ -69,7 +74,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 256; 32 with the mask; 64 for c5)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--check", action="store_true", help="verify one frame of the batch against the oracle")
@@ -92,7 +97,10 @@ def main():
     shard.init("nccl", torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
 
     cfg = CONFIGS[args.config]
+    if args.batch <= 0:
+        args.batch = cfg.get("default_batch", 256)
     W, H, B = cfg["width"], cfg["height"], args.batch
+    use_mask = bool(cfg.get("mask"))
     frames_np = synth.frames(shard.stream_for_rank(rank), 0, B, H, W)  # one stream per GPU
     d_frames = torch.from_numpy(frames_np).cuda(local_rank)
 
@@ -106,10 +114,35 @@ def main():
     torch.cuda.synchronize()
 
     ev_stream = torch.cuda.ExternalStream(ext.stream, device=local_rank)
-    match_events = []
+    match_events, mask_events = [], []
+    engine = d_bgr = None
+    if use_mask:
+        mask_mod = importlib.import_module("amos_slam_amd.mask")
+        engine = mask_mod.MaskEngine(device=f"cuda:{local_rank}", seed=0)
+        with torch.no_grad():
+            head = engine.net.prediction_layers[0].conf_layer.bias
+            b = head.detach().cpu().view(3, 81).clone()
+            b[:, 1] += 5.0
+            b[1, 3] += 5.5
+            head.copy_(b.view(-1).to(head.device))
+        d_bgr = d_frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()  # gray replicated to BGR, resident in HBM
 
     def step(timed):
-        ext.extract_batch_device(d_frames.data_ptr(), H * W, W, W, H, B)
+        if use_mask:
+            ext.detect_batch_device(d_frames.data_ptr(), H * W, W, W, H, B)
+            with torch.cuda.stream(ev_stream):  # the network runs on the extractor's stream: ordering is implicit
+                if timed:
+                    m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    m0.record(ev_stream)
+                masks = engine.eval_bgr_batch(d_bgr)
+                if timed:
+                    m1.record(ev_stream)
+                    mask_events.append((m0, m1))
+                ext.gate_batch_device(masks.data_ptr(), H * W, W)
+                ext.describe_batch_device()
+                step.keep = masks  # alive until the stream has consumed it
+        else:
+            ext.extract_batch_device(d_frames.data_ptr(), H * W, W, W, H, B)
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
@@ -139,6 +172,8 @@ def main():
 
     stage_ms, n_rec = ext.timing_collect()
     stage_ms["match"] = float(np.mean([a.elapsed_time(b) for a, b in match_events])) if match_events else 0.0
+    if mask_events:
+        stage_ms["mask_net"] = float(np.mean([a.elapsed_time(b) for a, b in mask_events]))
     # result digest: keypoint counts + number of matches within TH_LOW (final gather over RCCL)
     n_kp = [len(ext.batch_fetch(f)[0]) for f in range(min(B, 8))]
     mean_kp = float(np.mean(n_kp))
@@ -158,7 +193,7 @@ def main():
         lw, lh = ext.level_sizes(W, H)
         alg = algorithmic_bytes(lw, lh, mean_kp, W, H)
         total_alg = sum(alg.values())
-        dominant = max(stage_ms, key=lambda k: stage_ms[k])
+        dominant = max((k for k in stage_ms if k != "mask_net"), key=lambda k: stage_ms[k])
         dom_bytes = alg[dominant] * B  # bytes one launch (one batch) of the dominant kernel processes
         dom_ms = stage_ms[dominant]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -174,7 +209,7 @@ def main():
                 traffic = None
         fps = world * B * args.steps / elapsed
         out = {
-            "metric": "front-end frames/sec (ORB extract+match, mask off) at %dx%d" % (W, H),
+            "metric": "front-end frames/sec (ORB extract+match%s) at %dx%d" % ("+mask" if use_mask else ", mask off", W, H),
             "value": round(fps, 1),
             "unit": "frames/s",
             "n_gpus": world,

@@ -155,6 +155,15 @@ int amos_orb_level_candidates(amos_orb *h, int frame, int level, amos_keypoint *
  * the handle's stream; amos_orb_sync() waits. */
 int amos_orb_extract_batch_device(amos_orb *h, const uint8_t *d_gray, size_t frame_stride,
                                   size_t row_stride, int width, int height, int n_frames);
+/* The same split in stages for the full front-end with the mask (a7 -> a8 -> a9 per frame of the
+ * batch, everything device-resident): detect, then gate with n_frames 8-bit masks (frame f at
+ * d_masks + f * mask_frame_stride; label gate off), then describe.  Asynchronous. */
+int amos_orb_detect_batch_device(amos_orb *h, const uint8_t *d_gray, size_t frame_stride, size_t row_stride,
+                                 int width, int height, int n_frames);
+int amos_orb_gate_batch_device(amos_orb *h, const uint8_t *d_masks, size_t mask_frame_stride,
+                               size_t mask_row_stride);
+int amos_orb_describe_batch_device(amos_orb *h);
+
 /* Device pointers of the batch results: keypoints [max_batch][capacity], descriptors
  * [max_batch][capacity][32], counts [max_batch].  Valid until destroy. */
 int amos_orb_batch_results_device(amos_orb *h, const amos_keypoint **d_kps, const uint8_t **d_desc,

@@ -227,6 +227,31 @@ def test_batch_equals_single(gpu_lib, ob, synth):
         _same(dg, do, f"frame {f} descriptors")
 
 
+def test_staged_batch_with_masks(gpu_lib, ob, synth):
+    """Full front-end, device resident: detect -> gate (closed mask) -> describe for a batch,
+    frame by frame equal to the oracle's a7 -> a8 -> a9."""
+    import torch
+    n = 5
+    frames = synth.frames(3, 4, n)
+    masks = np.stack([synth.person_mask(3, 4 + k) for k in range(n)])
+    masks[2] = 0  # one frame without dynamic objects
+    ext = gpu_lib.OrbExtractor(max_batch=n)
+    d_frames, d_masks = torch.from_numpy(frames).cuda(), torch.from_numpy(masks).cuda()
+    torch.cuda.synchronize()
+    ext.detect_batch_device(d_frames.data_ptr(), 480 * 640, 640, 640, 480, n)
+    ext.gate_batch_device(d_masks.data_ptr(), 480 * 640, 640)
+    ext.describe_batch_device()
+    ext.sync()
+    for f in range(n):
+        orc = ob.Oracle()
+        orc.detect(frames[f])
+        orc.gate(masks[f])
+        ko, do = orc.describe()
+        kg, dg = ext.batch_fetch(f)
+        _same(kg, ko, f"frame {f} keypoints")
+        _same(dg, do, f"frame {f} descriptors")
+
+
 def test_hd_config(gpu_lib, ob, synth):
     """BASELINE.json configs[4] geometry: 1920x1080, 4000 features, 12 levels."""
     img = synth.frame(21, 0, 1080, 1920)

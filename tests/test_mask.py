@@ -118,6 +118,14 @@ def test_network_vs_reference_cpu(mask):
     assert _run(mask, "cpu", 2e-4, 2e-5) >= 1 - 1e-3
 
 
+def test_batch_path_equals_single(mask):
+    eng = _engine(mask, "cpu")
+    f0 = _frame()
+    f1 = np.ascontiguousarray(f0[:, ::-1])
+    batch = eng.eval_bgr_batch(torch.from_numpy(np.stack([f0, f1])), chunk=2)
+    assert torch.equal(batch[0], eng.eval_bgr(f0)) and torch.equal(batch[1], eng.eval_bgr(f1))
+
+
 def test_no_detection_returns_none(mask):
     eng = mask.MaskEngine(device="cpu", seed=1)  # unbiased random weights: softmax ~ 1/81 < 0.05
     assert eng.eval_bgr(_frame()) is None
