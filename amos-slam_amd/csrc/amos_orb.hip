@@ -318,9 +318,10 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
     for (int l = 0; l < g.nLevels; l++) {
         const LevelGeom &lg = g.lv[l];
         const int groups = (kPadLeft + lg.w + kEdge + 3) / 4;
-        dim3 grid((groups + 63) / 64, (lg.h + 2 * kEdge + 3) / 4, nFrames), block(64, 4);
+        dim3 grid((groups + 63) / 64, (lg.h + 2 * kEdge + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames), block(64, 4);
+        const int srcAligned = ((uintptr_t)dSrc % 4 == 0) && (frameStride % 4 == 0) && (rowStride % 4 == 0);
         if (l == 0)
-            hipLaunchKernelGGL(k_pyramid_level0, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom);
+            hipLaunchKernelGGL(k_pyramid_level0, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, srcAligned);
         else
             hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);
     }

@@ -58,32 +58,48 @@ __device__ __forceinline__ uint8_t *level_origin(uint8_t *pyr, const Geom *g, in
 // reflect-101 source coordinate (the host-built tap tables are indexed by padded
 // coordinate with the reflection folded in).
 // grid = (ceil(groups/64), ceil((h+38)/4), frames), block = (64, 4).
+constexpr int kPyrRows = 4;  // padded rows per thread (x taps are loaded once, row loads overlap)
+
 __global__ __launch_bounds__(256) void k_pyramid_level0(const uint8_t *__restrict__ src, size_t srcFrameStride,
                                                        size_t srcRowStride, uint8_t *__restrict__ pyr,
-                                                       const Geom *__restrict__ g)
+                                                       const Geom *__restrict__ g, int srcAligned)
 {
     const LevelGeom &lg = g->lv[0];
     const int frame = blockIdx.z;
     const int gx = blockIdx.x * 64 + threadIdx.x;  // dword column, starts at x = -kPadLeft
-    const int yo = blockIdx.y * 4 + threadIdx.y - kEdge;
+    const int row0 = (blockIdx.y * 4 + threadIdx.y) * kPyrRows;
     const int groups = (kPadLeft + lg.w + kEdge + 3) >> 2;
-    if (gx >= groups || yo >= lg.h + kEdge) return;
-    const int yi = reflect101(yo, lg.h);
-    uint8_t *dst = level_origin(pyr, g, frame, 0) + (ptrdiff_t)yo * lg.stride + (gx * 4 - kPadLeft);
-    const uint8_t *s = src + (size_t)frame * srcFrameStride + (size_t)yi * srcRowStride;
-    uint32_t packed = 0;
+    if (gx >= groups) return;
+    const int x0 = gx * 4 - kPadLeft;
+    const bool interior = srcAligned && x0 >= 0 && x0 + 3 < lg.w;  // one aligned source dword
+    int xi[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        int xo = gx * 4 - kPadLeft + k;
+        int xo = x0 + k;
         xo = xo < -kEdge ? -kEdge : (xo > lg.w + kEdge - 1 ? lg.w + kEdge - 1 : xo);
-        packed |= (uint32_t)s[reflect101(xo, lg.w)] << (8 * k);
+        xi[k] = reflect101(xo, lg.w);
     }
-    *reinterpret_cast<uint32_t *>(dst) = packed;
+    uint8_t *plane = level_origin(pyr, g, frame, 0);
+    const uint8_t *s0 = src + (size_t)frame * srcFrameStride;
+#pragma unroll
+    for (int r = 0; r < kPyrRows; r++) {
+        const int yo = row0 + r - kEdge;
+        if (yo >= lg.h + kEdge) break;
+        const uint8_t *s = s0 + (size_t)reflect101(yo, lg.h) * srcRowStride;
+        uint32_t packed;
+        if (interior) {
+            packed = *reinterpret_cast<const uint32_t *>(s + x0);
+        } else {
+            packed = (uint32_t)s[xi[0]] | ((uint32_t)s[xi[1]] << 8) | ((uint32_t)s[xi[2]] << 16) | ((uint32_t)s[xi[3]] << 24);
+        }
+        *reinterpret_cast<uint32_t *>(plane + (ptrdiff_t)yo * lg.stride + x0) = packed;
+    }
 }
 
 // Levels >= 1.  The (at most 12-byte) source window of the four outputs is fetched as three
 // aligned dwords per source row; each output picks its two taps with v_alignbyte and weighs them
 // with one v_dot2_u32_u16.  Valid while 3 * scaleFactor + 5 <= 12 (host-checked: scaleFactor <= 2).
+// A thread keeps its four x-tap records and walks kPyrRows padded rows.
 __global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
                                                       const ResizeTap *__restrict__ taps, int level)
 {
@@ -91,39 +107,51 @@ __global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr
     const LevelGeom &lg = g->lv[level];
     const int frame = blockIdx.z;
     const int gx = blockIdx.x * 64 + threadIdx.x;
-    const int row = blockIdx.y * 4 + threadIdx.y;  // padded row, 0 = yo -19
+    const int row0 = (blockIdx.y * 4 + threadIdx.y) * kPyrRows;  // padded row, 0 = yo -19
     const int groups = (kPadLeft + lg.w + kEdge + 3) >> 2;
-    if (gx >= groups || row >= lg.h + 2 * kEdge) return;
+    const int nrows = lg.h + 2 * kEdge;
+    if (gx >= groups || row0 >= nrows) return;
     const LevelGeom &pg = g->lv[level - 1];
     const uint8_t *prev = level_origin((const uint8_t *)pyr, g, frame, level - 1);
-    const ResizeTap ty = taps[lg.tabY + row];
     const uint4 *txp = reinterpret_cast<const uint4 *>(taps + lg.tabX + gx * 4);
     const uint4 t01 = txp[0], t23 = txp[1];  // four ResizeTap records
     const int ofs[4] = {(int)(short)(t01.x & 0xffff), (int)(short)(t01.z & 0xffff), (int)(short)(t23.x & 0xffff),
                         (int)(short)(t23.z & 0xffff)};
     const unsigned wgt[4] = {t01.y, t01.w, t23.y, t23.w};  // a0 | a1 << 16
     const int base = min(min(ofs[0], ofs[1]), min(ofs[2], ofs[3])) & ~3;
-    const uint32_t *S0 = reinterpret_cast<const uint32_t *>(prev + (ptrdiff_t)ty.ofs * pg.stride + base);
-    const uint32_t *S1 = reinterpret_cast<const uint32_t *>(prev + (ptrdiff_t)ty.ofs1 * pg.stride + base);
-    const unsigned d0 = S0[0], d1 = S0[1], d2 = S0[2];
-    const unsigned e0 = S1[0], e1 = S1[1], e2 = S1[2];
-    const unsigned b0 = (unsigned)ty.a0, b1 = (unsigned)ty.a1;
-    uint32_t packed = 0;
+    unsigned sel[4], shift[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const unsigned o = (unsigned)(ofs[k] - base);
-        const unsigned lo0 = o < 4 ? d0 : (o < 8 ? d1 : d2), hi0 = o < 4 ? d1 : (o < 8 ? d2 : 0u);
-        const unsigned lo1 = o < 4 ? e0 : (o < 8 ? e1 : e2), hi1 = o < 4 ? e1 : (o < 8 ? e2 : 0u);
-        const unsigned w0 = __builtin_amdgcn_alignbyte(hi0, lo0, o & 3u);  // bytes ofs, ofs + 1 of row 0
-        const unsigned w1 = __builtin_amdgcn_alignbyte(hi1, lo1, o & 3u);
-        const ushort2v wk = __builtin_bit_cast(ushort2v, wgt[k]);
-        const unsigned h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, w0, 0x0c010c00u)), wk, 0u, false);
-        const unsigned h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, w1, 0x0c010c00u)), wk, 0u, false);
-        const unsigned v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2u) >> 2;
-        packed |= (v & 0xffu) << (8 * k);
+        sel[k] = o >> 2;  // 0, 1 or 2: which dword pair holds the taps
+        shift[k] = o & 3u;
     }
-    uint8_t *dst = level_origin(pyr, g, frame, level) + (ptrdiff_t)(row - kEdge) * lg.stride + (gx * 4 - kPadLeft);
-    *reinterpret_cast<uint32_t *>(dst) = packed;
+    uint8_t *dstPlane = level_origin(pyr, g, frame, level) + (gx * 4 - kPadLeft);
+    const ResizeTap *tyTab = taps + lg.tabY;
+#pragma unroll
+    for (int r = 0; r < kPyrRows; r++) {
+        const int row = min(row0 + r, nrows - 1);  // clamped duplicate rows rewrite the same bytes
+        const ResizeTap ty = tyTab[row];
+        const uint32_t *S0 = reinterpret_cast<const uint32_t *>(prev + (ptrdiff_t)ty.ofs * pg.stride + base);
+        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(prev + (ptrdiff_t)ty.ofs1 * pg.stride + base);
+        const unsigned d0 = S0[0], d1 = S0[1], d2 = S0[2];
+        const unsigned e0 = S1[0], e1 = S1[1], e2 = S1[2];
+        const unsigned b0 = (unsigned)ty.a0, b1 = (unsigned)ty.a1;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned lo0 = sel[k] == 0 ? d0 : (sel[k] == 1 ? d1 : d2), hi0 = sel[k] == 0 ? d1 : (sel[k] == 1 ? d2 : 0u);
+            const unsigned lo1 = sel[k] == 0 ? e0 : (sel[k] == 1 ? e1 : e2), hi1 = sel[k] == 0 ? e1 : (sel[k] == 1 ? e2 : 0u);
+            const unsigned w0 = __builtin_amdgcn_alignbyte(hi0, lo0, shift[k]);  // bytes ofs, ofs + 1 of row 0
+            const unsigned w1 = __builtin_amdgcn_alignbyte(hi1, lo1, shift[k]);
+            const ushort2v wk = __builtin_bit_cast(ushort2v, wgt[k]);
+            const unsigned h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, w0, 0x0c010c00u)), wk, 0u, false);
+            const unsigned h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, w1, 0x0c010c00u)), wk, 0u, false);
+            const unsigned v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2u) >> 2;
+            packed |= (v & 0xffu) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(dstPlane + (ptrdiff_t)(row - kEdge) * lg.stride) = packed;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
