@@ -777,15 +777,11 @@ __device__ __forceinline__ int level_of_slot(const Geom *g, int slot)
     return level;
 }
 
-// grid = (ceil(kpLevelTotal/16), frames), block = 256 = 16 keypoints: SIXTEEN LANES PER KEYPOINT.
-// Lane j of a group owns patch columns u = 2j-15 and 2j-14 and walks the 31 rows (fully unrolled,
-// loads unconditional so they are all in flight; masked lanes re-read the centre pixel).
-__device__ __forceinline__ constexpr int umax_of(int v)
-{
-    constexpr int t[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, -1};
-    return t[v < 0 ? -v : v];
-}
-
+// grid = xcd_grid(ceil(kpLevelTotal/16), frames), block = 256 = 16 keypoints: SIXTEEN LANES PER
+// KEYPOINT.  In each of 16 steps a group reads two patch rows as 2 x 8 unaligned dwords (32 pixels,
+// columns -15 .. +16); a per-(step, lane) table in LDS holds, per byte, the weight u + 16 inside the
+// circular patch (0 outside) and a 0/1 mask, so one row costs two v_dot4_u32_u8:
+//   m10 = sum (u + 16) p - 16 sum p,   m01 = sum v p.
 __device__ __forceinline__ int group16_sum(int v)
 {
 #pragma unroll
@@ -796,6 +792,24 @@ __device__ __forceinline__ int group16_sum(int v)
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
                                                amos_keypoint *__restrict__ lvKps, const int *__restrict__ lvCount, int nFrames)
 {
+    __shared__ uint2 wtab[16][16];
+    {
+        const int step = threadIdx.x >> 4, jj = threadIdx.x & 15;
+        const int v = -kHalfPatch + 2 * step + (jj >> 3);
+        const int um = v <= kHalfPatch ? c_umax[v < 0 ? -v : v] : -1;
+        unsigned wu = 0, ones = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int u = -kHalfPatch + 4 * (jj & 7) + b;
+            const int au = u < 0 ? -u : u;
+            if (au <= um) {
+                wu |= (unsigned)(u + 16) << (8 * b);
+                ones |= 1u << (8 * b);
+            }
+        }
+        wtab[step][jj] = uint2{wu, ones};
+    }
+    __syncthreads();
     const int j = threadIdx.x & 15;
     int frame, chunk;
     if (!xcd_frame_chunk(blockIdx.x, (g->kpLevelTotal + 15) >> 4, nFrames, frame, chunk)) return;
@@ -807,20 +821,23 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     amos_keypoint *kp = lvKps + (size_t)frame * g->kpLevelTotal + (active ? slot : 0);
     const int cx = active ? __float2int_rn(kp->x) : kEdge, cy = active ? __float2int_rn(kp->y) : kEdge;
     const int stride = lg.stride;
-    const uint8_t *center = level_origin(pyr, g, frame, active ? level : 0) + (ptrdiff_t)cy * stride + cx;
-    const int u0 = 2 * j - kHalfPatch, u1 = u0 + 1;  // u1 = 16 for j = 15: never valid
-    const int au0 = u0 < 0 ? -u0 : u0, au1 = u1 < 0 ? -u1 : u1;
-    int m10 = 0, m01 = 0;
+    const uint8_t *col = level_origin(pyr, g, frame, active ? level : 0) + (ptrdiff_t)cy * stride + cx - kHalfPatch + 4 * (j & 7);
+    const int rowpar = j >> 3;
+    unsigned acc10 = 0, sum1 = 0;
+    int m01 = 0;
 #pragma unroll
-    for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
-        const int um = umax_of(v);
-        const bool ok0 = au0 <= um, ok1 = au1 <= um;
-        const int rowOff = v * stride;
-        const int p0 = center[ok0 ? rowOff + u0 : 0], p1 = center[ok1 ? rowOff + u1 : 0];
-        const int s0 = ok0 ? p0 : 0, s1 = ok1 ? p1 : 0;
-        m10 += u0 * s0 + u1 * s1;
-        m01 += v * (s0 + s1);
+    for (int step = 0; step < 16; step++) {
+        const int v = -kHalfPatch + 2 * step + rowpar;
+        const int vr = min(v, kHalfPatch);  // row 16 does not exist: its weights are zero
+        unsigned p;
+        __builtin_memcpy(&p, col + (ptrdiff_t)vr * stride, 4);  // unaligned global_load_dword
+        const uint2 w = wtab[step][j];
+        const unsigned s1 = __builtin_amdgcn_udot4(p, w.y, 0u, false);
+        acc10 = __builtin_amdgcn_udot4(p, w.x, acc10, false);
+        sum1 += s1;
+        m01 += v * (int)s1;
     }
+    int m10 = (int)acc10 - 16 * (int)sum1;
     m10 = group16_sum(m10);
     m01 = group16_sum(m01);
     if (active && j == 0) kp->angle = fast_atan2_deg((float)m01, (float)m10);
