@@ -458,11 +458,20 @@ __device__ __forceinline__ OctNode oct_child(const OctNode &b, int q, int midx, 
     return c;
 }
 
+// Double-buffered node arrays are addressed as base + buffer * NC (a runtime-indexed array of pointers
+// would live in scratch memory).
+template <typename T>
+struct OctBuf2 {
+    T *base;
+    int stride;
+    __device__ __forceinline__ T *operator[](int b) const { return base + b * stride; }
+};
+
 struct OctLds {
-    int *cnt[2];
-    int *seq[2];
-    OctNode *box[2];
-    uint8_t *noMore[2];
+    OctBuf2<int> cnt;
+    OctBuf2<int> seq;
+    OctBuf2<OctNode> box;
+    OctBuf2<uint8_t> noMore;
     int *child;   // [4*NC] child counts, then child positions in the new list
     int *newPos;  // [NC]
     int *scanA;   // [SC]
@@ -483,12 +492,9 @@ __device__ inline OctLds oct_carve(unsigned char *base, int NC, int SC)
 {
     OctLds L;
     int *ip = reinterpret_cast<int *>(base);
-    L.cnt[0] = ip; ip += NC;
-    L.cnt[1] = ip; ip += NC;
-    L.seq[0] = ip; ip += NC;
-    L.seq[1] = ip; ip += NC;
-    L.box[0] = reinterpret_cast<OctNode *>(ip); ip += 2 * NC;
-    L.box[1] = reinterpret_cast<OctNode *>(ip); ip += 2 * NC;
+    L.cnt.base = ip; L.cnt.stride = NC; ip += 2 * NC;
+    L.seq.base = ip; L.seq.stride = NC; ip += 2 * NC;
+    L.box.base = reinterpret_cast<OctNode *>(ip); L.box.stride = NC; ip += 4 * NC;
     L.child = ip; ip += 4 * NC;
     L.newPos = ip; ip += NC;
     L.scanA = ip; ip += SC;
@@ -498,8 +504,7 @@ __device__ inline OctLds oct_carve(unsigned char *base, int NC, int SC)
     L.part = ip; ip += 256;
     L.vars = ip; ip += 16;
     uint8_t *bp = reinterpret_cast<uint8_t *>(ip);
-    L.noMore[0] = bp; bp += NC;
-    L.noMore[1] = bp;
+    L.noMore.base = bp; L.noMore.stride = NC;
     return L;
 }
 
@@ -507,46 +512,42 @@ __device__ inline OctLds oct_carve(unsigned char *base, int NC, int SC)
 enum { V_SIZE = 0, V_NEXPAND = 1, V_RSTAR = 2, V_NCAND = 3 };
 
 // grid = frames * nLevels, block = 256, dynamic LDS = oct_lds_bytes(NC, SC).
-__global__ __launch_bounds__(256) void k_octree(const Geom *__restrict__ g, const Cell *__restrict__ cells,
-                                               const int *__restrict__ slotCount,
-                                               const uint32_t *__restrict__ slots, uint32_t *__restrict__ pts,
-                                               uint16_t *__restrict__ nodeOf, uint8_t *__restrict__ quadOf,
-                                               int *__restrict__ candCount, amos_keypoint *__restrict__ lvKps,
-                                               int *__restrict__ lvCount, int NC, int SC)
-{
-    extern __shared__ __align__(16) unsigned char oct_smem[];
-    const OctLds L = oct_carve(oct_smem, NC, SC);
-    const int tid = threadIdx.x;
-    const int frame = blockIdx.x / g->nLevels, level = blockIdx.x - frame * g->nLevels;
-    const LevelGeom &lg = g->lv[level];
-    const int N = lg.quota;
+//
+// Candidate state (packed point, node index, quadrant) lives in REGISTERS when the level has at most
+// 256 * kOctRegPts candidates (thread t owns candidates t, t + 256, ...): the subdivision passes then
+// touch only LDS.  Larger levels run the same code with the state in global scratch.
+constexpr int kOctRegPts = 8;
 
-    // ---- 1. candidates of the level in the reference's order: cells row-major, FAST order inside
-    const int *sc = slotCount + (size_t)frame * g->totalCells + lg.cellStart;
-    for (int c = tid; c < lg.nCells; c += 256) L.scanA[c] = sc[c];
-    __syncthreads();
-    const int n = block_excl_scan(L.scanA, lg.nCells, L.part);
-    uint32_t *P = pts + (size_t)frame * g->ptsTotal + lg.ptsOff;
-    uint16_t *nodeIdx = nodeOf + (size_t)frame * g->ptsTotal + lg.ptsOff;
-    uint8_t *quad = quadOf + (size_t)frame * g->ptsTotal + lg.ptsOff;
-    for (int c = tid; c < lg.nCells; c += 256) {
-        const int cnt = sc[c], off = L.scanA[c];
-        const uint32_t *s = slots + (size_t)frame * g->slotTotal + cells[lg.cellStart + c].slotOff;
-        for (int k = 0; k < cnt; k++) P[off + k] = s[k];
+template <bool kRegs>
+__device__ __forceinline__ void octree_body(const OctLds &L, const LevelGeom &lg, int level, int n, uint32_t *__restrict__ P,
+                                            uint16_t *__restrict__ nodeIdx, uint8_t *__restrict__ quad,
+                                            amos_keypoint *__restrict__ out, int *__restrict__ lvCountOut)
+{
+    const int tid = threadIdx.x;
+    const int N = lg.quota;
+    uint32_t rp[kOctRegPts];
+    int rnode[kOctRegPts], rquad[kOctRegPts];
+#define OCT_POINTS(k, i) _Pragma("unroll") for (int k = 0, i = tid; k < (kRegs ? kOctRegPts : (n + 255) / 256); k++, i += 256) if (i < n)
+#define OCT_P(k, i) (kRegs ? rp[k] : P[i])
+#define OCT_NODE(k, i) (kRegs ? rnode[k] : (int)nodeIdx[i])
+#define OCT_SET_NODE(k, i, v) do { if (kRegs) rnode[k] = (v); else nodeIdx[i] = (uint16_t)(v); } while (0)
+#define OCT_QUAD(k, i) (kRegs ? rquad[k] : (int)quad[i])
+#define OCT_SET_QUAD(k, i, v) do { if (kRegs) rquad[k] = (v); else quad[i] = (uint8_t)(v); } while (0)
+    if (kRegs) {
+        OCT_POINTS(k, i) rp[k] = P[i];
     }
-    if (tid == 0) candCount[frame * g->nLevels + level] = n;
 
     // ---- 2. root nodes, ORBextractor.cc:718-786
     const int spanX = lg.maxBX - kMinBorder, spanY = lg.maxBY - kMinBorder;
     const int nIni = lg.nIni;
     const float hX = __fdiv_rn((float)spanX, (float)nIni);
     for (int i = tid; i < nIni; i += 256) L.cnt[0][i] = 0;
-    __syncthreads();  // also orders the P[] writes above before the reads below (same block)
-    for (int i = tid; i < n; i += 256) {
-        const int x = P[i] & 0xfff;
+    __syncthreads();
+    OCT_POINTS(k, i) {
+        const int x = OCT_P(k, i) & 0xfff;
         int idx = (int)__fdiv_rn((float)x, hX);
         idx = min(max(idx, 0), nIni - 1);
-        nodeIdx[i] = (uint16_t)idx;
+        OCT_SET_NODE(k, i, idx);
         atomicAdd(&L.cnt[0][idx], 1);
     }
     __syncthreads();
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(256) void k_octree(const Geom *__restrict__ g, cons
         L.vars[V_SIZE] = size;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) nodeIdx[i] = (uint16_t)L.newPos[nodeIdx[i]];
+    OCT_POINTS(k, i) OCT_SET_NODE(k, i, L.newPos[OCT_NODE(k, i)]);
     int cur = 1;
     int size = L.vars[V_SIZE];
     int seqBase = nIni;
@@ -586,13 +587,13 @@ __global__ __launch_bounds__(256) void k_octree(const Geom *__restrict__ g, cons
         for (int i = tid; i < 4 * size; i += 256) L.child[i] = 0;
         if (tid == 0) { L.vars[V_NEXPAND] = 0; L.vars[V_RSTAR] = 0x7fffffff; L.vars[V_NCAND] = 0; }
         __syncthreads();
-        for (int i = tid; i < n; i += 256) {
-            const int nd = nodeIdx[i];
+        OCT_POINTS(k, i) {
+            const int nd = OCT_NODE(k, i);
             if (!L.noMore[cur][nd]) {
-                const uint32_t p = P[i];
+                const uint32_t p = OCT_P(k, i);
                 int mx, my;
                 const int q = oct_quadrant(L.box[cur][nd], p & 0xfff, (p >> 12) & 0xfff, mx, my);
-                quad[i] = (uint8_t)q;
+                OCT_SET_QUAD(k, i, q);
                 atomicAdd(&L.child[nd * 4 + q], 1);
             }
         }
@@ -677,28 +678,29 @@ __global__ __launch_bounds__(256) void k_octree(const Geom *__restrict__ g, cons
             const OctNode b = L.box[cur][i];
             int mx, my;
             oct_quadrant(b, 0, 0, mx, my);
-            int cc[4] = {L.child[i * 4], L.child[i * 4 + 1], L.child[i * 4 + 2], L.child[i * 4 + 3]};
+            const int c0 = L.child[i * 4], c1 = L.child[i * 4 + 1], c2 = L.child[i * 4 + 2], c3 = L.child[i * 4 + 3];
             int nex = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if (cc[q] > 0) {
+                const int cq = q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3;
+                if (cq > 0) {
                     const int p = K - 1 - ci;
                     L.box[nxt][p] = oct_child(b, q, mx, my);
-                    L.cnt[nxt][p] = cc[q];
+                    L.cnt[nxt][p] = cq;
                     L.seq[nxt][p] = seqBase + ci;
-                    L.noMore[nxt][p] = (cc[q] == 1);
+                    L.noMore[nxt][p] = (cq == 1);
                     L.child[i * 4 + q] = p;
-                    nex += cc[q] > 1;
+                    nex += cq > 1;
                     ci++;
                 }
             }
             if (nex) atomicAdd(&L.vars[V_NEXPAND], nex);
         }
         __syncthreads();
-        for (int i = tid; i < n; i += 256) {
-            const int nd = nodeIdx[i];
+        OCT_POINTS(k, i) {
+            const int nd = OCT_NODE(k, i);
             const int np = L.newPos[nd];
-            nodeIdx[i] = (uint16_t)(np >= 0 ? np : L.child[nd * 4 + quad[i]]);
+            OCT_SET_NODE(k, i, np >= 0 ? np : L.child[nd * 4 + OCT_QUAD(k, i)]);
         }
         const int nToExpand = L.vars[V_NEXPAND];
         size = K + M;
@@ -715,12 +717,11 @@ __global__ __launch_bounds__(256) void k_octree(const Geom *__restrict__ g, cons
     //         and the coordinate / octave / size fix-up of :1175-1190
     for (int i = tid; i < size; i += 256) L.best[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        const unsigned key = ((P[i] >> 24) << 20) | (unsigned)(0xfffff - i);
-        atomicMax(&L.best[nodeIdx[i]], key);
+    OCT_POINTS(k, i) {
+        const unsigned key = ((OCT_P(k, i) >> 24) << 20) | (unsigned)(0xfffff - i);
+        atomicMax(&L.best[OCT_NODE(k, i)], key);
     }
     __syncthreads();
-    amos_keypoint *out = lvKps + (size_t)frame * g->kpLevelTotal + lg.kpOff;
     for (int i = tid; i < size; i += 256) {
         const uint32_t p = P[0xfffff - (L.best[i] & 0xfffff)];
         amos_keypoint kp;
@@ -733,7 +734,53 @@ __global__ __launch_bounds__(256) void k_octree(const Geom *__restrict__ g, cons
         kp.class_id = -1;
         out[i] = kp;
     }
-    if (tid == 0) lvCount[frame * g->nLevels + level] = size;
+    if (tid == 0) *lvCountOut = size;
+#undef OCT_POINTS
+#undef OCT_P
+#undef OCT_NODE
+#undef OCT_SET_NODE
+#undef OCT_QUAD
+#undef OCT_SET_QUAD
+}
+
+__global__ __launch_bounds__(256) void k_octree(const Geom *__restrict__ g, const Cell *__restrict__ cells,
+                                               const int *__restrict__ slotCount,
+                                               const uint32_t *__restrict__ slots, uint32_t *__restrict__ pts,
+                                               uint16_t *__restrict__ nodeOf, uint8_t *__restrict__ quadOf,
+                                               int *__restrict__ candCount, amos_keypoint *__restrict__ lvKps,
+                                               int *__restrict__ lvCount, int NC, int SC)
+{
+    extern __shared__ __align__(16) unsigned char oct_smem[];
+    const OctLds L = oct_carve(oct_smem, NC, SC);
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x / g->nLevels, level = blockIdx.x - frame * g->nLevels;
+    const LevelGeom &lg = g->lv[level];
+
+    // ---- 1. candidates of the level in the reference's order: cells row-major, FAST order inside.
+    // A wave copies a run of cells: lanes cover the slots of 64 / 16 cells... simple form: each thread
+    // copies the slots of its cells, the per-cell counts are small (a few per cell).
+    const int *sc = slotCount + (size_t)frame * g->totalCells + lg.cellStart;
+    for (int c = tid; c < lg.nCells; c += 256) L.scanA[c] = sc[c];
+    __syncthreads();
+    const int n = block_excl_scan(L.scanA, lg.nCells, L.part);
+    uint32_t *P = pts + (size_t)frame * g->ptsTotal + lg.ptsOff;
+    for (int c = tid; c < lg.nCells; c += 256) {
+        const int cnt = sc[c], off = L.scanA[c];
+        const uint32_t *s = slots + (size_t)frame * g->slotTotal + cells[lg.cellStart + c].slotOff;
+        for (int k = 0; k < cnt; k++) P[off + k] = s[k];
+    }
+    if (tid == 0) candCount[frame * g->nLevels + level] = n;
+    __threadfence_block();
+    __syncthreads();  // P[] is complete for this work-group
+
+    uint16_t *nodeIdx = nodeOf + (size_t)frame * g->ptsTotal + lg.ptsOff;
+    uint8_t *quad = quadOf + (size_t)frame * g->ptsTotal + lg.ptsOff;
+    amos_keypoint *out = lvKps + (size_t)frame * g->kpLevelTotal + lg.kpOff;
+    int *cntOut = lvCount + frame * g->nLevels + level;
+    if (n <= 256 * kOctRegPts)
+        octree_body<true>(L, lg, level, n, P, nodeIdx, quad, out, cntOut);
+    else
+        octree_body<false>(L, lg, level, n, P, nodeIdx, quad, out, cntOut);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -975,10 +1022,16 @@ __device__ __forceinline__ void glibc_sincosf(float y, float &sinp, float &cosp)
 // ---------------------------------------------------------------------------------------------
 // a9 (second half) + a10  computeDescriptors / computeOrbDescriptor (ORBextractor.cc:173-227,
 // 1525-1540) and the level-0 rescale + concatenation of ProcessDesp (:1747-1820).
-// SIXTEEN LANES PER KEYPOINT (16 keypoints per work-group): in step i lane j evaluates point pair
-// 16 i + j; one __ballot per step yields, for each of the wave's four keypoints, the 16-bit
-// descriptor word i, which lane i of the group keeps and finally stores (16 x 2 B = one 32-byte
-// row).  The pattern sits in LDS as floats (one ds_read_b128 per pair).
+// SIXTEEN LANES PER KEYPOINT (16 keypoints per work-group).  The group first stages the keypoint's
+// 37-row window of the blurred level (rotated pattern offsets are <= 18 in magnitude) in LDS with
+// 111 unaligned 16-byte loads (7 per lane) instead of 512 scattered byte gathers; then in step i lane j
+// evaluates point pair 16 i + j from LDS; one __ballot per step yields, for each of the wave's four
+// keypoints, the 16-bit descriptor word i, which lane i of the group keeps and finally stores
+// (16 x 2 B = one 32-byte row).  The pattern sits in LDS as floats (one ds_read_b128 per pair).
+constexpr int kDescR = 18;          // |rotated offset| <= sqrt(13^2 + 13^2) = 18.4 -> 18 after rounding
+constexpr int kDescRowBytes = 48;   // columns -18 .. +29 as three 16-byte pieces
+constexpr int kDescRows = 2 * kDescR + 1;
+
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ blur, const Geom *__restrict__ g,
                                                  const amos_keypoint *__restrict__ lvKps,
                                                  const int *__restrict__ lvCount,
@@ -986,15 +1039,15 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
                                                  int *__restrict__ outCount, int nFrames)
 {
     __shared__ float4 pat[256];
+    __shared__ uint4 patch[16][kDescRows * 3];
     int frame, chunk;
     if (!xcd_frame_chunk(blockIdx.x, (g->kpLevelTotal + 15) >> 4, nFrames, frame, chunk)) return;
     {
         const signed char *p = &c_pattern[threadIdx.x * 4];
         pat[threadIdx.x] = float4{(float)p[0], (float)p[1], (float)p[2], (float)p[3]};
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, j = threadIdx.x & 15, sub = lane >> 4;
-    const int slot = chunk * 16 + (threadIdx.x >> 4);
+    const int lane = threadIdx.x & 63, j = threadIdx.x & 15, sub = lane >> 4, grp = threadIdx.x >> 4;
+    const int slot = chunk * 16 + grp;
     const int *cnt = lvCount + frame * g->nLevels;
     if (slot == 0 && j == 0) {
         int total = 0;
@@ -1010,13 +1063,25 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
     for (int l = 0; l < (active ? level : 0); l++) dstIdx += cnt[l];
     active = active && dstIdx < g->kpCap;
     amos_keypoint kp = lvKps[(size_t)frame * g->kpLevelTotal + (active ? slot : 0)];
-    if (!active) { kp.x = kp.y = (float)kEdge; kp.angle = 0.f; }
+    if (!active) { kp.x = kp.y = (float)(kEdge + kDescR); kp.angle = 0.f; }
+    const int stride = lg.stride;
+    const uint8_t *corner = level_origin(blur, g, frame, active ? level : 0) + (ptrdiff_t)(__float2int_rn(kp.y) - kDescR) * stride +
+                            (__float2int_rn(kp.x) - kDescR);
+#pragma unroll
+    for (int it = 0; it < (kDescRows * 3 + 15) / 16; it++) {
+        const int piece = it * 16 + j;
+        if (piece < kDescRows * 3) {
+            const int r = piece / 3, c = piece - 3 * r;
+            uint4 v;
+            __builtin_memcpy(&v, corner + (ptrdiff_t)r * stride + 16 * c, 16);  // unaligned global_load_dwordx4
+            patch[grp][piece] = v;
+        }
+    }
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a, b;
     glibc_sincosf(__fmul_rn(kp.angle, factorPI), b, a);
-    const int stride = lg.stride;
-    const uint8_t *center =
-        level_origin(blur, g, frame, active ? level : 0) + (ptrdiff_t)__float2int_rn(kp.y) * stride + __float2int_rn(kp.x);
+    __syncthreads();
+    const uint8_t *center = reinterpret_cast<const uint8_t *>(&patch[grp][0]) + kDescR * kDescRowBytes + kDescR;
     unsigned myword = 0;
 #pragma unroll
     for (int step = 0; step < 16; step++) {
@@ -1025,8 +1090,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
         const int c0 = __float2int_rn(__fmaf_rn(pt.x, a, -__fmul_rn(pt.y, b)));
         const int r1 = __float2int_rn(__fmaf_rn(pt.z, b, __fmul_rn(pt.w, a)));
         const int c1 = __float2int_rn(__fmaf_rn(pt.z, a, -__fmul_rn(pt.w, b)));
-        const int t0 = center[r0 * stride + c0];
-        const int t1 = center[r1 * stride + c1];
+        const int t0 = center[r0 * kDescRowBytes + c0];
+        const int t1 = center[r1 * kDescRowBytes + c1];
         const unsigned long long bal = __ballot(t0 < t1);
         const unsigned word = (unsigned)(bal >> (16 * sub)) & 0xffffu;
         if (j == step) myword = word;
