@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_bf_best2(const uint8_t *__restrict__ de
 {
     __shared__ uint4 tileLds[4][kBfTile * 2];
     __shared__ unsigned mergeB[4][64], mergeS[4][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar loop bounds
     const int pair = blockIdx.y;
     const int fq = pairsQ ? pairsQ[pair] : 0, ft = pairsT ? pairsT[pair] : 0;
     const int nq = counts ? min(counts[fq], capacity) : nqFixed;

@@ -252,7 +252,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
                                                    uint32_t *__restrict__ slots, int nFrames)
 {
     extern __shared__ __align__(16) unsigned char fast_smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index is wave-uniform: tell the compiler, so that the cell record, loop bounds and LDS
+    // bases live in SGPRs and the per-cell loops are scalar loops
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int frame, chunk;
     if (!xcd_frame_chunk(blockIdx.x, (g->totalCells + 3) >> 2, nFrames, frame, chunk)) return;
     const int cellIdx = chunk * 4 + wave;

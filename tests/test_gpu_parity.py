@@ -227,6 +227,30 @@ def test_batch_equals_single(gpu_lib, ob, synth):
         _same(dg, do, f"frame {f} descriptors")
 
 
+def test_batch_with_unaligned_strides(gpu_lib, ob, synth):
+    """Frames inside a larger device buffer with odd row / frame strides and an odd base offset
+    (the level-0 import then takes its byte path)."""
+    import torch
+    n, w, h = 3, 322, 241
+    frames = synth.frames(7, 0, n, h, w)
+    row_stride, frame_stride = w + 5, (w + 5) * h + 3
+    buf = torch.zeros(7 + n * frame_stride + 64, dtype=torch.uint8)
+    for f in range(n):
+        for y in range(h):
+            o = 7 + f * frame_stride + y * row_stride
+            buf[o:o + w] = torch.from_numpy(frames[f, y])
+    d = buf.cuda()
+    torch.cuda.synchronize()
+    ext = gpu_lib.OrbExtractor(n_features=500, n_levels=4, max_width=w, max_height=h, max_batch=n)
+    ext.extract_batch_device(d.data_ptr() + 7, frame_stride, row_stride, w, h, n)
+    ext.sync()
+    for f in range(n):
+        kg, dg = ext.batch_fetch(f)
+        ko, do = ob.Oracle(n_features=500, n_levels=4).extract(frames[f])
+        _same(kg, ko, f"frame {f} keypoints")
+        _same(dg, do, f"frame {f} descriptors")
+
+
 def test_staged_batch_with_masks(gpu_lib, ob, synth):
     """Full front-end, device resident: detect -> gate (closed mask) -> describe for a batch,
     frame by frame equal to the oracle's a7 -> a8 -> a9."""
