@@ -68,9 +68,9 @@ struct Cell {
     short level;
     short x0, y0;  // first tested pixel (level coordinates) = (iniX + 3, iniY + 3)
     short tw, th;  // tested region size
-    short ndw;     // dwords per staged tile row = (tw + 10) / 4
+    short ndw;     // 16-byte pieces per staged tile row = (tw + 7 + 15) / 16
     int slotOff;   // first candidate slot of the cell inside one frame
-    unsigned magicDw, magicG;  // (1 << 20) / d + 1 for d = ndw, groups: division by multiplication
+    unsigned magicDw, magicG;  // (1 << 20) / d + 1 for d = pieces per row, groups: division by multiplication
     short groups;  // 4-pixel groups per row = (tw + 3) / 4
     short pad[3];
 };

@@ -209,7 +209,7 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
                 c.tw = (short)tw;
                 c.th = (short)th;
                 c.slotOff = slotOff;
-                c.ndw = (short)((tw + 10) >> 2);
+                c.ndw = (short)((tw + 7 + 15) >> 4);  // bytes 0 .. tw + 6 of the staged row, in 16-byte pieces
                 c.groups = (short)((tw + 3) >> 2);
                 c.magicDw = (1u << 20) / (unsigned)c.ndw + 1u;
                 c.magicG = (1u << 20) / (unsigned)c.groups + 1u;
@@ -265,7 +265,7 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
     g.kpLevelTotal = kpOff;
     g.kpCap = kpOff;
     g.blurItems = blurOff;
-    g.fastTileStrideDw = (maxTw + 10) >> 2;
+    g.fastTileStrideDw = ((maxTw + 7 + 15) >> 4) * 4;  // whole 16-byte pieces
     g.fastTileRows = maxTh + 6;
     g.fastMapRows = maxTh + 2;
     g.fastKeptCap = ((maxTw + 1) / 2) * ((maxTh + 1) / 2);

@@ -234,6 +234,18 @@ __device__ __forceinline__ unsigned fast_compass(short2v c, short2v n, short2v s
 // Candidates of a cell are written in FAST's order (row-major) to the cell's own slot range:
 // packed x | y << 12 | score << 24, coordinates relative to (minBorderX, minBorderY) as the
 // reference hands them to DistributeOctTree.
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP adds (row_shr 1/2/4/8, row_bcast 15/31).
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, false);  // row_shr:4, banks 1-3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, false);  // row_shr:8, banks 2-3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 constexpr int kFastCandCap = 1024;  // candidate list; a cell with more falls back to scanning the arc map
 
 __device__ __forceinline__ void fast_score_chunk(const uint8_t *tile, int tileStride, uint8_t *amap, const uint16_t *cand,
@@ -269,18 +281,23 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     uint32_t *kept = reinterpret_cast<uint32_t *>(cand + kFastCandCap);
     const uint8_t *img = level_origin(pyr, g, frame, c.level);
     const int tw = c.tw, th = c.th;
-    // LDS row r holds image row y0 - 3 + r; LDS byte b of a row holds image column x0 - 4 + b
-    const int ga = (c.x0 - 4) & ~3, sh = (c.x0 - 4) & 3;
-    const int ndw = c.ndw, lh = th + 6;
-    for (int idx = lane; idx < lh * ndw; idx += 64) {
-        const int r = div_small(idx, c.magicDw), cc = idx - r * ndw;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(img + (ptrdiff_t)(c.y0 - 3 + r) * lg.stride + ga) + cc;
-        tile32[r * rowDw + cc] = __builtin_amdgcn_alignbyte(src[1], src[0], (unsigned)sh);
+    // LDS row r holds image row y0 - 3 + r; LDS byte b of a row holds image column x0 - 4 + b.  Rows are
+    // fetched as unaligned 16-byte pieces (global memory takes any byte alignment) and land 16-byte aligned.
+    const int npc = c.ndw, lh = th + 6;  // pieces per row
+    const uint8_t *corner = img + (ptrdiff_t)(c.y0 - 3) * lg.stride + (c.x0 - 4);
+    for (int idx = lane; idx < lh * npc; idx += 64) {
+        const int r = div_small(idx, c.magicDw), cc = idx - r * npc;
+        uint4 v;
+        __builtin_memcpy(&v, corner + (ptrdiff_t)r * lg.stride + 16 * cc, 16);
+        reinterpret_cast<uint4 *>(tile32 + r * rowDw)[cc] = v;
     }
     for (int idx = lane; idx < (th + 2) * (kFastMapStride / 16); idx += 64) reinterpret_cast<uint4 *>(amap)[idx] = uint4{0, 0, 0, 0};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint8_t *tile = reinterpret_cast<const uint8_t *>(tile32) + 3 * tileStride + 4;  // pixel (x0, y0)
+#ifdef AMOS_FAST_ABLATE  // timing-only builds (outputs wrong): where does the kernel spend its time?
+    if (AMOS_FAST_ABLATE == 1) { if (lane == 0) slotCount[(size_t)frame * g->totalCells + cellIdx] = tile32[lane]; return; }
+#endif
     const int iniTh = min(max(g->iniTh, 0), 255), minTh = min(max(g->minTh, 0), 255);
     const int groups = c.groups, nitems = th * groups;
     const unsigned long long ltmask = (1ull << lane) - 1ull;
@@ -317,21 +334,36 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool b = (bits >> k) & 1u;
-                const unsigned long long bal = __ballot(b);
-                if (b) cand[ncand + __popcll(bal & ltmask)] = (uint16_t)(p0 + k);
-                ncand += __popcll(bal);
+#ifdef AMOS_FAST_ABLATE
+            if (AMOS_FAST_ABLATE == 2) { if (bits == 0xffu) cand[lane] = (uint16_t)p0; continue; }
+#endif
+            {   // append the survivors: one wave-wide prefix sum of the per-lane counts, then up to 4 stores
+                const int c = __popc(bits);
+                const int incl = wave_inclusive_scan(c);
+                int o = ncand + incl - c;
+                if (bits & 1u) cand[o++] = (uint16_t)p0;
+                if (bits & 2u) cand[o++] = (uint16_t)(p0 + 1);
+                if (bits & 4u) cand[o++] = (uint16_t)(p0 + 2);
+                if (bits & 8u) cand[o] = (uint16_t)(p0 + 3);
+                ncand += __builtin_amdgcn_readlane(incl, 63);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#ifdef AMOS_FAST_ABLATE
+            if (AMOS_FAST_ABLATE == 3) { done = ncand & ~63; continue; }
+#endif
             while (ncand - done >= 64) {  // wave-uniform: dense chunks of 64 survivors
                 fast_score_chunk(tile, tileStride, amap, cand, done, 64, lane, t);
                 done += 64;
             }
         }
+#ifdef AMOS_FAST_ABLATE
+        if (AMOS_FAST_ABLATE == 2 || AMOS_FAST_ABLATE == 3) { nkept = 1; kept[0] = cand[0]; break; }
+#endif
         fast_score_chunk(tile, tileStride, amap, cand, done, ncand - done, lane, t);
+#ifdef AMOS_FAST_ABLATE
+        if (AMOS_FAST_ABLATE == 4) { nkept = 1; kept[0] = amap[70]; break; }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- phase 3: strict 3x3 NMS.  For a corner at threshold t (a > t) every non-corner neighbour is
