@@ -325,11 +325,8 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
         else
             hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);
     }
-    if (ev) (void)hipEventRecord(ev[1], h->stream);
-    hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid((g.totalCells + 3) / 4, nFrames)), dim3(256), 4 * (size_t)g.fastWaveBytes, h->stream,
-                       h->dPyr, h->dGeom, h->dCells, h->dSlotCount, h->dSlots, nFrames);
-    if (ev) (void)hipEventRecord(ev[2], h->stream);
-    // fork: blur on the side stream once FAST is done with the (read-only) pyramid bandwidth
+    // fork: the blur only needs the pyramid; it streams memory on the side stream while FAST (VALU-bound)
+    // and the quad-tree (latency-bound) run on the main one
     AMOS_HIP_CHECK(hipEventRecord(h->evFork, h->stream));
     AMOS_HIP_CHECK(hipStreamWaitEvent(h->streamB, h->evFork, 0));
     if (ev) (void)hipEventRecord(h->evBlur0, h->streamB);
@@ -337,6 +334,10 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
     if (ev) (void)hipEventRecord(h->evBlur1, h->streamB);
     AMOS_HIP_CHECK(hipEventRecord(h->evJoin, h->streamB));
     h->blurDone = true;
+    if (ev) (void)hipEventRecord(ev[1], h->stream);
+    hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid((g.totalCells + 3) / 4, nFrames)), dim3(256), 4 * (size_t)g.fastWaveBytes, h->stream,
+                       h->dPyr, h->dGeom, h->dCells, h->dSlotCount, h->dSlots, nFrames);
+    if (ev) (void)hipEventRecord(ev[2], h->stream);
     const size_t lds = oct_lds_bytes(h->octNC, h->octSC);
     hipLaunchKernelGGL(k_octree, dim3(nFrames * g.nLevels), dim3(256), lds, h->stream, h->dGeom, h->dCells, h->dSlotCount,
                        h->dSlots, h->dPts, h->dNodeOf, h->dQuadOf, h->dCandCount, h->dLvKps, h->dLvCount, h->octNC, h->octSC);
