@@ -33,6 +33,15 @@ __device__ __forceinline__ Desc load_desc(const uint8_t *p)
     return d;
 }
 
+// popcount(x) + acc in ONE instruction.  The compiler knows v_bcnt_u32_b32's accumulate operand but
+// re-associates an 8-term sum into 8 x v_bcnt(.., 0) + 3 x v_add3; the chained form is 8 instructions.
+__device__ __forceinline__ int bcnt_acc(uint32_t x, int acc)
+{
+    int r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 // top-2 of unique keys
 template <typename K>
 __device__ __forceinline__ void top2_push(K &best, K &second, K key)
@@ -116,15 +125,14 @@ __global__ __launch_bounds__(256) void k_list_best2(const uint8_t *__restrict__ 
 // train set) pairs.  Block = 64 queries x 4 waves; wave w scans the w-th quarter of the train set
 // from LDS tiles (every lane reads the same descriptor: LDS broadcast), the four partial top-2s are
 // merged through LDS.  grid = (ceil(maxQueries/64), nPairs).
-constexpr int kBfTile = 64;  // train descriptors per wave per LDS tile
 
+template <bool kGate>
 __global__ __launch_bounds__(256) void k_bf_best2(const uint8_t *__restrict__ descBaseQ, const uint8_t *__restrict__ descBaseT,
                                                  size_t frameStrideBytes, const int *__restrict__ counts,
                                                  const int *__restrict__ pairsQ, const int *__restrict__ pairsT,
                                                  int nqFixed, int ntFixed, int capacity, int initDist,
                                                  amos_best2 *__restrict__ out)
 {
-    __shared__ uint4 tileLds[4][kBfTile * 2];
     __shared__ unsigned mergeB[4][64], mergeS[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar loop bounds
     const int pair = blockIdx.y;
@@ -142,21 +150,33 @@ __global__ __launch_bounds__(256) void k_bf_best2(const uint8_t *__restrict__ de
     const int per = (nt + 3) >> 2;  // contiguous quarter per wave
     const int j0 = wave * per, j1 = min(j0 + per, nt);
     unsigned best = 0xffffffffu, second = 0xffffffffu;
-    for (int it = 0; it < per; it += kBfTile) {  // uniform trip count: every wave reaches the barriers
-        const int base = j0 + it;
-        const int cnt = min(kBfTile, j1 - base);
-        // the wave stages its own tile: 2 x 16 B per descriptor, lanes stride over the 16-byte pieces
-        for (int p = lane; p < cnt * 2; p += 64) tileLds[wave][p] = reinterpret_cast<const uint4 *>(tb + (size_t)base * 32)[p];
-        __syncthreads();
-        for (int k = 0; k < cnt; k++) {
-            const uint4 lo = tileLds[wave][2 * k], hi = tileLds[wave][2 * k + 1];
-            int d = __popc(qd.w[0] ^ lo.x) + __popc(qd.w[1] ^ lo.y) + __popc(qd.w[2] ^ lo.z) + __popc(qd.w[3] ^ lo.w) +
-                    __popc(qd.w[4] ^ hi.x) + __popc(qd.w[5] ^ hi.y) + __popc(qd.w[6] ^ hi.z) + __popc(qd.w[7] ^ hi.w);
-            const unsigned key = d < initDist ? ((unsigned)d << 16) | (unsigned)(base + k) : 0xffffffffu;
-            top2_push(best, second, key);
-        }
-        __syncthreads();
+    // Every lane of the wave compares against the SAME train descriptor: its address is wave-uniform, so the
+    // 32 bytes arrive through the scalar data cache (s_load_dwordx8) straight into SGPR operands of the
+    // v_xor -- no LDS tile, no vector registers for the train side.
+    const uint4 *tv = reinterpret_cast<const uint4 *>(tb);
+    auto eval = [&](const uint4 &lo, const uint4 &hi, int jj) {
+        int d = __popc(qd.w[0] ^ lo.x);
+        d = bcnt_acc(qd.w[1] ^ lo.y, d);
+        d = bcnt_acc(qd.w[2] ^ lo.z, d);
+        d = bcnt_acc(qd.w[3] ^ lo.w, d);
+        d = bcnt_acc(qd.w[4] ^ hi.x, d);
+        d = bcnt_acc(qd.w[5] ^ hi.y, d);
+        d = bcnt_acc(qd.w[6] ^ hi.z, d);
+        d = bcnt_acc(qd.w[7] ^ hi.w, d);
+        unsigned key = ((unsigned)d << 16) | (unsigned)jj;
+        if (kGate) key = d < initDist ? key : 0xffffffffu;  // initDist >= 257 can never reject
+        top2_push(best, second, key);
+    };
+    int jj = j0;
+    for (; jj + 4 <= j1; jj += 4) {  // four descriptors (eight scalar loads) in flight per trip
+        const uint4 a0 = tv[2 * jj], a1 = tv[2 * jj + 1], b0 = tv[2 * jj + 2], b1 = tv[2 * jj + 3];
+        const uint4 c0 = tv[2 * jj + 4], c1 = tv[2 * jj + 5], d0 = tv[2 * jj + 6], d1 = tv[2 * jj + 7];
+        eval(a0, a1, jj);
+        eval(b0, b1, jj + 1);
+        eval(c0, c1, jj + 2);
+        eval(d0, d1, jj + 3);
     }
+    for (; jj < j1; jj++) eval(tv[2 * jj], tv[2 * jj + 1], jj);
     mergeB[wave][lane] = best;
     mergeS[wave][lane] = second;
     __syncthreads();
@@ -348,8 +368,12 @@ int amos_match_bruteforce_best2(amos_match *m, const uint8_t *q, int nq, const u
     if (rc != AMOS_OK) return rc;
     rc = grow_out(m, (size_t)nq * sizeof(amos_best2));
     if (rc != AMOS_OK) return rc;
-    hipLaunchKernelGGL(k_bf_best2, dim3((nq + 63) / 64, 1), dim3(256), 0, m->stream, m->dQ, m->dT, (size_t)0, (const int *)nullptr,
-                       (const int *)nullptr, (const int *)nullptr, nq, nt, nq, init_dist, (amos_best2 *)m->dOut);
+    if (init_dist > 256)
+        hipLaunchKernelGGL(k_bf_best2<false>, dim3((nq + 63) / 64, 1), dim3(256), 0, m->stream, m->dQ, m->dT, (size_t)0, (const int *)nullptr,
+                           (const int *)nullptr, (const int *)nullptr, nq, nt, nq, init_dist, (amos_best2 *)m->dOut);
+    else
+        hipLaunchKernelGGL(k_bf_best2<true>, dim3((nq + 63) / 64, 1), dim3(256), 0, m->stream, m->dQ, m->dT, (size_t)0, (const int *)nullptr,
+                           (const int *)nullptr, (const int *)nullptr, nq, nt, nq, init_dist, (amos_best2 *)m->dOut);
     AMOS_HIP_CHECK(hipGetLastError());
     AMOS_HIP_CHECK(hipMemcpyAsync(out, m->dOut, (size_t)nq * sizeof(amos_best2), hipMemcpyDeviceToHost, m->stream));
     AMOS_HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -365,8 +389,12 @@ int amos_match_bruteforce_best2_batch_device(amos_match *m, const uint8_t *d_des
         return AMOS_ERR_INVALID;
     }
     AMOS_HIP_CHECK(hipSetDevice(m->device));
-    hipLaunchKernelGGL(k_bf_best2, dim3((capacity + 63) / 64, n_pairs), dim3(256), 0, m->stream, d_desc, d_desc, frame_stride_bytes,
-                       d_counts, d_pairs_q, d_pairs_t, 0, 0, capacity, init_dist, d_out);
+    if (init_dist > 256)
+        hipLaunchKernelGGL(k_bf_best2<false>, dim3((capacity + 63) / 64, n_pairs), dim3(256), 0, m->stream, d_desc, d_desc, frame_stride_bytes,
+                           d_counts, d_pairs_q, d_pairs_t, 0, 0, capacity, init_dist, d_out);
+    else
+        hipLaunchKernelGGL(k_bf_best2<true>, dim3((capacity + 63) / 64, n_pairs), dim3(256), 0, m->stream, d_desc, d_desc, frame_stride_bytes,
+                           d_counts, d_pairs_q, d_pairs_t, 0, 0, capacity, init_dist, d_out);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }

@@ -31,7 +31,8 @@ CONFIGS = {
     "c3": dict(width=640, height=480, n_features=1000, n_levels=8, mask=True, default_batch=32,
                label="configs[2]: 640x480 L8 N1000 YOLACT-R50 mask + extract + gate + match"),
     # BASELINE.json configs[4]: synthetic HD stream
-    "c5": dict(width=1920, height=1080, n_features=4000, n_levels=12, label="configs[4]: 1920x1080 L12 N4000 extract+match"),
+    "c5": dict(width=1920, height=1080, n_features=4000, n_levels=12, default_batch=64,
+               label="configs[4]: 1920x1080 L12 N4000 extract+match"),
 }
 
 
