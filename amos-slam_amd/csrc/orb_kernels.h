@@ -85,14 +85,14 @@ __global__ __launch_bounds__(256) void k_pyramid_level0(const uint8_t *__restric
     for (int r = 0; r < kPyrRows; r++) {
         const int yo = row0 + r - kEdge;
         if (yo >= lg.h + kEdge) break;
-        const uint8_t *s = s0 + (size_t)reflect101(yo, lg.h) * srcRowStride;
+        const uint8_t *s = s0 + (size_t)reflect101(yo, lg.h) * srcRowStride;  // caller's stride: may exceed 24 bits
         uint32_t packed;
         if (interior) {
             packed = *reinterpret_cast<const uint32_t *>(s + x0);
         } else {
             packed = (uint32_t)s[xi[0]] | ((uint32_t)s[xi[1]] << 8) | ((uint32_t)s[xi[2]] << 16) | ((uint32_t)s[xi[3]] << 24);
         }
-        *reinterpret_cast<uint32_t *>(plane + (ptrdiff_t)yo * lg.stride + x0) = packed;
+        *reinterpret_cast<uint32_t *>(plane + __mul24(yo, lg.stride) + x0) = packed;
     }
 }
 
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr
     for (int r = 0; r < kPyrRows; r++) {
         const int row = min(row0 + r, nrows - 1);  // clamped duplicate rows rewrite the same bytes
         const ResizeTap ty = tyTab[row];
-        const uint32_t *S0 = reinterpret_cast<const uint32_t *>(prev + (ptrdiff_t)ty.ofs * pg.stride + base);
-        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(prev + (ptrdiff_t)ty.ofs1 * pg.stride + base);
+        const uint32_t *S0 = reinterpret_cast<const uint32_t *>(prev + __mul24((int)ty.ofs, pg.stride) + base);
+        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(prev + __mul24((int)ty.ofs1, pg.stride) + base);
         const unsigned d0 = S0[0], d1 = S0[1], d2 = S0[2];
         const unsigned e0 = S1[0], e1 = S1[1], e2 = S1[2];
         const unsigned b0 = (unsigned)ty.a0, b1 = (unsigned)ty.a1;
@@ -147,10 +147,10 @@ __global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr
             const ushort2v wk = __builtin_bit_cast(ushort2v, wgt[k]);
             const unsigned h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, w0, 0x0c010c00u)), wk, 0u, false);
             const unsigned h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, w1, 0x0c010c00u)), wk, 0u, false);
-            const unsigned v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2u) >> 2;
+            const unsigned v = ((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2;  // 12 x 15 bits
             packed |= (v & 0xffu) << (8 * k);
         }
-        *reinterpret_cast<uint32_t *>(dstPlane + (ptrdiff_t)(row - kEdge) * lg.stride) = packed;
+        *reinterpret_cast<uint32_t *>(dstPlane + __mul24(row - kEdge, lg.stride)) = packed;
     }
 }
 
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
         const int v = -kHalfPatch + 2 * step + rowpar;
         const int vr = min(v, kHalfPatch);  // row 16 does not exist: its weights are zero
         unsigned p;
-        __builtin_memcpy(&p, col + (ptrdiff_t)vr * stride, 4);  // unaligned global_load_dword
+        __builtin_memcpy(&p, col + __mul24(vr, stride), 4);  // unaligned global_load_dword
         const uint2 w = wtab[step][j];
         const unsigned s1 = __builtin_amdgcn_udot4(p, w.y, 0u, false);
         acc10 = __builtin_amdgcn_udot4(p, w.x, acc10, false);
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 #pragma unroll
     for (int r = 0; r < kBlurStrip + 6; r++) {
         const int y = min(y0 + r - 3, lastRow);
-        const uint32_t *row = reinterpret_cast<const uint32_t *>(src + (ptrdiff_t)y * lg.stride);
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(src + __mul24(y, lg.stride));  // 24-bit multiplies are full rate
         const unsigned d0 = row[0], d1 = row[1], d2 = row[2];
         unsigned hsum[4];
         hsum[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA,
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
             if (r >= 1) pairs[c][(r - 1) % 6] = prev[c] | (hsum[c] << 16);
             prev[c] = hsum[c];
             if (r >= 6) {  // output row y0 + r - 6: rows r-6 .. r
-                unsigned a = 32768u + hsum[c] * 18u;
+                unsigned a = __umul24(hsum[c], 18u) + 32768u;
                 a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pairs[c][(r - 6) % 6]), K01, a, false);
                 a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pairs[c][(r - 4) % 6]), K23, a, false);
                 a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pairs[c][(r - 2) % 6]), K45, a, false);
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
                 // byte 2 of each accumulator is the pixel
                 const unsigned lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
                 const unsigned hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
-                *reinterpret_cast<uint32_t *>(dst + (ptrdiff_t)yo * lg.stride) = lo | hi;  // row pitch leaves room past w
+                *reinterpret_cast<uint32_t *>(dst + __mul24(yo, lg.stride)) = lo | hi;  // row pitch leaves room past w
             }
         }
     }
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
         if (piece < kDescRows * 3) {
             const int r = piece / 3, c = piece - 3 * r;
             uint4 v;
-            __builtin_memcpy(&v, corner + (ptrdiff_t)r * stride + 16 * c, 16);  // unaligned global_load_dwordx4
+            __builtin_memcpy(&v, corner + __mul24(r, stride) + 16 * c, 16);  // unaligned global_load_dwordx4
             patch[grp][piece] = v;
         }
     }
@@ -1124,8 +1124,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
         const int c0 = __float2int_rn(__fmaf_rn(pt.x, a, -__fmul_rn(pt.y, b)));
         const int r1 = __float2int_rn(__fmaf_rn(pt.z, b, __fmul_rn(pt.w, a)));
         const int c1 = __float2int_rn(__fmaf_rn(pt.z, a, -__fmul_rn(pt.w, b)));
-        const int t0 = center[r0 * kDescRowBytes + c0];
-        const int t1 = center[r1 * kDescRowBytes + c1];
+        const int t0 = center[__mul24(r0, kDescRowBytes) + c0];
+        const int t1 = center[__mul24(r1, kDescRowBytes) + c1];
         const unsigned long long bal = __ballot(t0 < t1);
         const unsigned word = (unsigned)(bal >> (16 * sub)) & 0xffffu;
         if (j == step) myword = word;
