@@ -55,3 +55,34 @@ def detect(pred, batch_idx=0):
         return None
     b, m, c, s = fast_nms(boxes[keep], pred["mask"][batch_idx][keep], cls_scores[:, keep])
     return {"box": b, "mask": m, "class": c, "score": s, "proto": pred["proto"][batch_idx]}
+
+
+def detect_batch(pred):
+    """Detect for a whole batch with STATIC shapes (no boolean indexing, so one set of kernel launches
+    serves every frame).  Priors that fail the 0.05 prior-level threshold get score -1 instead of being
+    removed; they sort behind every real candidate, cannot suppress anything (suppression is by
+    higher-scored boxes only) and are dropped later by the 0.15 score threshold.  Returns box [B, 100, 4],
+    mask [B, 100, 32], class [B, 100], score [B, 100] (score <= 0 marks padding)."""
+    loc, conf, coef, priors = pred["loc"], pred["conf"], pred["mask"], pred["priors"]
+    B, P = loc.shape[:2]
+    centre = priors[None, :, :2] + loc[..., :2] * 0.1 * priors[None, :, 2:]
+    size = priors[None, :, 2:] * torch.exp(loc[..., 2:] * 0.2)
+    x1y1 = centre - size / 2
+    boxes = torch.cat((x1y1, x1y1 + size), -1)                       # [B, P, 4]
+    cls = conf.transpose(1, 2)[:, 1:, :]                             # [B, 80, P]
+    keep = cls.max(dim=1, keepdim=True)[0] > CONF_THRESH             # [B, 1, P]
+    cls = torch.where(keep, cls, torch.full_like(cls, -1.0))
+    k = min(NMS_TOP_K, P)
+    scores, idx = cls.topk(k, dim=2)                                 # [B, 80, k], descending
+    gather = idx.reshape(B, -1)
+    cand_boxes = torch.gather(boxes, 1, gather[..., None].expand(-1, -1, 4)).view(B, -1, k, 4)
+    cand_coefs = torch.gather(coef, 1, gather[..., None].expand(-1, -1, coef.shape[-1])).view(B, -1, k, coef.shape[-1])
+    n_cls = cand_boxes.shape[1]
+    iou = _pairwise_iou(cand_boxes.view(B * n_cls, k, 4)).triu_(diagonal=1).view(B, n_cls, k, k)
+    alive = (iou.max(dim=2)[0] <= NMS_THRESH) & (scores > 0)
+    flat_scores = torch.where(alive, scores, torch.full_like(scores, -1.0)).view(B, -1)
+    top_scores, order = flat_scores.topk(MAX_DETECTIONS, dim=1)       # [B, 100]
+    classes = order // k
+    out_boxes = torch.gather(cand_boxes.view(B, -1, 4), 1, order[..., None].expand(-1, -1, 4))
+    out_coefs = torch.gather(cand_coefs.view(B, -1, coef.shape[-1]), 1, order[..., None].expand(-1, -1, coef.shape[-1]))
+    return {"box": out_boxes, "mask": out_coefs, "class": classes, "score": top_scores, "proto": pred["proto"]}

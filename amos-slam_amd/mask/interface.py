@@ -6,9 +6,9 @@ returns the 8-bit person mask (480 x 640, values 0 / 255, overlaps wrapping modu
 """
 import torch
 
-from .detect import detect
+from .detect import detect, detect_batch
 from .net import YolactR50
-from .post import person_mask
+from .post import person_mask, person_mask_batch
 from .pre import cxx_marshalling, fast_base_transform, resize_f32_cv
 
 
@@ -61,8 +61,6 @@ class MaskEngine:
             chw = cxx_marshalling(frames[b0:b0 + chunk])                      # [b, 3, 640, 480]
             imgs = resize_f32_cv(chw.permute(0, 2, 3, 1) * 255, 640, 480)     # [b, 480, 640, 3]
             pred = self.net(fast_base_transform(imgs))
-            for k in range(imgs.shape[0]):
-                m = person_mask(detect(pred, k), imgs.shape[2], imgs.shape[1])
-                if m is not None:
-                    out[b0 + k] = m
+            masks, _found = person_mask_batch(detect_batch(pred), imgs.shape[2], imgs.shape[1])
+            out[b0:b0 + imgs.shape[0]] = masks
         return out

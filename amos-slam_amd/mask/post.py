@@ -52,3 +52,31 @@ def person_mask(det, w, h):
     classes, masks = classes[order], masks[order]
     total = masks[classes == PERSON_CLASS].sum(0)
     return ((total.to(torch.int64) * 255) & 0xFF).to(torch.uint8)
+
+
+def person_mask_batch(det, w, h):
+    """person_mask for a batch from detect_batch's static-shape output.  Only the (at most 15) detections
+    that the reference would display are assembled: the 15 best with score > 0.15, of which the persons
+    are summed.  Returns uint8 [B, h, w] and a bool [B] "the network found something" (where it is False
+    the reference raises and its caller keeps an all-zero mask)."""
+    scores, classes, boxes, coefs, proto = det["score"], det["class"], det["box"], det["mask"], det["proto"]
+    B = scores.shape[0]
+    valid = scores > SCORE_THRESHOLD
+    found = valid.any(dim=1)
+    top_scores, order = torch.where(valid, scores, torch.full_like(scores, -1.0)).topk(TOP_K_DISPLAY, dim=1)
+    sel_valid = top_scores > SCORE_THRESHOLD
+    sel_cls = torch.gather(classes, 1, order)
+    sel_box = torch.gather(boxes, 1, order[..., None].expand(-1, -1, 4))
+    sel_coef = torch.gather(coefs, 1, order[..., None].expand(-1, -1, coefs.shape[-1]))
+    masks = torch.sigmoid(torch.einsum("bhwk,bnk->bnhw", proto, sel_coef))          # [B, 15, 138, 138]
+    ph, pw = masks.shape[2:]
+    x1, x2 = _sanitize(sel_box[..., 0], sel_box[..., 2], pw, 1)
+    y1, y2 = _sanitize(sel_box[..., 1], sel_box[..., 3], ph, 1)
+    cols = torch.arange(pw, device=masks.device, dtype=x1.dtype).view(1, 1, 1, -1)
+    rows = torch.arange(ph, device=masks.device, dtype=x1.dtype).view(1, 1, -1, 1)
+    inside = (cols >= x1[..., None, None]) & (cols < x2[..., None, None]) & (rows >= y1[..., None, None]) & (rows < y2[..., None, None])
+    masks = masks * inside.to(masks.dtype)
+    masks = F.interpolate(masks, (h, w), mode="bilinear", align_corners=False) > 0.5
+    person = (sel_valid & (sel_cls == PERSON_CLASS))[..., None, None]
+    total = (masks & person).sum(dim=1)
+    return ((total.to(torch.int64) * 255) & 0xFF).to(torch.uint8), found

@@ -126,6 +126,31 @@ def test_batch_path_equals_single(mask):
     assert torch.equal(batch[0], eng.eval_bgr(f0)) and torch.equal(batch[1], eng.eval_bgr(f1))
 
 
+def test_static_shape_batch_post_equals_reference_order_post(mask):
+    """detect_batch / person_mask_batch (static shapes, one launch set per batch) give the masks of the
+    per-frame detect / person_mask, which follow the reference's code path operation by operation."""
+    eng = _engine(mask, "cpu")
+    f0 = _frame()
+    frames = torch.from_numpy(np.stack([f0, np.ascontiguousarray(f0[::-1]), np.ascontiguousarray(f0[:, ::-1])]))
+    chw = mask.cxx_marshalling(frames)
+    imgs = mask.resize_f32_cv(chw.permute(0, 2, 3, 1) * 255, 640, 480)
+    with torch.no_grad():
+        pred = eng.net(mask.fast_base_transform(imgs))
+    got, found = mask.person_mask_batch(mask.detect_batch(pred), 640, 480)
+    assert bool(found.all())
+    for k in range(3):
+        want = mask.person_mask(mask.detect(pred, k), 640, 480)
+        g, w_ = got[k].numpy() > 0, want.numpy() > 0
+        assert (g & w_).sum() / max((g | w_).sum(), 1) >= 1 - 1e-3
+        assert torch.equal(got[k], want)
+    # nothing detected: zeros and found == False
+    none = mask.MaskEngine(device="cpu", seed=1)
+    with torch.no_grad():
+        pred0 = none.net(mask.fast_base_transform(imgs[:1]))
+    m0, f0_ = mask.person_mask_batch(mask.detect_batch(pred0), 640, 480)
+    assert not bool(f0_[0]) and int(m0.sum()) == 0
+
+
 def test_no_detection_returns_none(mask):
     eng = mask.MaskEngine(device="cpu", seed=1)  # unbiased random weights: softmax ~ 1/81 < 0.05
     assert eng.eval_bgr(_frame()) is None

@@ -1,33 +1,31 @@
-import sys, time, importlib, torch, numpy as np
-sys.path.insert(0,'.')
+#!/usr/bin/env python3
+"""Where the mask pass spends its time (GPU)."""
+import importlib, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import __graft_entry__ as e
 e.load_package()
 mask = importlib.import_module("amos_slam_amd.mask")
 eng = mask.MaskEngine(device="cuda:0", seed=0)
 with torch.no_grad():
     head = eng.net.prediction_layers[0].conf_layer.bias
-    b = head.detach().cpu().view(3,81).clone(); b[:,1]+=5.0; b[1,3]+=5.5; head.copy_(b.view(-1).to(head.device))
-frames = torch.randint(0,255,(32,480,640,3),dtype=torch.uint8,device="cuda:0")
+    b = head.detach().cpu().view(3, 81).clone(); b[:, 1] += 5.0; b[1, 3] += 5.5; head.copy_(b.view(-1).to(head.device))
+frames = torch.randint(0, 255, (32, 480, 640, 3), dtype=torch.uint8, device="cuda:0")
 def T(f, n=3):
-    f(); torch.cuda.synchronize(); t=time.time()
+    f(); torch.cuda.synchronize(); t = time.time()
     for _ in range(n): f()
-    torch.cuda.synchronize(); return (time.time()-t)/n*1e3
+    torch.cuda.synchronize(); return (time.time() - t) / n * 1e3
 with torch.no_grad():
-    print("full batch32 ms", T(lambda: eng.eval_bgr_batch(frames)))
-    chw = mask.cxx_marshalling(frames[0])
-    print("marshal 1 frame ms", T(lambda: mask.cxx_marshalling(frames[0])))
-    img = mask.resize_f32_cv(chw.permute(1,2,0)*255, 640, 480)
-    print("resize_f32 ms", T(lambda: mask.resize_f32_cv(chw.permute(1,2,0)*255, 640, 480)))
-    x = mask.fast_base_transform(img)
-    print("fbt ms", T(lambda: mask.fast_base_transform(img)))
-    batch = x.repeat(16,1,1,1)
-    print("net fwd b16 fp32 ms", T(lambda: eng.net(batch)))
-    pred = eng.net(batch)
-    print("detect ms", T(lambda: mask.detect(pred, 0)))
-    det = mask.detect(pred,0)
-    print("person_mask ms", T(lambda: mask.person_mask(det, 640, 480)))
-    net_cl = eng.net.to(memory_format=torch.channels_last)
-    bcl = batch.to(memory_format=torch.channels_last)
-    print("net fwd b16 fp32 channels_last ms", T(lambda: net_cl(bcl)))
-    with torch.autocast("cuda", dtype=torch.float16):
-        print("net fwd b16 fp16 autocast ms", T(lambda: net_cl(bcl)))
+    print("eval_bgr_batch(32)      ms", round(T(lambda: eng.eval_bgr_batch(frames)), 2))
+    chw = mask.cxx_marshalling(frames[:16])
+    print("marshal 16              ms", round(T(lambda: mask.cxx_marshalling(frames[:16])), 2))
+    imgs = mask.resize_f32_cv(chw.permute(0, 2, 3, 1) * 255, 640, 480)
+    print("resize_f32 16           ms", round(T(lambda: mask.resize_f32_cv(chw.permute(0, 2, 3, 1) * 255, 640, 480)), 2))
+    x = mask.fast_base_transform(imgs)
+    print("fast_base_transform 16  ms", round(T(lambda: mask.fast_base_transform(imgs)), 2))
+    print("net fwd 16 fp32         ms", round(T(lambda: eng.net(x)), 2))
+    pred = eng.net(x)
+    print("detect x16              ms", round(T(lambda: [mask.detect(pred, k) for k in range(16)]), 2))
+    dets = [mask.detect(pred, k) for k in range(16)]
+    print("person_mask x16         ms", round(T(lambda: [mask.person_mask(d, 640, 480) for d in dets]), 2))
