@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 256; 32 with the mask; 64 for c5)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--streams", type=int, default=2, help="independent lanes (handle + HIP streams) the batch is split over")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--check", action="store_true", help="verify one frame of the batch against the oracle")
     args = ap.parse_args()
@@ -105,18 +106,17 @@ def main():
     frames_np = synth.frames(shard.stream_for_rank(rank), 0, B, H, W)  # one stream per GPU
     d_frames = torch.from_numpy(frames_np).cuda(local_rank)
 
-    ext = pkg.OrbExtractor(n_features=cfg["n_features"], n_levels=cfg["n_levels"], max_width=W, max_height=H,
-                           max_batch=B, device=local_rank)
-    matcher = pkg.OrbMatcher(device=local_rank, stream=ext.stream)  # same stream: match follows extract
-    d_kps, d_desc, d_counts, cap = ext.batch_results_device()
-    pairs_q = torch.arange(B, dtype=torch.int32, device=f"cuda:{local_rank}")
-    pairs_t = (pairs_q - 1) % B  # frame k against frame k-1 (frame 0 against the last one)
-    d_match = torch.full((B, cap, 4), 1 << 30, dtype=torch.int32, device=f"cuda:{local_rank}")
-    torch.cuda.synchronize()
+    # The batch is split over S independent lanes (extractor + matcher handle, own HIP streams): kernels of
+    # one lane (e.g. the memory-bound pyramid) overlap kernels of the other (e.g. the VALU-bound FAST).
+    S = max(1, min(args.streams, B))
+    while B % S:
+        S -= 1
+    Bl = B // S  # frames per lane and step
 
-    ev_stream = torch.cuda.ExternalStream(ext.stream, device=local_rank)
-    match_events, mask_events = [], []
-    engine = d_bgr = None
+    class Lane:
+        pass
+
+    engine = None
     if use_mask:
         mask_mod = importlib.import_module("amos_slam_amd.mask")
         engine = mask_mod.MaskEngine(device=f"cuda:{local_rank}", seed=0)
@@ -126,36 +126,54 @@ def main():
             b[:, 1] += 5.0
             b[1, 3] += 5.5
             head.copy_(b.view(-1).to(head.device))
-        d_bgr = d_frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()  # gray replicated to BGR, resident in HBM
+    lanes = []
+    for li in range(S):
+        ln = Lane()
+        ln.ext = pkg.OrbExtractor(n_features=cfg["n_features"], n_levels=cfg["n_levels"], max_width=W, max_height=H,
+                                  max_batch=Bl, device=local_rank)
+        ln.matcher = pkg.OrbMatcher(device=local_rank, stream=ln.ext.stream)  # same stream: match follows extract
+        _, ln.d_desc, ln.d_counts, ln.cap = ln.ext.batch_results_device()
+        ln.frames = d_frames[li * Bl:(li + 1) * Bl]
+        ln.pairs_q = torch.arange(Bl, dtype=torch.int32, device=f"cuda:{local_rank}")
+        ln.pairs_t = (ln.pairs_q - 1) % Bl  # frame k against frame k-1 (the lane's first frame against its last)
+        ln.d_match = torch.full((Bl, ln.cap, 4), 1 << 30, dtype=torch.int32, device=f"cuda:{local_rank}")
+        ln.stream = torch.cuda.ExternalStream(ln.ext.stream, device=local_rank)
+        ln.bgr = ln.frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous() if use_mask else None  # gray as BGR, in HBM
+        lanes.append(ln)
+    ext, cap = lanes[0].ext, lanes[0].cap
+    torch.cuda.synchronize()
+    match_events, mask_events = [], []
 
     def step(timed):
-        if use_mask:
-            ext.detect_batch_device(d_frames.data_ptr(), H * W, W, W, H, B)
-            with torch.cuda.stream(ev_stream):  # the network runs on the extractor's stream: ordering is implicit
-                if timed:
-                    m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    m0.record(ev_stream)
-                masks = engine.eval_bgr_batch(d_bgr)
-                if timed:
-                    m1.record(ev_stream)
-                    mask_events.append((m0, m1))
-                ext.gate_batch_device(masks.data_ptr(), H * W, W)
-                ext.describe_batch_device()
-                step.keep = masks  # alive until the stream has consumed it
-        else:
-            ext.extract_batch_device(d_frames.data_ptr(), H * W, W, W, H, B)
-        if timed:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(ev_stream)
-        matcher.bruteforce_best2_batch_device(d_desc, cap * 32, d_counts, pairs_q.data_ptr(), pairs_t.data_ptr(), B, cap,
-                                              256, d_match.data_ptr())
-        if timed:
-            e1.record(ev_stream)
-            match_events.append((e0, e1))
+        for li, ln in enumerate(lanes):
+            rec = timed and li == 0  # per-kernel events on lane 0 only
+            if use_mask:
+                ln.ext.detect_batch_device(ln.frames.data_ptr(), H * W, W, W, H, Bl)
+                with torch.cuda.stream(ln.stream):  # the network runs on the lane's stream: ordering is implicit
+                    if rec:
+                        m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        m0.record(ln.stream)
+                    ln.masks = engine.eval_bgr_batch(ln.bgr)  # kept alive until the stream has consumed it
+                    if rec:
+                        m1.record(ln.stream)
+                        mask_events.append((m0, m1))
+                    ln.ext.gate_batch_device(ln.masks.data_ptr(), H * W, W)
+                    ln.ext.describe_batch_device()
+            else:
+                ln.ext.extract_batch_device(ln.frames.data_ptr(), H * W, W, W, H, Bl)
+            if rec:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(ln.stream)
+            ln.matcher.bruteforce_best2_batch_device(ln.d_desc, ln.cap * 32, ln.d_counts, ln.pairs_q.data_ptr(), ln.pairs_t.data_ptr(),
+                                                     Bl, ln.cap, 256, ln.d_match.data_ptr())
+            if rec:
+                e1.record(ln.stream)
+                match_events.append((e0, e1))
 
     def barrier():
-        ext.sync()
+        for ln in lanes:
+            ln.ext.sync()
         torch.cuda.synchronize()
         shard.barrier()
         torch.cuda.synchronize()
@@ -176,18 +194,18 @@ def main():
     if mask_events:
         stage_ms["mask_net"] = float(np.mean([a.elapsed_time(b) for a, b in mask_events]))
     # result digest: keypoint counts + number of matches within TH_LOW (final gather over RCCL)
-    n_kp = [len(ext.batch_fetch(f)[0]) for f in range(min(B, 8))]
+    n_kp = [len(ext.batch_fetch(f)[0]) for f in range(min(Bl, 8))]
     mean_kp = float(np.mean(n_kp))
-    good = int(((d_match[:, :, 1] <= 50).sum()).item())
+    good = int(sum(int((ln.d_match[:, :, 1] <= 50).sum().item()) for ln in lanes))
     # the one collective of the path: final gather of the per-rank digests
     digest_all = shard.gather_digests([float(sum(n_kp)), float(good)], f"cuda:{local_rank}")
 
     if args.check and rank == 0:
         import oracle_binding as ob
         orc = ob.Oracle(n_features=cfg["n_features"], n_levels=cfg["n_levels"])
-        for f in (0, B - 1):
-            kg, dg = ext.batch_fetch(f)
-            ko, do = orc.extract(frames_np[f])
+        for li, f in ((0, 0), (S - 1, Bl - 1)):
+            kg, dg = lanes[li].ext.batch_fetch(f)
+            ko, do = orc.extract(frames_np[li * Bl + f])
             assert kg.tobytes() == ko.tobytes() and dg.tobytes() == do.tobytes(), f"frame {f} differs from the oracle"
 
     if rank == 0:
@@ -195,7 +213,7 @@ def main():
         alg = algorithmic_bytes(lw, lh, mean_kp, W, H)
         total_alg = sum(alg.values())
         dominant = max((k for k in stage_ms if k != "mask_net"), key=lambda k: stage_ms[k])
-        dom_bytes = alg[dominant] * B  # bytes one launch (one batch) of the dominant kernel processes
+        dom_bytes = alg[dominant] * Bl  # bytes one launch (one lane's batch) of the dominant kernel processes
         dom_ms = stage_ms[dominant]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
@@ -204,7 +222,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 ent = tj.get(args.config, {}).get(dominant)
-                if ent and ent.get("batch") == B:
+                if ent and ent.get("batch") == Bl:
                     traffic = ent["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
@@ -222,7 +240,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": cfg["label"], "frames_per_step_per_gpu": B, "width": W, "height": H,
+            "config": {"workload": cfg["label"], "frames_per_step_per_gpu": B, "lanes_per_gpu": S, "frames_per_launch": Bl, "width": W, "height": H,
                        "n_features": cfg["n_features"], "n_levels": cfg["n_levels"], "ini_th_fast": 20, "min_th_fast": 7,
                        "mean_keypoints_per_frame": round(mean_kp, 1), "match": "frame k vs k-1, N x N best-2",
                        "synthetic_stream_seed": "stream = rank, frame k seeded 1000*rank+k (amos-slam_amd/synth.py)",
@@ -233,8 +251,8 @@ def main():
             "pipeline_roofline": {"algorithmic_bytes_per_frame": int(total_alg),
                                   "achieved_GBs": round(total_alg * fps / world / 1e9, 2),
                                   "frac": round(total_alg * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
-            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
-            "stage_frac_of_hbm_peak": {k: (round(alg[k] * B / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if v > 0 else None)
+            "stage_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
+            "stage_frac_of_hbm_peak": {k: (round(alg[k] * Bl / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if v > 0 else None)
                                        for k, v in stage_ms.items()},
             "digest_per_rank": digest_all,
         }

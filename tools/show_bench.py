@@ -7,4 +7,4 @@ for line in sys.stdin:
     line = line.strip()
     if line.startswith("{"):
         d = json.loads(line)
-        print(tag, d["value"], d["ms_per_step"], d["stage_ms_per_step"])
+        print(tag, d["value"], d["ms_per_step"], d.get("stage_ms_per_launch", d.get("stage_ms_per_step")))
