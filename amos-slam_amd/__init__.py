@@ -254,7 +254,7 @@ class OrbExtractor:
     def sync(self):
         _check(self.L.amos_orb_sync(self.h), "amos_orb_sync")
 
-    STAGES = ("pyramid", "fast", "octree", "orient", "blur", "describe")
+    STAGES = ("import", "pyramid", "fast", "octree", "orient", "blur", "describe")
 
     def timing_enable(self, max_records):
         _check(self.L.amos_orb_timing_enable(self.h, C.c_int(max_records)), "amos_orb_timing_enable")

@@ -42,7 +42,6 @@ struct LevelGeom {
     int kpOff;                       // offset of the level's keypoint list inside one frame
     int tabX, tabY;                  // offsets into the resize coefficient tables
     int blurGroups, blurItemStart;   // blur work items: 4-px column groups x 32-row strips
-    int fastMagic;                   // unused (reserved)
     float scale;                     // mvScaleFactor[level]
     float patchSize;                 // (float)(int)(31 * scale), ORBextractor.cc:1177
 };

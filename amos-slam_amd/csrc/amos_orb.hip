@@ -34,6 +34,10 @@ static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cv_round(float v) { return (int)lrintf(v); }  // round half to even
 
+// events of one timed pass: 0 start, 1 after the level-0 import, 2 after the last resize level, 3 before FAST,
+// 4 after FAST, 5 after the quad-tree, 6 after the orientation, 7 before rBRIEF, 8 after rBRIEF
+constexpr int kTimingEvents = 9;
+
 }  // namespace amos
 
 using namespace amos;
@@ -77,7 +81,7 @@ struct amos_orb {
     int capCenters = 0, capRm = 0;
     int inputPitch = 0, maskPitch = 0;
     int nFrames = 0;      // frames of the last detect / batch
-    std::vector<hipEvent_t> events;  // [maxRecords][AMOS_ORB_STAGES + 1]
+    std::vector<hipEvent_t> events;  // [maxRecords][kTimingEvents]
     int maxRecords = 0, nRecords = 0;
     bool detected = false, described = false, gated = false;
 };
@@ -313,7 +317,7 @@ static int set_geometry(amos_orb *h, int W, int Hh)
 static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, size_t rowStride, int nFrames)
 {
     const Geom &g = h->geom;
-    hipEvent_t *ev = (h->maxRecords > 0 && h->nRecords < h->maxRecords) ? &h->events[(size_t)h->nRecords * (AMOS_ORB_STAGES + 1)] : nullptr;
+    hipEvent_t *ev = (h->maxRecords > 0 && h->nRecords < h->maxRecords) ? &h->events[(size_t)h->nRecords * (kTimingEvents)] : nullptr;
     if (ev) (void)hipEventRecord(ev[0], h->stream);
     for (int l = 0; l < g.nLevels; l++) {
         const LevelGeom &lg = g.lv[l];
@@ -324,7 +328,9 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
             hipLaunchKernelGGL(k_pyramid_level0, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, srcAligned);
         else
             hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);
+        if (ev && l == 0) (void)hipEventRecord(ev[1], h->stream);
     }
+    if (ev) (void)hipEventRecord(ev[2], h->stream);
     // fork: the blur only needs the pyramid; it streams memory on the side stream while FAST (VALU-bound)
     // and the quad-tree (latency-bound) run on the main one
     AMOS_HIP_CHECK(hipEventRecord(h->evFork, h->stream));
@@ -334,17 +340,17 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
     if (ev) (void)hipEventRecord(h->evBlur1, h->streamB);
     AMOS_HIP_CHECK(hipEventRecord(h->evJoin, h->streamB));
     h->blurDone = true;
-    if (ev) (void)hipEventRecord(ev[1], h->stream);
+    if (ev) (void)hipEventRecord(ev[3], h->stream);
     hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid((g.totalCells + 3) / 4, nFrames)), dim3(256), 4 * (size_t)g.fastWaveBytes, h->stream,
                        h->dPyr, h->dGeom, h->dCells, h->dSlotCount, h->dSlots, nFrames);
-    if (ev) (void)hipEventRecord(ev[2], h->stream);
+    if (ev) (void)hipEventRecord(ev[4], h->stream);
     const size_t lds = oct_lds_bytes(h->octNC, h->octSC);
     hipLaunchKernelGGL(k_octree, dim3(nFrames * g.nLevels), dim3(256), lds, h->stream, h->dGeom, h->dCells, h->dSlotCount,
                        h->dSlots, h->dPts, h->dNodeOf, h->dQuadOf, h->dCandCount, h->dLvKps, h->dLvCount, h->octNC, h->octSC);
-    if (ev) (void)hipEventRecord(ev[3], h->stream);
+    if (ev) (void)hipEventRecord(ev[5], h->stream);
     hipLaunchKernelGGL(k_orient, dim3(xcd_grid((g.kpLevelTotal + 15) / 16, nFrames)), dim3(256), 0, h->stream, h->dPyr, h->dGeom,
                        h->dLvKps, h->dLvCount, nFrames);
-    if (ev) (void)hipEventRecord(ev[4], h->stream);
+    if (ev) (void)hipEventRecord(ev[6], h->stream);
     AMOS_HIP_CHECK(hipGetLastError());
     h->nFrames = nFrames;
     h->detected = true;
@@ -355,12 +361,12 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
 static int launch_describe(amos_orb *h, int nFrames)
 {
     const Geom &g = h->geom;
-    hipEvent_t *ev = (h->maxRecords > 0 && h->nRecords < h->maxRecords) ? &h->events[(size_t)h->nRecords * (AMOS_ORB_STAGES + 1)] : nullptr;
+    hipEvent_t *ev = (h->maxRecords > 0 && h->nRecords < h->maxRecords) ? &h->events[(size_t)h->nRecords * (kTimingEvents)] : nullptr;
     AMOS_HIP_CHECK(hipStreamWaitEvent(h->stream, h->evJoin, 0));  // join: blurred planes ready
-    if (ev) (void)hipEventRecord(ev[5], h->stream);
+    if (ev) (void)hipEventRecord(ev[7], h->stream);
     hipLaunchKernelGGL(k_describe, dim3(xcd_grid((g.kpLevelTotal + 15) / 16, nFrames)), dim3(256), 0, h->stream, h->dBlur, h->dGeom,
                        h->dLvKps, h->dLvCount, h->dOutKps, h->dOutDesc, h->dOutCount, nFrames);
-    if (ev) { (void)hipEventRecord(ev[6], h->stream); h->nRecords++; }
+    if (ev) { (void)hipEventRecord(ev[8], h->stream); h->nRecords++; }
     AMOS_HIP_CHECK(hipGetLastError());
     h->described = true;
     return AMOS_OK;
@@ -851,7 +857,7 @@ int amos_orb_timing_enable(amos_orb *h, int max_records)
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     h->events.clear();
     h->maxRecords = h->nRecords = 0;
-    for (int i = 0; i < max_records * (AMOS_ORB_STAGES + 1); i++) {
+    for (int i = 0; i < max_records * (kTimingEvents); i++) {
         hipEvent_t e;
         AMOS_HIP_CHECK(hipEventCreate(&e));
         h->events.push_back(e);
@@ -865,20 +871,21 @@ int amos_orb_timing_collect(amos_orb *h, float *avg_ms, int *n_records)
     if (!h || !avg_ms) return AMOS_ERR_INVALID;
     AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
     for (int s = 0; s < AMOS_ORB_STAGES; s++) avg_ms[s] = 0.f;
+    static const int first[AMOS_ORB_STAGES] = {0, 1, 3, 4, 5, -1, 7}, last[AMOS_ORB_STAGES] = {1, 2, 4, 5, 6, -1, 8};
     for (int r = 0; r < h->nRecords; r++)
         for (int s = 0; s < AMOS_ORB_STAGES; s++) {
+            if (first[s] < 0) continue;  // the blur runs on the side stream: timed below from its own events
             float ms = 0.f;
-            const hipEvent_t *ev = &h->events[(size_t)r * (AMOS_ORB_STAGES + 1)];
-            if (s == 4) continue;  // the blur runs on the side stream: timed below from its own events
-            AMOS_HIP_CHECK(hipEventElapsedTime(&ms, ev[s], ev[s + 1]));
+            const hipEvent_t *ev = &h->events[(size_t)r * kTimingEvents];
+            AMOS_HIP_CHECK(hipEventElapsedTime(&ms, ev[first[s]], ev[last[s]]));
             avg_ms[s] += ms;
         }
     if (h->nRecords > 0) {
         for (int s = 0; s < AMOS_ORB_STAGES; s++) avg_ms[s] /= (float)h->nRecords;
         AMOS_HIP_CHECK(hipStreamSynchronize(h->streamB));
-        float ms = 0.f;  // last pass only (one event pair): the blur overlaps stages 2-3
+        float ms = 0.f;  // last pass only (one event pair): the blur overlaps FAST
         AMOS_HIP_CHECK(hipEventElapsedTime(&ms, h->evBlur0, h->evBlur1));
-        avg_ms[4] = ms;
+        avg_ms[5] = ms;
     }
     if (n_records) *n_records = h->nRecords;
     h->nRecords = 0;

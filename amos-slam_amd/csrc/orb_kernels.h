@@ -295,9 +295,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint8_t *tile = reinterpret_cast<const uint8_t *>(tile32) + 3 * tileStride + 4;  // pixel (x0, y0)
-#ifdef AMOS_FAST_ABLATE  // timing-only builds (outputs wrong): where does the kernel spend its time?
-    if (AMOS_FAST_ABLATE == 1) { if (lane == 0) slotCount[(size_t)frame * g->totalCells + cellIdx] = tile32[lane]; return; }
-#endif
     const int iniTh = min(max(g->iniTh, 0), 255), minTh = min(max(g->minTh, 0), 255);
     const int groups = c.groups, nitems = th * groups;
     const unsigned long long ltmask = (1ull << lane) - 1ull;
@@ -334,9 +331,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-#ifdef AMOS_FAST_ABLATE
-            if (AMOS_FAST_ABLATE == 2) { if (bits == 0xffu) cand[lane] = (uint16_t)p0; continue; }
-#endif
             {   // append the survivors: one wave-wide prefix sum of the per-lane counts, then up to 4 stores
                 const int c = __popc(bits);
                 const int incl = wave_inclusive_scan(c);
@@ -349,21 +343,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-#ifdef AMOS_FAST_ABLATE
-            if (AMOS_FAST_ABLATE == 3) { done = ncand & ~63; continue; }
-#endif
             while (ncand - done >= 64) {  // wave-uniform: dense chunks of 64 survivors
                 fast_score_chunk(tile, tileStride, amap, cand, done, 64, lane, t);
                 done += 64;
             }
         }
-#ifdef AMOS_FAST_ABLATE
-        if (AMOS_FAST_ABLATE == 2 || AMOS_FAST_ABLATE == 3) { nkept = 1; kept[0] = cand[0]; break; }
-#endif
         fast_score_chunk(tile, tileStride, amap, cand, done, ncand - done, lane, t);
-#ifdef AMOS_FAST_ABLATE
-        if (AMOS_FAST_ABLATE == 4) { nkept = 1; kept[0] = amap[70]; break; }
-#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- phase 3: strict 3x3 NMS.  For a corner at threshold t (a > t) every non-corner neighbour is

@@ -42,7 +42,8 @@ def algorithmic_bytes(level_w, level_h, n_kp, width, height):
     wh = [int(w) * int(h) for w, h in zip(level_w, level_h)]
     padded = [(int(w) + 38) * (int(h) + 38) for w, h in zip(level_w, level_h)]
     return {
-        "pyramid": width * height + sum(wh[:-1]) + sum(padded),
+        "import": width * height + padded[0],                  # level 0: frame read, padded plane written
+        "pyramid": sum(wh[:-1]) + sum(padded[1:]),             # levels >= 1: level l-1 read, padded level l written
         "fast": sum(wh),
         "octree": 0,  # selection over the candidate list: negligible bytes, latency-bound
         "orient": n_kp * 749,
@@ -212,9 +213,13 @@ def main():
         lw, lh = ext.level_sizes(W, H)
         alg = algorithmic_bytes(lw, lh, mean_kp, W, H)
         total_alg = sum(alg.values())
+        # the dominant KERNEL: largest total time per pass; "pyramid" is n_levels - 1 launches of one kernel,
+        # so its per-launch figures are the averages over those launches (what rocprofv3 --stats reports)
+        launches = {k: 1 for k in stage_ms}
+        launches["pyramid"] = cfg["n_levels"] - 1
         dominant = max((k for k in stage_ms if k != "mask_net"), key=lambda k: stage_ms[k])
-        dom_bytes = alg[dominant] * Bl  # bytes one launch (one lane's batch) of the dominant kernel processes
-        dom_ms = stage_ms[dominant]
+        dom_bytes = alg[dominant] * Bl / launches[dominant]  # algorithmic bytes of one (average) launch
+        dom_ms = stage_ms[dominant] / launches[dominant]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -223,7 +228,7 @@ def main():
                 tj = json.load(open(tpath))
                 ent = tj.get(args.config, {}).get(dominant)
                 if ent and ent.get("batch") == Bl:
-                    traffic = ent["hbm_bytes_per_launch"]
+                    traffic = ent["hbm_bytes_per_launch"] / launches[dominant]
             except Exception:
                 traffic = None
         fps = world * B * args.steps / elapsed
@@ -247,7 +252,8 @@ def main():
                        "parallelism": f"frames sharded {world} ways, one process per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},
+                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
+                         "launches_per_pass": launches[dominant]},
             "pipeline_roofline": {"algorithmic_bytes_per_frame": int(total_alg),
                                   "achieved_GBs": round(total_alg * fps / world / 1e9, 2),
                                   "frac": round(total_alg * fps / world / 1e9 / HBM_PEAK_GBS, 5)},

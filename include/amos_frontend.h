@@ -176,9 +176,10 @@ int amos_orb_sync(amos_orb *h);
  * After amos_orb_timing_enable(h, max_records) every batch / extract pass records one event
  * between consecutive stages; amos_orb_timing_collect() synchronises, returns the average
  * duration of each stage in milliseconds over the recorded passes and resets the record count.
- * Stages: 0 pyramid (all level launches), 1 FAST cells, 2 quad-tree, 3 orientation, 4 blur,
- * 5 rBRIEF.  max_records = 0 switches timing off. */
-#define AMOS_ORB_STAGES 6
+ * Stages: 0 level-0 import (k_pyramid_level0), 1 resize levels (n_levels - 1 launches of
+ * k_pyramid_level), 2 FAST cells, 3 quad-tree, 4 orientation, 5 blur (side stream, overlaps
+ * FAST), 6 rBRIEF.  max_records = 0 switches timing off. */
+#define AMOS_ORB_STAGES 7
 int amos_orb_timing_enable(amos_orb *h, int max_records);
 int amos_orb_timing_collect(amos_orb *h, float *avg_ms, int *n_records);
 /* The hipStream_t the handle issues on. */
