@@ -71,6 +71,41 @@ def cpu_baseline(synth, cfg, n_sample):
             "sample": f"{n_sample} frames of the same synthetic stream: oracle extract + N x N best-2 match, 1 thread"}
 
 
+def _cpu_worker(job):
+    """One worker process of the all-cores CPU baseline: frames of its own synthetic stream."""
+    root, cfg, stream, n = job
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import importlib
+    import __graft_entry__ as entry
+    entry.load_package()
+    synth = importlib.import_module("amos_slam_amd.synth")
+    import oracle_binding as ob
+    orc = ob.Oracle(n_features=cfg["n_features"], n_levels=cfg["n_levels"])
+    frames = [synth.frame(stream, k, cfg["height"], cfg["width"]) for k in range(n + 1)]
+    t0 = time.perf_counter()
+    prev = orc.extract(frames[0])[1]
+    for k in range(1, n + 1):
+        _, desc = orc.extract(frames[k])
+        ob.bruteforce_best2(desc, prev)
+        prev = desc
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(cfg, workers, n_per_worker):
+    """The same oracle, one frame stream per process, `workers` processes (the GPU box grants 16 host
+    cores per GPU).  Extra information beside the contract's single-thread cpu_baseline."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(workers) as pool:
+        t0 = time.perf_counter()
+        pool.map(_cpu_worker, [(ROOT, {k: cfg[k] for k in ("n_features", "n_levels", "height", "width")}, 100 + w, n_per_worker)
+                               for w in range(workers)])
+        dt = time.perf_counter() - t0  # includes process start-up and frame synthesis: a lower bound on fps
+    return {"value": round(workers * n_per_worker / dt, 2), "unit": "frames/s", "cores": workers, "kind": "port",
+            "sample": f"{workers} processes x {n_per_worker} frames (wall time incl. start-up)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +116,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="independent lanes (handle + HIP streams) the batch is split over")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--check", action="store_true", help="verify one frame of the batch against the oracle")
+    ap.add_argument("--cpu-all-cores", type=int, default=0, help="also time the oracle on this many processes (0 = off)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -266,6 +302,8 @@ def main():
         if world == 1 and n_cpu > 0:
             out["cpu_baseline"] = cpu_baseline(synth, cfg, n_cpu)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            if args.cpu_all_cores > 0:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, args.cpu_all_cores, 24 if args.config != "c5" else 3)
         print(json.dumps(out), flush=True)
 
     shard.finalize()
