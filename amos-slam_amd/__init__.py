@@ -27,7 +27,8 @@ EXPORTS = [
     "amos_orb_set_level_keypoints", "amos_orb_level_layout", "amos_orb_fetch_levels", "amos_orb_store_levels", "amos_orb_gate", "amos_orb_closed_mask", "amos_orb_describe",
     "amos_orb_extract", "amos_orb_level_image", "amos_orb_blurred_image", "amos_orb_level_candidates",
     "amos_orb_extract_batch_device", "amos_orb_detect_batch_device", "amos_orb_gate_batch_device",
-    "amos_orb_describe_batch_device", "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
+    "amos_orb_describe_batch_device", "amos_orb_extract_batch_device_color", "amos_frame_rgbd_glue_batch_device",
+    "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device",
@@ -236,6 +237,22 @@ class OrbExtractor:
 
     def describe_batch_device(self):
         _check(self.L.amos_orb_describe_batch_device(self.h), "amos_orb_describe_batch_device")
+
+    def extract_batch_device_color(self, d_ptr, frame_stride, row_stride, width, height, n_frames, channels=3, rgb_order=False):
+        """cvtColor(BGR/RGB[A] -> gray) fused into the level-0 import (Tracking.cc:308-321)."""
+        self.shape = (height, width)
+        _check(self.L.amos_orb_extract_batch_device_color(self.h, C.c_void_p(d_ptr), C.c_size_t(frame_stride), C.c_size_t(row_stride),
+                                                          C.c_int(width), C.c_int(height), C.c_int(n_frames), C.c_int(channels),
+                                                          C.c_int(int(rgb_order))), "amos_orb_extract_batch_device_color")
+
+    def rgbd_glue_batch_device(self, d_depth, depth_is_u16, depth_map_factor, depth_frame_stride, depth_row_stride, mbf, bounds,
+                               d_u_right, d_depth_out, d_grid_cell):
+        """ComputeStereoFromRGBD + grid cell of every keypoint of the last batch (Frame.cc:1576-1615, 1007-1030)."""
+        _check(self.L.amos_frame_rgbd_glue_batch_device(self.h, C.c_void_p(d_depth), C.c_int(int(depth_is_u16)), C.c_float(depth_map_factor),
+                                                        C.c_size_t(depth_frame_stride), C.c_size_t(depth_row_stride), C.c_float(mbf),
+                                                        C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]),
+                                                        C.c_void_p(d_u_right), C.c_void_p(d_depth_out), C.c_void_p(d_grid_cell)),
+               "amos_frame_rgbd_glue_batch_device")
 
     def batch_results_device(self):
         kps, desc, cnt, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)

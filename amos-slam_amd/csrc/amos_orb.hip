@@ -314,7 +314,7 @@ static int set_geometry(amos_orb *h, int W, int Hh)
 }
 
 // ---------------------------------------------------------------------------------------------
-static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, size_t rowStride, int nFrames)
+static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, size_t rowStride, int nFrames, int channels = 1, int rgbOrder = 0)
 {
     const Geom &g = h->geom;
     hipEvent_t *ev = (h->maxRecords > 0 && h->nRecords < h->maxRecords) ? &h->events[(size_t)h->nRecords * (kTimingEvents)] : nullptr;
@@ -324,7 +324,9 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
         const int groups = (kPadLeft + lg.w + kEdge + 3) / 4;
         dim3 grid((groups + 63) / 64, (lg.h + 2 * kEdge + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames), block(64, 4);
         const int srcAligned = ((uintptr_t)dSrc % 4 == 0) && (frameStride % 4 == 0) && (rowStride % 4 == 0);
-        if (l == 0)
+        if (l == 0 && channels > 1)
+            hipLaunchKernelGGL(k_pyramid_level0_color, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, channels, rgbOrder);
+        else if (l == 0)
             hipLaunchKernelGGL(k_pyramid_level0, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, srcAligned);
         else
             hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);
@@ -820,6 +822,38 @@ int amos_orb_describe_batch_device(amos_orb *h)
     if (!h || !h->detected) { set_error("amos_orb_describe_batch_device before detect"); return AMOS_ERR_STATE; }
     AMOS_HIP_CHECK(hipSetDevice(h->device));
     return launch_describe(h, h->nFrames);
+}
+
+int amos_orb_extract_batch_device_color(amos_orb *h, const uint8_t *d_color, size_t frame_stride, size_t row_stride, int width,
+                                        int height, int n_frames, int channels, int rgb_order)
+{
+    if (!h || !d_color || n_frames < 1 || width < 1 || height < 1 || (channels != 3 && channels != 4) || row_stride < (size_t)width * channels) {
+        set_error("amos_orb_extract_batch_device_color: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    if (n_frames > h->maxB) { set_error("batch of %d frames exceeds the handle's max_batch %d", n_frames, h->maxB); return AMOS_ERR_CAPACITY; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    int rc = set_geometry(h, width, height);
+    if (rc != AMOS_OK) return rc;
+    rc = launch_detect(h, d_color, frame_stride, row_stride, n_frames, channels, rgb_order != 0);
+    if (rc != AMOS_OK) return rc;
+    return launch_describe(h, n_frames);
+}
+
+int amos_frame_rgbd_glue_batch_device(amos_orb *h, const void *d_depth, int depth_is_u16, float depth_map_factor,
+                                      size_t depth_frame_stride_bytes, size_t depth_row_stride_bytes, float mbf, float min_x, float max_x,
+                                      float min_y, float max_y, float *d_u_right, float *d_depth_out, int32_t *d_grid_cell)
+{
+    if (!h || !d_depth || !d_u_right || !d_depth_out || !d_grid_cell || !(max_x > min_x) || !(max_y > min_y)) { set_error("amos_frame_rgbd_glue_batch_device: invalid argument"); return AMOS_ERR_INVALID; }
+    if (!h->described) { set_error("amos_frame_rgbd_glue_batch_device before an extraction"); return AMOS_ERR_STATE; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    const float wInv = static_cast<float>(AMOS_FRAME_GRID_COLS) / static_cast<float>(max_x - min_x);  // Frame.cc:302-303
+    const float hInv = static_cast<float>(AMOS_FRAME_GRID_ROWS) / static_cast<float>(max_y - min_y);
+    hipLaunchKernelGGL(k_rgbd_glue, dim3((h->geom.kpCap + 255) / 256, h->nFrames), dim3(256), 0, h->stream, h->dGeom, h->dOutKps, h->dOutCount,
+                       (const uint8_t *)d_depth, depth_is_u16, depth_map_factor, depth_frame_stride_bytes, depth_row_stride_bytes, mbf, min_x, min_y,
+                       wInv, hInv, d_u_right, d_depth_out, d_grid_cell);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
 }
 
 int amos_orb_batch_results_device(amos_orb *h, const amos_keypoint **d_kps, const uint8_t **d_desc, const int32_t **d_counts,

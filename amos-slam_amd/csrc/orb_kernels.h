@@ -9,6 +9,7 @@
 #pragma once
 #include "amos_common.h"
 #include "../../include/amos_orb_pattern.h"
+#include "../../include/amos_host_types.h"
 
 namespace amos {
 
@@ -91,6 +92,45 @@ __global__ __launch_bounds__(256) void k_pyramid_level0(const uint8_t *__restric
             packed = *reinterpret_cast<const uint32_t *>(s + x0);
         } else {
             packed = (uint32_t)s[xi[0]] | ((uint32_t)s[xi[1]] << 8) | ((uint32_t)s[xi[2]] << 16) | ((uint32_t)s[xi[3]] << 24);
+        }
+        *reinterpret_cast<uint32_t *>(plane + __mul24(yo, lg.stride) + x0) = packed;
+    }
+}
+
+// Level 0 from interleaved colour frames: cv::cvtColor(..., CV_{BGR,RGB}[A]2GRAY) (Tracking.cc:308-321)
+// fused into the import.  OpenCV 4.x 8-bit path: gray = (B*3735 + G*19235 + R*9798 + 16384) >> 15.
+__global__ __launch_bounds__(256) void k_pyramid_level0_color(const uint8_t *__restrict__ src, size_t srcFrameStride,
+                                                             size_t srcRowStride, uint8_t *__restrict__ pyr,
+                                                             const Geom *__restrict__ g, int channels, int rgbOrder)
+{
+    const LevelGeom &lg = g->lv[0];
+    const int frame = blockIdx.z;
+    const int gx = blockIdx.x * 64 + threadIdx.x;
+    const int row0 = (blockIdx.y * 4 + threadIdx.y) * kPyrRows;
+    const int groups = (kPadLeft + lg.w + kEdge + 3) >> 2;
+    if (gx >= groups) return;
+    const int x0 = gx * 4 - kPadLeft;
+    int xi[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int xo = x0 + k;
+        xo = xo < -kEdge ? -kEdge : (xo > lg.w + kEdge - 1 ? lg.w + kEdge - 1 : xo);
+        xi[k] = reflect101(xo, lg.w) * channels;
+    }
+    const unsigned c0 = rgbOrder ? 9798u : 3735u, c2 = rgbOrder ? 3735u : 9798u;  // weight of byte 0 / byte 2
+    uint8_t *plane = level_origin(pyr, g, frame, 0);
+    const uint8_t *s0 = src + (size_t)frame * srcFrameStride;
+#pragma unroll
+    for (int r = 0; r < kPyrRows; r++) {
+        const int yo = row0 + r - kEdge;
+        if (yo >= lg.h + kEdge) break;
+        const uint8_t *s = s0 + (size_t)reflect101(yo, lg.h) * srcRowStride;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint8_t *px = s + xi[k];
+            const unsigned y = (px[0] * c0 + px[1] * 19235u + px[2] * c2 + 16384u) >> 15;
+            packed |= y << (8 * k);
         }
         *reinterpret_cast<uint32_t *>(plane + __mul24(yo, lg.stride) + x0) = packed;
     }
@@ -1221,6 +1261,34 @@ __global__ __launch_bounds__(256) void k_gate(const Geom *__restrict__ g, amos_k
         if (tid == 0) lvCount[frame * g->nLevels + level] = keepBase;
     }
     if (tid == 0) nRemoved[frame] = remBase;
+}
+
+// Frame::ComputeStereoFromRGBD (Frame.cc:1576-1615) + the grid cell of PosInGrid (Frame.cc:1007-1030),
+// one thread per keypoint of the batch result.  grid = (ceil(kpCap/256), frames).
+__global__ __launch_bounds__(256) void k_rgbd_glue(const Geom *__restrict__ g, const amos_keypoint *__restrict__ outKps,
+                                                  const int *__restrict__ outCount, const uint8_t *__restrict__ depth,
+                                                  int depthIsU16, float depthFactor, size_t depthFrameStride,
+                                                  size_t depthRowStride, float mbf, float minX, float minY,
+                                                  float gridWInv, float gridHInv, float *__restrict__ uRight,
+                                                  float *__restrict__ depthOut, int *__restrict__ gridCell)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
+    if (i >= outCount[frame] || i >= g->kpCap) return;
+    const size_t o = (size_t)frame * g->kpCap + i;
+    const amos_keypoint kp = outKps[o];
+    const int u = (int)kp.x, v = (int)kp.y;  // imDepth.at<float>(v, u) with float arguments
+    float d = -1.f;
+    if (u >= 0 && v >= 0 && u < g->W && v < g->H) {
+        const uint8_t *row = depth + (size_t)frame * depthFrameStride + (size_t)v * depthRowStride;
+        d = depthIsU16 ? __fmul_rn((float)reinterpret_cast<const uint16_t *>(row)[u], depthFactor)
+                       : reinterpret_cast<const float *>(row)[u];
+    }
+    const bool ok = d > 0;
+    depthOut[o] = ok ? d : -1.f;
+    uRight[o] = ok ? __fsub_rn(kp.x, __fdiv_rn(mbf, d)) : -1.f;
+    const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, minX), gridWInv));
+    const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, minY), gridHInv));
+    gridCell[o] = (px < 0 || px >= AMOS_FRAME_GRID_COLS || py < 0 || py >= AMOS_FRAME_GRID_ROWS) ? -1 : px * AMOS_FRAME_GRID_ROWS + py;
 }
 
 // Unpacks the compacted candidates of one level into amos_keypoint records (parity tests only).

@@ -164,6 +164,23 @@ int amos_orb_gate_batch_device(amos_orb *h, const uint8_t *d_masks, size_t mask_
                                size_t mask_row_stride);
 int amos_orb_describe_batch_device(amos_orb *h);
 
+/* ---- callers either side of the path (SURVEY 8f "next" rows), device resident ----
+ * Tracking::GrabImageRGBD's cvtColor(..., CV_{BGR,RGB}[A]2GRAY) (Tracking.cc:308-321) fused into the
+ * level-0 import: d_color holds interleaved 8-bit frames with `channels` = 3 or 4 bytes per pixel,
+ * rgb_order != 0 for RGB[A] (Tracking's mbRGB), 0 for BGR[A].  Otherwise as amos_orb_extract_batch_device. */
+int amos_orb_extract_batch_device_color(amos_orb *h, const uint8_t *d_color, size_t frame_stride, size_t row_stride,
+                                        int width, int height, int n_frames, int channels, int rgb_order);
+/* Frame::ComputeStereoFromRGBD (Frame.cc:1576-1615) and the cell of Frame::AssignFeaturesToGrid /
+ * PosInGrid (Frame.cc:431-461, 1007-1030) for every keypoint of the last batch, zero-distortion cameras
+ * (mvKeysUn == mvKeys, as for TUM3).  The depth map is 16-bit with Tracking's convertTo(CV_32F,
+ * depth_map_factor) applied on the fly (depth_is_u16 != 0) or already float32.  Outputs are
+ * [n_frames][capacity] arrays on the device (capacity from amos_orb_batch_results_device):
+ * u_right / depth = -1 where the depth is not positive, grid_cell = col * 48 + row or -1. */
+int amos_frame_rgbd_glue_batch_device(amos_orb *h, const void *d_depth, int depth_is_u16, float depth_map_factor,
+                                      size_t depth_frame_stride_bytes, size_t depth_row_stride_bytes, float mbf,
+                                      float min_x, float max_x, float min_y, float max_y, float *d_u_right,
+                                      float *d_depth_out, int32_t *d_grid_cell);
+
 /* Device pointers of the batch results: keypoints [max_batch][capacity], descriptors
  * [max_batch][capacity][32], counts [max_batch].  Valid until destroy. */
 int amos_orb_batch_results_device(amos_orb *h, const amos_keypoint **d_kps, const uint8_t **d_desc,

@@ -1290,3 +1290,40 @@ int orc_search_for_initialization(const amos_frame_view *f1, const amos_frame_vi
     grid_free(&g);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Callers either side of the path.                                                  */
+void orc_color_to_gray(const uint8_t *src, size_t sstride, int w, int h, int channels, int rgb_order, uint8_t *dst,
+                       size_t dstride)
+{
+    const int RY15 = 9798, GY15 = 19235, BY15 = 3735; /* color.hpp: gray_shift = 15 */
+    const int c0 = rgb_order ? RY15 : BY15, c2 = rgb_order ? BY15 : RY15;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t *p = src + (size_t)y * sstride + (size_t)x * channels;
+            dst[(size_t)y * dstride + x] = (uint8_t)((p[0] * c0 + p[1] * GY15 + p[2] * c2 + (1 << 14)) >> 15);
+        }
+}
+
+float orc_depth_convert(uint16_t raw, float factor) { return (float)raw * factor; }
+
+void orc_rgbd_glue(const amos_keypoint *kps, int n, const float *depth, size_t depth_stride_elems, int w, int h, float mbf,
+                   float min_x, float max_x, float min_y, float max_y, float *u_right, float *depth_out, int32_t *grid_cell)
+{
+    const float winv = (float)AMOS_FRAME_GRID_COLS / (float)(max_x - min_x);
+    const float hinv = (float)AMOS_FRAME_GRID_ROWS / (float)(max_y - min_y);
+    for (int i = 0; i < n; i++) {
+        const float v = kps[i].y, u = kps[i].x;
+        u_right[i] = -1.f;
+        depth_out[i] = -1.f;
+        if ((int)u >= 0 && (int)v >= 0 && (int)u < w && (int)v < h) { /* outside is UB in the reference */
+            const float d = depth[(size_t)(int)v * depth_stride_elems + (int)u];
+            if (d > 0) {
+                depth_out[i] = d;
+                u_right[i] = kps[i].x - mbf / d;
+            }
+        }
+        const int px = (int)roundf((kps[i].x - min_x) * winv), py = (int)roundf((kps[i].y - min_y) * hinv);
+        grid_cell[i] = (px < 0 || px >= AMOS_FRAME_GRID_COLS || py < 0 || py >= AMOS_FRAME_GRID_ROWS) ? -1 : px * AMOS_FRAME_GRID_ROWS + py;
+    }
+}

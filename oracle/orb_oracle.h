@@ -90,6 +90,17 @@ void orc_bruteforce_best2(const uint8_t *q, int nq, const uint8_t *t, int nt, in
 /* ORBmatcher::ComputeThreeMaxima, ORBmatcher.cc:1866-1908, on bin sizes. */
 void orc_three_maxima(const int32_t *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
 
+/* ---- callers either side of the path ---- */
+/* cv::cvtColor(src, dst, CV_{BGR,RGB}[A]2GRAY), 8-bit (Tracking.cc:308-321): OpenCV 4.x 15-bit coefficients
+ * (RY15 9798, GY15 19235, BY15 3735), dst = (sum + 16384) >> 15.  PARITY UNPINNED (OpenCV primitive). */
+void orc_color_to_gray(const uint8_t *src, size_t sstride, int w, int h, int channels, int rgb_order, uint8_t *dst,
+                       size_t dstride);
+/* Tracking's imDepth.convertTo(CV_32F, factor) on one 16-bit value */
+float orc_depth_convert(uint16_t raw, float factor);
+/* Frame::ComputeStereoFromRGBD (Frame.cc:1576-1615) + PosInGrid cell (Frame.cc:1007-1030), mvKeysUn == mvKeys */
+void orc_rgbd_glue(const amos_keypoint *kps, int n, const float *depth, size_t depth_stride_elems, int w, int h, float mbf,
+                   float min_x, float max_x, float min_y, float max_y, float *u_right, float *depth_out, int32_t *grid_cell);
+
 /* ---- gated searches of the tracking thread, over plain frame views ---- */
 /* Frame::GetFeaturesInArea (Frame.cc:894-1003) on a grid built as Frame::AssignFeaturesToGrid does
  * (Frame.cc:431-461).  Returns the number of indices written. */

@@ -257,3 +257,30 @@ def three_maxima(sizes):
     i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
     lib().orc_three_maxima(_p(sizes), C.c_int(len(sizes)), C.byref(i1), C.byref(i2), C.byref(i3))
     return i1.value, i2.value, i3.value
+
+
+def color_to_gray(img, rgb_order=False):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, c = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_color_to_gray(_p(img), C.c_size_t(img.strides[0]), C.c_int(w), C.c_int(h), C.c_int(c), C.c_int(int(rgb_order)), _p(out),
+                            C.c_size_t(w))
+    return out
+
+
+def depth_convert(raw_u16, factor):
+    f = lib().orc_depth_convert
+    f.restype = C.c_float
+    f.argtypes = [C.c_uint16, C.c_float]
+    return np.array([f(int(v), factor) for v in np.asarray(raw_u16).ravel()], np.float32).reshape(np.shape(raw_u16))
+
+
+def rgbd_glue(kps, depth_f32, mbf, bounds):
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    depth_f32 = np.ascontiguousarray(depth_f32, np.float32)
+    n = len(kps)
+    ur, dep, cell = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+    lib().orc_rgbd_glue(_p(kps), C.c_int(n), _p(depth_f32), C.c_size_t(depth_f32.shape[1]), C.c_int(depth_f32.shape[1]),
+                        C.c_int(depth_f32.shape[0]), C.c_float(mbf), C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]),
+                        C.c_float(bounds[3]), _p(ur), _p(dep), _p(cell))
+    return ur, dep, cell

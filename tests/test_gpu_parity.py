@@ -276,6 +276,45 @@ def test_staged_batch_with_masks(gpu_lib, ob, synth):
         _same(dg, do, f"frame {f} descriptors")
 
 
+@pytest.mark.parametrize("channels,rgb", [(3, False), (3, True), (4, False)])
+def test_color_import_and_rgbd_glue(gpu_lib, ob, synth, channels, rgb):
+    """8f rows: cvtColor fused into the level-0 import, then ComputeStereoFromRGBD + grid cells on the device."""
+    import torch
+    n = 3
+    rng = np.random.default_rng(20 + channels + int(rgb))
+    gray = synth.frames(9, 0, n)
+    color = np.clip(gray[..., None].astype(np.int16) + rng.integers(-40, 40, (n, 480, 640, channels)), 0, 255).astype(np.uint8)
+    raw = rng.integers(0, 30000, (n, 480, 640)).astype(np.uint16)
+    raw[rng.random(raw.shape) < 0.25] = 0
+    factor = float(np.float32(1.0) / np.float32(5000.0))
+    ext = gpu_lib.OrbExtractor(max_batch=n)
+    d_color, d_raw = torch.from_numpy(color).cuda(), torch.from_numpy(raw.view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    ext.extract_batch_device_color(d_color.data_ptr(), 480 * 640 * channels, 640 * channels, 640, 480, n, channels, rgb)
+    _, _, _, cap = ext.batch_results_device()
+    d_ur = torch.zeros((n, cap), dtype=torch.float32, device="cuda")
+    d_dep = torch.zeros_like(d_ur)
+    d_cell = torch.zeros((n, cap), dtype=torch.int32, device="cuda")
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    ext.rgbd_glue_batch_device(d_raw.data_ptr(), True, factor, 480 * 640 * 2, 640 * 2, 40.0, bounds, d_ur.data_ptr(), d_dep.data_ptr(),
+                               d_cell.data_ptr())
+    ext.sync()
+    torch.cuda.synchronize()
+    for f in range(n):
+        g = ob.color_to_gray(color[f], rgb)
+        ko, do = ob.Oracle().extract(g)
+        kg, dg = ext.batch_fetch(f)
+        _same(kg, ko, f"frame {f} keypoints")
+        _same(dg, do, f"frame {f} descriptors")
+        depth = (raw[f].astype(np.float32) * np.float32(factor)).astype(np.float32)
+        ur, dep, cell = ob.rgbd_glue(ko, depth, 40.0, bounds)
+        m = len(ko)
+        _same(d_ur[f, :m].cpu().numpy(), ur, "mvuRight")
+        _same(d_dep[f, :m].cpu().numpy(), dep, "mvDepth")
+        _same(d_cell[f, :m].cpu().numpy(), cell, "grid cell")
+        assert (ur > 0).sum() > m // 2
+
+
 def test_hd_config(gpu_lib, ob, synth):
     """BASELINE.json configs[4] geometry: 1920x1080, 4000 features, 12 levels."""
     img = synth.frame(21, 0, 1080, 1920)

@@ -496,6 +496,43 @@ def test_three_maxima(ob):
     assert ob.three_maxima(h)[:2] == (1, 2)
 
 
+# ------------------------------------------------------------------------------------ callers either side (8f)
+
+
+def test_color_to_gray_definition(ob):
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    b, g, r = (img[..., k].astype(np.int64) for k in range(3))
+    want = ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
+    assert np.array_equal(ob.color_to_gray(img, rgb_order=False), want)
+    assert np.array_equal(ob.color_to_gray(img[..., ::-1], rgb_order=True), want)
+    assert np.array_equal(ob.color_to_gray(np.dstack([img, img[..., :1]]), rgb_order=False), want)  # BGRA: alpha ignored
+    grey = np.repeat(rng.integers(0, 256, (5, 7, 1), dtype=np.uint8), 3, axis=2)
+    assert np.array_equal(ob.color_to_gray(grey), grey[..., 0])  # weights sum to 2^15
+
+
+def test_rgbd_glue_definition(ob):
+    rng = np.random.default_rng(12)
+    n, w, h = 200, 640, 480
+    kps = np.zeros(n, ob.KP_DTYPE)
+    kps["x"], kps["y"] = rng.uniform(0, w - 0.01, n), rng.uniform(0, h - 0.01, n)
+    raw = rng.integers(0, 40000, (h, w)).astype(np.uint16)
+    raw[rng.random((h, w)) < 0.2] = 0
+    factor = np.float32(1.0) / np.float32(5000.0)
+    depth = (raw.astype(np.float32) * factor).astype(np.float32)
+    assert np.array_equal(ob.depth_convert(raw[:3, :5], float(factor)), depth[:3, :5])
+    ur, dep, cell = ob.rgbd_glue(kps, depth, 40.0, (0.0, 640.0, 0.0, 480.0))
+    for i in range(n):
+        d = depth[int(kps["y"][i]), int(kps["x"][i])]
+        if d > 0:
+            assert dep[i] == d and ur[i] == np.float32(kps["x"][i]) - np.float32(40.0) / d
+        else:
+            assert dep[i] == -1 and ur[i] == -1
+        px = int(math.floor(abs(float(np.float32(kps["x"][i]) * np.float32(0.1))) + 0.5))
+        py = int(math.floor(abs(float(np.float32(kps["y"][i]) * np.float32(0.1))) + 0.5))
+        assert cell[i] == (px * 48 + py if px < 64 and py < 48 else -1)
+
+
 # ------------------------------------------------------------------------------------ golden fixtures
 
 
