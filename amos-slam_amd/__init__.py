@@ -27,7 +27,7 @@ EXPORTS = [
     "amos_orb_set_level_keypoints", "amos_orb_level_layout", "amos_orb_fetch_levels", "amos_orb_store_levels", "amos_orb_gate", "amos_orb_closed_mask", "amos_orb_describe",
     "amos_orb_extract", "amos_orb_level_image", "amos_orb_blurred_image", "amos_orb_level_candidates",
     "amos_orb_extract_batch_device", "amos_orb_detect_batch_device", "amos_orb_gate_batch_device",
-    "amos_orb_describe_batch_device", "amos_orb_extract_batch_device_color", "amos_frame_rgbd_glue_batch_device",
+    "amos_orb_describe_batch_device", "amos_orb_extract_batch_device_color", "amos_frame_rgbd_glue_batch_device", "amos_frame_grid_build_batch_device", "amos_match_window_best2_batch_device",
     "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
@@ -288,6 +288,15 @@ class OrbExtractor:
         return self.L.amos_orb_stream(self.h)
 
 
+class WindowSearch(C.Structure):
+    """amos_window_search (include/amos_frontend.h)."""
+    _fields_ = [("d_kps", C.c_void_p), ("d_desc", C.c_void_p), ("d_counts", C.c_void_p), ("d_cell_start", C.c_void_p),
+                ("d_items", C.c_void_p), ("d_query_uv", C.c_void_p), ("d_query_invz", C.c_void_p), ("d_u_right", C.c_void_p),
+                ("d_pairs_q", C.c_void_p), ("d_pairs_t", C.c_void_p), ("scale_factors", C.c_void_p), ("n_pairs", C.c_int32),
+                ("capacity", C.c_int32), ("n_levels", C.c_int32), ("mode", C.c_int32), ("init_dist", C.c_int32), ("th", C.c_float),
+                ("mbf", C.c_float), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
+
+
 class OrbMatcher:
     """The distance / best-two primitives every ORBmatcher::Search* inner loop reduces to
     (ORBmatcher.cc:1913-1933 and the candidate loops at :127-148, :278-304, :560-580, :1644-1690)."""
@@ -348,6 +357,22 @@ class OrbMatcher:
             self.m, C.c_void_p(d_desc), C.c_size_t(frame_stride_bytes), C.c_void_p(d_counts), C.c_void_p(d_pairs_q),
             C.c_void_p(d_pairs_t), C.c_int(n_pairs), C.c_int(capacity), C.c_int(init_dist), C.c_void_p(d_out)),
             "amos_match_bruteforce_best2_batch_device")
+
+    def grid_build_batch_device(self, d_grid_cell, d_counts, n_frames, capacity, d_cell_start, d_items):
+        """Frame::AssignFeaturesToGrid for a resident batch (Frame.cc:431-461)."""
+        _check(self.L.amos_frame_grid_build_batch_device(self.m, C.c_void_p(d_grid_cell), C.c_void_p(d_counts), C.c_int(n_frames),
+                                                         C.c_int(capacity), C.c_void_p(d_cell_start), C.c_void_p(d_items)),
+               "amos_frame_grid_build_batch_device")
+
+    def window_best2_batch_device(self, d_kps, d_desc, d_counts, d_cell_start, d_items, d_pairs_q, d_pairs_t, n_pairs, capacity,
+                                  scale_factors, th, d_out, mode=0, init_dist=256, bounds=(0.0, 640.0, 0.0, 480.0), d_query_uv=None,
+                                  d_query_invz=None, d_u_right=None, mbf=0.0):
+        """GetFeaturesInArea + best/second loop of SearchByProjection(F, LastF) (Frame.cc:894-1003, ORBmatcher.cc:1629-1690)."""
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        w = WindowSearch(d_kps, d_desc, d_counts, d_cell_start, d_items, d_query_uv, d_query_invz, d_u_right, d_pairs_q, d_pairs_t,
+                         sf.ctypes.data, n_pairs, capacity, len(sf), mode, init_dist, th, mbf, *bounds)
+        _check(self.L.amos_match_window_best2_batch_device(self.m, C.byref(w), C.c_void_p(d_out)),
+               "amos_match_window_best2_batch_device")
 
     def sync(self):
         _check(self.L.amos_match_sync(self.m), "amos_match_sync")

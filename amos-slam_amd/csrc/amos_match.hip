@@ -121,6 +121,144 @@ __global__ __launch_bounds__(256) void k_list_best2(const uint8_t *__restrict__ 
     }
 }
 
+// ---- Frame::AssignFeaturesToGrid (Frame.cc:431-461) for a batch: one work-group per frame turns the
+// per-keypoint cell numbers (k_rgbd_glue) into CSR lists, ascending keypoint index inside a cell (the
+// reference push_back()s in index order).  Counting by LDS atomics, exclusive scan of the 3072
+// counts, unordered fill, then each thread insertion-sorts the (tiny) lists of its 12 cells.
+constexpr int kGridCells = AMOS_FRAME_GRID_COLS * AMOS_FRAME_GRID_ROWS;
+
+__global__ __launch_bounds__(256) void k_grid_build(const int *__restrict__ cell, const int *__restrict__ counts, int capacity,
+                                                   int *__restrict__ cellStart, int *__restrict__ items)
+{
+    __shared__ int cnt[kGridCells], part[256];
+    const int tid = threadIdx.x, frame = blockIdx.x;
+    const int n = min(counts[frame], capacity);
+    cell += (size_t)frame * capacity;
+    items += (size_t)frame * capacity;
+    cellStart += (size_t)frame * (kGridCells + 1);
+    for (int c = tid; c < kGridCells; c += 256) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int c = cell[i];
+        if (c >= 0) atomicAdd(&cnt[c], 1);
+    }
+    __syncthreads();
+    constexpr int kPer = kGridCells / 256;  // 12 consecutive cells per thread
+    int local[kPer], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) { local[k] = cnt[tid * kPer + k]; sum += local[k]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int base = part[tid] - sum;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        cellStart[tid * kPer + k] = base;
+        cnt[tid * kPer + k] = base;  // becomes the fill cursor
+        base += local[k];
+    }
+    if (tid == 255) cellStart[kGridCells] = base;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int c = cell[i];
+        if (c >= 0) items[atomicAdd(&cnt[c], 1)] = i;
+    }
+    __syncthreads();
+    __threadfence_block();
+    base = part[tid] - sum;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        for (int a = base + 1; a < base + local[k]; a++) {
+            const int v = items[a];
+            int b = a - 1;
+            while (b >= base && items[b] > v) { items[b + 1] = items[b]; b--; }
+            items[b + 1] = v;
+        }
+        base += local[k];
+    }
+}
+
+// ---- Frame::GetFeaturesInArea (Frame.cc:894-1003) + the best / second-best loop of
+// ORBmatcher::SearchByProjection(F, LastF) (ORBmatcher.cc:1645-1690) for a batch of (query frame,
+// train frame) pairs, everything resident.  One thread per query keypoint: window of radius
+// th * scaleFactor[octave] around its (projected) position, cells x-major then y, items in insertion
+// order, level gate by mode (0: octave-1..octave+1, 1 forward: >= octave, 2 backward: <= octave),
+// optional right-coordinate gate; first candidate wins ties (strict <).  The greedy "already matched"
+// skip of the reference stays with the caller: the unrestricted best is also the
+// restricted best whenever it is free.
+struct WindowArgs {
+    const amos_keypoint *kps;   // [frames][capacity]
+    const uint8_t *desc;        // [frames][capacity][32]
+    const int *counts;
+    const int *cellStart;       // [frames][3073]
+    const int *items;           // [frames][capacity]
+    const float *queryUv;       // [pairs][capacity][2] or null: the query keypoint's own position
+    const float *queryInvZ;     // [pairs][capacity] or null
+    const float *uRight;        // [frames][capacity] or null
+    const int *pairsQ, *pairsT;
+    float scale[AMOS_MAX_LEVELS];
+    float th, mbf, minX, minY, wInv, hInv;
+    int capacity, mode, initDist;
+};
+
+__global__ __launch_bounds__(256) void k_window_best2(const WindowArgs a, amos_best2 *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, pair = blockIdx.y;
+    const int fq = a.pairsQ[pair], ft = a.pairsT[pair];
+    if (i >= min(a.counts[fq], a.capacity)) return;
+    const amos_keypoint qk = a.kps[(size_t)fq * a.capacity + i];
+    const Desc qd = load_desc(a.desc + ((size_t)fq * a.capacity + i) * 32);
+    const size_t po = (size_t)pair * a.capacity + i;
+    const float u = a.queryUv ? a.queryUv[2 * po] : qk.x, v = a.queryUv ? a.queryUv[2 * po + 1] : qk.y;
+    const int oct = qk.octave;
+    const float r = __fmul_rn(a.th, a.scale[oct]);
+    const int minLevel = a.mode == 1 ? oct : a.mode == 2 ? 0 : oct - 1;
+    const int maxLevel = a.mode == 1 ? -1 : a.mode == 2 ? oct : oct + 1;
+    const bool checkLevels = minLevel > 0 || maxLevel >= 0;
+    const bool gateRight = a.uRight != nullptr && a.queryInvZ != nullptr;
+    const float ur = gateRight ? __fsub_rn(u, __fmul_rn(a.mbf, a.queryInvZ[po])) : 0.f;
+    amos_best2 res = {-1, a.initDist, -1, a.initDist};
+    int x0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(u, a.minX), r), a.wInv));
+    int x1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(u, a.minX), r), a.wInv));
+    int y0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(v, a.minY), r), a.hInv));
+    int y1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(v, a.minY), r), a.hInv));
+    x0 = max(x0, 0); y0 = max(y0, 0);
+    x1 = min(x1, AMOS_FRAME_GRID_COLS - 1); y1 = min(y1, AMOS_FRAME_GRID_ROWS - 1);
+    // (the reference's early returns for an empty clamp range are the empty loops below)
+    const int *cs = a.cellStart + (size_t)ft * (kGridCells + 1);
+    const int *it = a.items + (size_t)ft * a.capacity;
+    const amos_keypoint *tk = a.kps + (size_t)ft * a.capacity;
+    const uint8_t *td = a.desc + (size_t)ft * a.capacity * 32;
+    const float *tr = gateRight ? a.uRight + (size_t)ft * a.capacity : nullptr;
+    for (int ix = x0; ix <= x1; ix++) {
+        // cells (ix, y0..y1) are consecutive in the CSR: one item range per column
+        const int b = cs[ix * AMOS_FRAME_GRID_ROWS + y0], e = y1 >= y0 ? cs[ix * AMOS_FRAME_GRID_ROWS + y1 + 1] : b;
+        for (int j = b; j < e; j++) {
+            const int idx = it[j];
+            const amos_keypoint k = tk[idx];
+            if (checkLevels && (k.octave < minLevel || (maxLevel >= 0 && k.octave > maxLevel))) continue;
+            if (!(fabsf(__fsub_rn(k.x, u)) < r && fabsf(__fsub_rn(k.y, v)) < r)) continue;
+            if (gateRight) {
+                const float t = tr[idx];
+                if (t > 0 && fabsf(__fsub_rn(ur, t)) > r) continue;
+            }
+            const int d = hamming256(qd, load_desc(td + (size_t)idx * 32));
+            if (d < res.best_dist) {
+                res.second_dist = res.best_dist; res.second_idx = res.best_idx;
+                res.best_dist = d; res.best_idx = idx;
+            } else if (d < res.second_dist) {
+                res.second_dist = d; res.second_idx = idx;
+            }
+        }
+    }
+    out[po] = res;
+}
+
 // ---- brute-force best / second best over ALL train descriptors, for a batch of (query set,
 // train set) pairs.  Block = 64 queries x 4 waves; wave w scans the w-th quarter of the train set
 // from LDS tiles (every lane reads the same descriptor: LDS broadcast), the four partial top-2s are
@@ -395,6 +533,41 @@ int amos_match_bruteforce_best2_batch_device(amos_match *m, const uint8_t *d_des
     else
         hipLaunchKernelGGL(k_bf_best2<true>, dim3((capacity + 63) / 64, n_pairs), dim3(256), 0, m->stream, d_desc, d_desc, frame_stride_bytes,
                            d_counts, d_pairs_q, d_pairs_t, 0, 0, capacity, init_dist, d_out);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_frame_grid_build_batch_device(amos_match *m, const int32_t *d_grid_cell, const int32_t *d_counts, int n_frames, int capacity,
+                                       int32_t *d_cell_start, int32_t *d_items)
+{
+    if (!m || !d_grid_cell || !d_counts || !d_cell_start || !d_items || n_frames < 1 || capacity < 1) {
+        set_error("amos_frame_grid_build_batch_device: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    AMOS_HIP_CHECK(hipSetDevice(m->device));
+    hipLaunchKernelGGL(k_grid_build, dim3(n_frames), dim3(256), 0, m->stream, d_grid_cell, d_counts, capacity, d_cell_start, d_items);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_match_window_best2_batch_device(amos_match *m, const amos_window_search *w, amos_best2 *d_out)
+{
+    if (!m || !w || !d_out || !w->d_kps || !w->d_desc || !w->d_counts || !w->d_cell_start || !w->d_items || !w->d_pairs_q ||
+        !w->d_pairs_t || w->n_pairs < 1 || w->capacity < 1 || w->n_levels < 1 || w->n_levels > AMOS_MAX_LEVELS || !w->scale_factors ||
+        !(w->max_x > w->min_x) || !(w->max_y > w->min_y) || w->mode < 0 || w->mode > 2 || !(w->th > 0)) {
+        set_error("amos_match_window_best2_batch_device: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    AMOS_HIP_CHECK(hipSetDevice(m->device));
+    WindowArgs a;
+    a.kps = w->d_kps; a.desc = w->d_desc; a.counts = w->d_counts; a.cellStart = w->d_cell_start; a.items = w->d_items;
+    a.queryUv = w->d_query_uv; a.queryInvZ = w->d_query_invz; a.uRight = w->d_u_right; a.pairsQ = w->d_pairs_q; a.pairsT = w->d_pairs_t;
+    for (int l = 0; l < AMOS_MAX_LEVELS; l++) a.scale[l] = l < w->n_levels ? w->scale_factors[l] : 0.f;
+    a.th = w->th; a.mbf = w->mbf; a.minX = w->min_x; a.minY = w->min_y;
+    a.wInv = static_cast<float>(AMOS_FRAME_GRID_COLS) / static_cast<float>(w->max_x - w->min_x);  // Frame.cc:302-303
+    a.hInv = static_cast<float>(AMOS_FRAME_GRID_ROWS) / static_cast<float>(w->max_y - w->min_y);
+    a.capacity = w->capacity; a.mode = w->mode; a.initDist = w->init_dist;
+    hipLaunchKernelGGL(k_window_best2, dim3((w->capacity + 255) / 256, w->n_pairs), dim3(256), 0, m->stream, a, d_out);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }

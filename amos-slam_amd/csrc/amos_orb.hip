@@ -844,7 +844,7 @@ int amos_frame_rgbd_glue_batch_device(amos_orb *h, const void *d_depth, int dept
                                       size_t depth_frame_stride_bytes, size_t depth_row_stride_bytes, float mbf, float min_x, float max_x,
                                       float min_y, float max_y, float *d_u_right, float *d_depth_out, int32_t *d_grid_cell)
 {
-    if (!h || !d_depth || !d_u_right || !d_depth_out || !d_grid_cell || !(max_x > min_x) || !(max_y > min_y)) { set_error("amos_frame_rgbd_glue_batch_device: invalid argument"); return AMOS_ERR_INVALID; }
+    if (!h || !d_grid_cell || (d_depth && (!d_u_right || !d_depth_out)) || !(max_x > min_x) || !(max_y > min_y)) { set_error("amos_frame_rgbd_glue_batch_device: invalid argument"); return AMOS_ERR_INVALID; }
     if (!h->described) { set_error("amos_frame_rgbd_glue_batch_device before an extraction"); return AMOS_ERR_STATE; }
     AMOS_HIP_CHECK(hipSetDevice(h->device));
     const float wInv = static_cast<float>(AMOS_FRAME_GRID_COLS) / static_cast<float>(max_x - min_x);  // Frame.cc:302-303

@@ -1278,14 +1278,14 @@ __global__ __launch_bounds__(256) void k_rgbd_glue(const Geom *__restrict__ g, c
     const amos_keypoint kp = outKps[o];
     const int u = (int)kp.x, v = (int)kp.y;  // imDepth.at<float>(v, u) with float arguments
     float d = -1.f;
-    if (u >= 0 && v >= 0 && u < g->W && v < g->H) {
+    if (depth != nullptr && u >= 0 && v >= 0 && u < g->W && v < g->H) {
         const uint8_t *row = depth + (size_t)frame * depthFrameStride + (size_t)v * depthRowStride;
         d = depthIsU16 ? __fmul_rn((float)reinterpret_cast<const uint16_t *>(row)[u], depthFactor)
                        : reinterpret_cast<const float *>(row)[u];
     }
     const bool ok = d > 0;
-    depthOut[o] = ok ? d : -1.f;
-    uRight[o] = ok ? __fsub_rn(kp.x, __fdiv_rn(mbf, d)) : -1.f;
+    if (depthOut) depthOut[o] = ok ? d : -1.f;
+    if (uRight) uRight[o] = ok ? __fsub_rn(kp.x, __fdiv_rn(mbf, d)) : -1.f;
     const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, minX), gridWInv));
     const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, minY), gridHInv));
     gridCell[o] = (px < 0 || px >= AMOS_FRAME_GRID_COLS || py < 0 || py >= AMOS_FRAME_GRID_ROWS) ? -1 : px * AMOS_FRAME_GRID_ROWS + py;

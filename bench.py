@@ -237,6 +237,45 @@ def main():
     # the one collective of the path: final gather of the per-rank digests
     digest_all = shard.gather_digests([float(sum(n_kp)), float(good)], f"cuda:{local_rank}")
 
+    # SURVEY 8d match workload (ii): window-gated search (SearchByProjection radius 15 * scale, levels
+    # octave-1..octave+1) of frame k's keypoints in frame k-1, everything resident: grid cells, CSR grid,
+    # window best-2.  Measured after the timed region on lane 0; not part of `value`.
+    gated = None
+    if not use_mask:
+        ln = lanes[0]
+        dev = f"cuda:{local_rank}"
+        d_kps = ln.ext.batch_results_device()[0]
+        d_cell = torch.zeros((Bl, ln.cap), dtype=torch.int32, device=dev)
+        d_start = torch.zeros((Bl, 64 * 48 + 1), dtype=torch.int32, device=dev)
+        d_items = torch.zeros((Bl, ln.cap), dtype=torch.int32, device=dev)
+        d_win = torch.zeros((Bl, ln.cap, 4), dtype=torch.int32, device=dev)
+        bounds = (0.0, float(W), 0.0, float(H))
+        sf = ln.ext.tables()["scale"]
+        torch.cuda.synchronize()
+        evs = []
+        for it in range(6):
+            with torch.cuda.stream(ln.stream):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                ev[0].record(ln.stream)
+                ln.ext.rgbd_glue_batch_device(None, False, 1.0, 0, 0, 0.0, bounds, None, None, d_cell.data_ptr())
+                ev[1].record(ln.stream)
+                ln.matcher.grid_build_batch_device(d_cell.data_ptr(), ln.d_counts, Bl, ln.cap, d_start.data_ptr(), d_items.data_ptr())
+                ev[2].record(ln.stream)
+                ln.matcher.window_best2_batch_device(d_kps, ln.d_desc, ln.d_counts, d_start.data_ptr(), d_items.data_ptr(),
+                                                     ln.pairs_q.data_ptr(), ln.pairs_t.data_ptr(), Bl, ln.cap, sf, 15.0, d_win.data_ptr(),
+                                                     mode=0, bounds=bounds)
+                ev[3].record(ln.stream)
+            if it > 0:
+                evs.append(ev)
+        ln.ext.sync()
+        torch.cuda.synchronize()
+        g_ms = [float(np.mean([e[k].elapsed_time(e[k + 1]) for e in evs])) for k in range(3)]
+        nq = mean_kp * Bl
+        gated = {"workload": "frame k keypoints searched in frame k-1: window 15*scale, levels octave-1..octave+1, best-2",
+                 "frames_per_launch": Bl, "grid_cells_ms": round(g_ms[0], 4), "grid_build_ms": round(g_ms[1], 4),
+                 "window_best2_ms": round(g_ms[2], 4), "queries_per_s": round(nq / (sum(g_ms) * 1e-3), 1),
+                 "matched_within_TH_HIGH": int((d_win[:, :, 1] <= 100).sum().item())}
+
     if args.check and rank == 0:
         import oracle_binding as ob
         orc = ob.Oracle(n_features=cfg["n_features"], n_levels=cfg["n_levels"])
@@ -298,6 +337,8 @@ def main():
                                        for k, v in stage_ms.items()},
             "digest_per_rank": digest_all,
         }
+        if gated:
+            out["gated_match"] = gated
         n_cpu = args.cpu_frames if args.cpu_frames >= 0 else (100 if args.config == "c2" else 12)
         if world == 1 and n_cpu > 0:
             out["cpu_baseline"] = cpu_baseline(synth, cfg, n_cpu)
@@ -310,4 +351,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as exc:  # a failed rank must not sit in the process group's teardown
+        if isinstance(exc, SystemExit) and exc.code in (0, None):
+            raise
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

@@ -43,6 +43,8 @@ extern "C" {
 
 #define AMOS_EDGE_THRESHOLD 19  /* border of every pyramid plane, ORBextractor.cc:93             */
 #define AMOS_MAX_LEVELS 16
+#define AMOS_FRAME_GRID_ROWS 48 /* Frame.h:56 */
+#define AMOS_FRAME_GRID_COLS 64 /* Frame.h:61 */
 #define AMOS_TH_HIGH 100        /* ORBmatcher.cc:49 */
 #define AMOS_TH_LOW 50          /* ORBmatcher.cc:50 */
 #define AMOS_HISTO_LENGTH 30    /* ORBmatcher.cc:51 */
@@ -233,6 +235,45 @@ int amos_match_bruteforce_best2_batch_device(amos_match *m, const uint8_t *d_des
                                              const int32_t *d_pairs_q, const int32_t *d_pairs_t,
                                              int n_pairs, int capacity, int init_dist,
                                              amos_best2 *d_out);
+
+/* ---------------------------------------------------------------- resident search (8f-1) ---- */
+
+/* Frame::AssignFeaturesToGrid (Frame.cc:431-461) for a batch on the device.  d_grid_cell is the
+ * per-keypoint cell number written by amos_frame_rgbd_glue_batch_device ([n_frames][capacity], -1 =
+ * outside the grid); d_counts the keypoint counts.  Output, per frame: CSR d_cell_start
+ * [64*48 + 1] (cell = x * 48 + y, as mGrid[x][y]) and d_items [capacity] holding keypoint indices,
+ * ascending inside a cell (the reference's push_back order).  Asynchronous on the matcher's stream. */
+int amos_frame_grid_build_batch_device(amos_match *m, const int32_t *d_grid_cell, const int32_t *d_counts,
+                                       int n_frames, int capacity, int32_t *d_cell_start,
+                                       int32_t *d_items);
+
+/* Frame::GetFeaturesInArea (Frame.cc:894-1003) + the best / second-best candidate loop of
+ * ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1629-1690) for a
+ * batch of (query frame, train frame) pairs of resident extraction results.  Query i of pair p is
+ * keypoint i of frame d_pairs_q[p]; it is searched in frame d_pairs_t[p] around d_query_uv[p][i]
+ * (its own position when d_query_uv is NULL) with radius th * scale_factors[octave] and the level
+ * window of mode (0: octave-1..octave+1, 1 = bForward: >= octave, 2 = bBackward: <= octave).  With
+ * d_u_right and d_query_invz the stereo gate |u - mbf*invz - uRight[i2]| > radius rejects (:1662-1669).
+ * d_out[p][i] = best / second best in candidate order under "dist < init_dist" (256 in the reference).
+ * The greedy skip of already-matched features (:1658-1660) is the caller's: the unrestricted best
+ * equals the restricted best whenever it is still free. */
+typedef struct amos_window_search {
+    const amos_keypoint *d_kps;   /* [frames][capacity]      (amos_orb_batch_results_device) */
+    const uint8_t *d_desc;        /* [frames][capacity][32] */
+    const int32_t *d_counts;      /* [frames] */
+    const int32_t *d_cell_start;  /* [frames][64*48+1]       (amos_frame_grid_build_batch_device) */
+    const int32_t *d_items;       /* [frames][capacity] */
+    const float *d_query_uv;      /* [n_pairs][capacity][2] or NULL */
+    const float *d_query_invz;    /* [n_pairs][capacity] or NULL */
+    const float *d_u_right;       /* [frames][capacity] or NULL */
+    const int32_t *d_pairs_q, *d_pairs_t; /* [n_pairs] */
+    const float *scale_factors;   /* host, n_levels entries (mvScaleFactors) */
+    int32_t n_pairs, capacity, n_levels;
+    int32_t mode, init_dist;
+    float th, mbf;
+    float min_x, max_x, min_y, max_y; /* Frame::mnMinX .. mnMaxY */
+} amos_window_search;
+int amos_match_window_best2_batch_device(amos_match *m, const amos_window_search *w, amos_best2 *d_out);
 
 #ifdef __cplusplus
 }

@@ -15,8 +15,7 @@
 extern "C" {
 #endif
 
-#define AMOS_FRAME_GRID_ROWS 48 /* Frame.h:56 */
-#define AMOS_FRAME_GRID_COLS 64 /* Frame.h:61 */
+/* AMOS_FRAME_GRID_ROWS (48) and AMOS_FRAME_GRID_COLS (64) come from amos_frontend.h (Frame.h:56,61). */
 
 /* What a search reads of the frame it searches IN (Frame::mvKeysUn, mDescriptors, mvuRight, the
  * undistorted image bounds mnMinX.. and the 64x48 feature grid built from them). */

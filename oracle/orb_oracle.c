@@ -1327,3 +1327,39 @@ void orc_rgbd_glue(const amos_keypoint *kps, int n, const float *depth, size_t d
         grid_cell[i] = (px < 0 || px >= AMOS_FRAME_GRID_COLS || py < 0 || py >= AMOS_FRAME_GRID_ROWS) ? -1 : px * AMOS_FRAME_GRID_ROWS + py;
     }
 }
+
+/* Checker of amos_match_window_best2_batch_device: Frame::GetFeaturesInArea (Frame.cc:894-1003) feeding
+ * the best / second-best loop of ORBmatcher::SearchByProjection(F, LastF) (ORBmatcher.cc:1629-1690)
+ * WITHOUT the greedy already-matched skip (which the caller resolves).  query_uv / query_invz may be
+ * NULL (own position; no stereo gate). */
+void orc_window_best2(const amos_frame_view *train, const amos_keypoint *qk, const uint8_t *qdesc, int nq, const float *query_uv,
+                      const float *query_invz, const float *scale_factors, float th, float mbf, int mode, int init_dist,
+                      amos_best2 *out)
+{
+    ogrid g = grid_build(train);
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (train->n + 1));
+    for (int i = 0; i < nq; i++) {
+        const float u = query_uv ? query_uv[2 * i] : qk[i].x, v = query_uv ? query_uv[2 * i + 1] : qk[i].y;
+        const int oct = qk[i].octave;
+        const float radius = th * scale_factors[oct];
+        int nc;
+        if (mode == 1) nc = grid_area(&g, train, u, v, radius, oct, -1, cand, train->n);
+        else if (mode == 2) nc = grid_area(&g, train, u, v, radius, 0, oct, cand, train->n);
+        else nc = grid_area(&g, train, u, v, radius, oct - 1, oct + 1, cand, train->n);
+        amos_best2 r = {-1, init_dist, -1, init_dist};
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            if (query_invz && train->u_right && train->u_right[i2] > 0) {
+                const float ur = u - mbf * query_invz[i];
+                const float er = fabsf(ur - train->u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int d = orc_descriptor_distance(qdesc + (size_t)i * 32, train->descriptors + (size_t)i2 * 32);
+            if (d < r.best_dist) { r.second_dist = r.best_dist; r.second_idx = r.best_idx; r.best_dist = d; r.best_idx = i2; }
+            else if (d < r.second_dist) { r.second_dist = d; r.second_idx = i2; }
+        }
+        out[i] = r;
+    }
+    free(cand);
+    grid_free(&g);
+}

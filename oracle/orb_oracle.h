@@ -117,6 +117,10 @@ int orc_search_by_projection_points(const amos_frame_view *f, const amos_map_que
 int orc_search_for_initialization(const amos_frame_view *f1, const amos_frame_view *f2, float *prev_matched,
                                   int32_t *matches12, int window_size, float nn_ratio, int check_orientation);
 
+void orc_window_best2(const amos_frame_view *train, const amos_keypoint *qk, const uint8_t *qdesc, int nq, const float *query_uv,
+                      const float *query_invz, const float *scale_factors, float th, float mbf, int mode, int init_dist,
+                      amos_best2 *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,18 @@ def frame_view(kps, desc, u_right=None, bounds=(0.0, 640.0, 0.0, 480.0)):
     return v, (kps, desc, ur)
 
 
+def window_best2(train_view, qk, qdesc, scale_factors, th, mode=0, init_dist=256, query_uv=None, query_invz=None, mbf=0.0):
+    """oracle: GetFeaturesInArea + best/second loop without the greedy skip (orc_window_best2)."""
+    qk, qdesc = np.ascontiguousarray(qk, KP), np.ascontiguousarray(qdesc, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    uv = None if query_uv is None else np.ascontiguousarray(query_uv, np.float32)
+    iz = None if query_invz is None else np.ascontiguousarray(query_invz, np.float32)
+    out = np.zeros(len(qk), ob.BEST2_DTYPE)
+    ob.lib().orc_window_best2(C.byref(train_view), _p(qk), _p(qdesc), C.c_int(len(qk)), _p(uv), _p(iz), _p(sf), C.c_float(th), C.c_float(mbf),
+                              C.c_int(mode), C.c_int(init_dist), _p(out))
+    return out
+
+
 _host = None
 
 

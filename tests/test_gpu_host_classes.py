@@ -152,3 +152,71 @@ def test_search_for_initialization(hb, ob, synth):
         assert rh == ro and np.array_equal(mh, mo) and np.array_equal(ph, po)
     assert rh > 30
     assert (mh[k0["octave"] > 0] == -1).all()  # only level-0 features take part
+
+
+@pytest.mark.parametrize("mode,stereo,shifted", [(0, False, False), (0, True, True), (1, False, True), (2, True, False)])
+def test_resident_grid_and_window_search(gpu_lib, ob, synth, mode, stereo, shifted):
+    """8f-1: AssignFeaturesToGrid + GetFeaturesInArea + best/second loop on resident batch results."""
+    import torch
+    import host_binding as hb
+    n, bounds, mbf, th = 4, (0.0, 640.0, 0.0, 480.0), 40.0, 15.0
+    rng = np.random.default_rng(77 + mode)
+    frames = synth.frames(5, 0, n)
+    depth = (1.0 + 2.0 * rng.random((n, 480, 640))).astype(np.float32)
+    depth[rng.random(depth.shape) < 0.2] = 0
+    ext = gpu_lib.OrbExtractor(max_batch=n)
+    d_frames, d_depth = torch.from_numpy(frames).cuda(), torch.from_numpy(depth).cuda()
+    torch.cuda.synchronize()
+    ext.extract_batch_device(d_frames.data_ptr(), 480 * 640, 640, 640, 480, n)
+    d_kps, d_desc, d_counts, cap = ext.batch_results_device()
+    d_ur = torch.zeros((n, cap), dtype=torch.float32, device="cuda")
+    d_dep = torch.zeros_like(d_ur)
+    d_cell = torch.zeros((n, cap), dtype=torch.int32, device="cuda")
+    ext.rgbd_glue_batch_device(d_depth.data_ptr(), False, 1.0, 480 * 640 * 4, 640 * 4, mbf, bounds, d_ur.data_ptr(), d_dep.data_ptr(),
+                               d_cell.data_ptr())
+    ext.sync()
+    mt = gpu_lib.OrbMatcher()
+    d_start = torch.zeros((n, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    d_items = torch.full((n, cap), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    mt.grid_build_batch_device(d_cell.data_ptr(), d_counts, n, cap, d_start.data_ptr(), d_items.data_ptr())
+    pq = torch.arange(0, n - 1, dtype=torch.int32, device="cuda")
+    pt = torch.arange(1, n, dtype=torch.int32, device="cuda")
+    uv = rng.uniform(-30, 700, (n - 1, cap, 2)).astype(np.float32) if shifted else None
+    host = [ext.batch_fetch(f) for f in range(n)]
+    if shifted:  # most queries near their own position, a few far outside the image
+        for p in range(n - 1):
+            m = len(host[p][0])
+            near = rng.random(m) < 0.9
+            uv[p, :m, 0] = np.where(near, host[p][0]["x"] + rng.uniform(-6, 6, m).astype(np.float32), uv[p, :m, 0])
+            uv[p, :m, 1] = np.where(near, host[p][0]["y"] + rng.uniform(-6, 6, m).astype(np.float32), uv[p, :m, 1])
+    invz = (1.0 / (1.0 + 2.0 * rng.random((n - 1, cap)))).astype(np.float32) if stereo else None
+    d_uv = torch.from_numpy(uv).cuda() if shifted else None
+    d_invz = torch.from_numpy(invz).cuda() if stereo else None
+    d_out = torch.zeros((n - 1, cap, 4), dtype=torch.int32, device="cuda")
+    sf = ext.tables()["scale"]
+    torch.cuda.synchronize()
+    mt.window_best2_batch_device(d_kps, d_desc, d_counts, d_start.data_ptr(), d_items.data_ptr(), pq.data_ptr(), pt.data_ptr(), n - 1, cap, sf,
+                                 th, d_out.data_ptr(), mode=mode, bounds=bounds, d_query_uv=d_uv.data_ptr() if shifted else None,
+                                 d_query_invz=d_invz.data_ptr() if stereo else None, d_u_right=d_ur.data_ptr() if stereo else None, mbf=mbf)
+    mt.sync()
+    torch.cuda.synchronize()
+    out, start, items, cell, ur = d_out.cpu().numpy(), d_start.cpu().numpy(), d_items.cpu().numpy(), d_cell.cpu().numpy(), d_ur.cpu().numpy()
+    nfound = 0
+    for f in range(n):  # the CSR itself: every keypoint in its cell, ascending inside a cell
+        m = len(host[f][0])
+        assert start[f, -1] == (cell[f, :m] >= 0).sum()
+        for c in np.unique(cell[f, :m]):
+            if c >= 0:
+                assert np.array_equal(items[f, start[f, c]:start[f, c + 1]], np.nonzero(cell[f, :m] == c)[0])
+    for p in range(n - 1):
+        qk, qd = host[p]
+        tk, td = host[p + 1]
+        view, keep = hb.frame_view(tk, td, ur[p + 1, :len(tk)] if stereo else None, bounds)
+        want = hb.window_best2(view, qk, qd, sf, th, mode=mode, query_uv=uv[p, :len(qk)] if shifted else None,
+                               query_invz=invz[p, :len(qk)] if stereo else None, mbf=mbf)
+        got = out[p, :len(qk)]
+        for k, name in enumerate(("best_idx", "best_dist", "second_idx", "second_dist")):
+            assert np.array_equal(got[:, k], want[name]), (p, name)
+        nfound += int((want["best_idx"] >= 0).sum())
+    assert nfound > 500
