@@ -323,13 +323,17 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
         const LevelGeom &lg = g.lv[l];
         const int groups = (kPadLeft + lg.w + kEdge + 3) / 4;
         dim3 grid((groups + 63) / 64, (lg.h + 2 * kEdge + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames), block(64, 4);
-        const int srcAligned = ((uintptr_t)dSrc % 4 == 0) && (frameStride % 4 == 0) && (rowStride % 4 == 0);
         if (l == 0 && channels > 1)
             hipLaunchKernelGGL(k_pyramid_level0_color, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, channels, rgbOrder);
-        else if (l == 0)
-            hipLaunchKernelGGL(k_pyramid_level0, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, srcAligned);
+        else if (l == 0) {
+            const int pieces = (kPadLeft + lg.w + kEdge + 15) / 16, chunks = (lg.h + 2 * kEdge + kImportRows - 1) / kImportRows;
+            hipLaunchKernelGGL(k_pyramid_level0_wide, dim3((pieces * chunks + 255) / 256, 1, nFrames), dim3(256), 0, h->stream, dSrc, frameStride,
+                               rowStride, h->dPyr, h->dGeom);
+        }
+        else if (h->p.scale_factor < 1.99f)  // the four taps of a thread fit one 8-byte window
+            hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);
         else
-            hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);
+            hipLaunchKernelGGL(k_pyramid_level<false>, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);
         if (ev && l == 0) (void)hipEventRecord(ev[1], h->stream);
     }
     if (ev) (void)hipEventRecord(ev[2], h->stream);

@@ -59,7 +59,7 @@ __device__ __forceinline__ uint8_t *level_origin(uint8_t *pyr, const Geom *g, in
 // reflect-101 source coordinate (the host-built tap tables are indexed by padded
 // coordinate with the reflection folded in).
 // grid = (ceil(groups/64), ceil((h+38)/4), frames), block = (64, 4).
-constexpr int kPyrRows = 4;  // padded rows per thread (x taps are loaded once, row loads overlap)
+constexpr int kPyrRows = 8;  // padded rows per thread (x taps are loaded once; consecutive rows share source rows)
 
 __global__ __launch_bounds__(256) void k_pyramid_level0(const uint8_t *__restrict__ src, size_t srcFrameStride,
                                                        size_t srcRowStride, uint8_t *__restrict__ pyr,
@@ -94,6 +94,57 @@ __global__ __launch_bounds__(256) void k_pyramid_level0(const uint8_t *__restric
             packed = (uint32_t)s[xi[0]] | ((uint32_t)s[xi[1]] << 8) | ((uint32_t)s[xi[2]] << 16) | ((uint32_t)s[xi[3]] << 24);
         }
         *reinterpret_cast<uint32_t *>(plane + __mul24(yo, lg.stride) + x0) = packed;
+    }
+}
+
+// Level 0, 16 bytes per lane.  A thread owns 16 consecutive bytes of the PADDED plane (column
+// -32 + 16 g) for kImportRows rows: interior pieces are one dwordx4 load (any source alignment) and
+// one aligned dwordx4 store; pieces touching the border gather byte by byte through reflect-101.
+// grid = (ceil(pieces * rowChunks / 256), 1, frames), 1-D thread -> (row chunk, piece).
+constexpr int kImportRows = 4;
+
+__global__ __launch_bounds__(256) void k_pyramid_level0_wide(const uint8_t *__restrict__ src, size_t srcFrameStride,
+                                                            size_t srcRowStride, uint8_t *__restrict__ pyr,
+                                                            const Geom *__restrict__ g)
+{
+    const LevelGeom &lg = g->lv[0];
+    const int frame = blockIdx.z;
+    const int pieces = (kPadLeft + lg.w + kEdge + 15) >> 4;  // stride is a multiple of 128: whole pieces fit
+    const int nrows = lg.h + 2 * kEdge;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int chunk = t / pieces, piece = t - chunk * pieces;
+    const int row0 = chunk * kImportRows;
+    if (row0 >= nrows) return;
+    const int x0 = piece * 16 - kPadLeft;
+    const bool interior = x0 >= 0 && x0 + 15 < lg.w;
+    uint8_t *plane = level_origin(pyr, g, frame, 0);
+    const uint8_t *s0 = src + (size_t)frame * srcFrameStride;
+    uint4 v[kImportRows];
+#pragma unroll
+    for (int r = 0; r < kImportRows; r++) {
+        const int yo = min(row0 + r, nrows - 1) - kEdge;
+        const uint8_t *s = s0 + (size_t)reflect101(yo, lg.h) * srcRowStride;
+        if (interior) {
+            __builtin_memcpy(&v[r], s + x0, 16);
+        } else {
+            unsigned w[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                w[d] = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int xo = x0 + d * 4 + k;
+                    xo = xo < -kEdge ? -kEdge : (xo > lg.w + kEdge - 1 ? lg.w + kEdge - 1 : xo);
+                    w[d] |= (unsigned)s[reflect101(xo, lg.w)] << (8 * k);
+                }
+            }
+            v[r] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kImportRows; r++) {
+        const int yo = row0 + r - kEdge;
+        if (yo < lg.h + kEdge) *reinterpret_cast<uint4 *>(plane + __mul24(yo, lg.stride) + x0) = v[r];
     }
 }
 
@@ -136,61 +187,111 @@ __global__ __launch_bounds__(256) void k_pyramid_level0_color(const uint8_t *__r
     }
 }
 
-// Levels >= 1.  The (at most 12-byte) source window of the four outputs is fetched as three
-// aligned dwords per source row; each output picks its two taps with v_alignbyte and weighs them
-// with one v_dot2_u32_u16.  Valid while 3 * scaleFactor + 5 <= 12 (host-checked: scaleFactor <= 2).
-// A thread keeps its four x-tap records and walks kPyrRows padded rows.
+// Levels >= 1.  Measured on MI355X (profiles/, tools/kt_var.sh): a CU issues about one vector-memory
+// instruction per 16 cycles whatever its width and one VALU instruction per cycle, and this kernel was
+// bound by the former.  So:
+//   * ONE unaligned 8-byte buffer load per source row fetches the taps of all four outputs of a
+//     thread (kWide; valid while 3 * scaleFactor + 2 < 8, i.e. scaleFactor < 2 -- otherwise four
+//     dword loads); buffer addressing = SGPR descriptor + per-lane column offset + wave-uniform row
+//     offset, so there is no vector address arithmetic;
+//   * per output and source row one v_perm (two tap bytes -> u16 pair, per-lane selector) and one
+//     v_dot2_u32_u16:  H = S[sx]*a0 + S[sx+1]*a1  (a1 == 0 wherever cv::resize clamps sx+1, so the
+//     byte after the tap may be read: the planes are padded);
+//   * a wave walks kPyrRows consecutive padded rows; rows are wave-uniform, and "the second source
+//     row of output row r is the first of row r+1" (most rows at scale 1.2) is a scalar branch that
+//     reuses the four H values;
+//   * vertical pass ((b*(H>>4))>>16 per tap) = v_and + v_mul_hi_u32_u24 with b << 12.
+// grid = (ceil(groups/64), ceil((h+38)/(4*kPyrRows)), frames), block = (64, 4).
+__device__ __forceinline__ unsigned mul_hi_u24(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Raw buffer descriptor over [p, p + bytes).  Word 3 = 0x00020000: raw 32-bit data format of gfx9.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_buffer(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <bool kWide>
 __global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
                                                       const ResizeTap *__restrict__ taps, int level)
 {
     typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
     const LevelGeom &lg = g->lv[level];
     const int frame = blockIdx.z;
     const int gx = blockIdx.x * 64 + threadIdx.x;
-    const int row0 = (blockIdx.y * 4 + threadIdx.y) * kPyrRows;  // padded row, 0 = yo -19
+    const int row0 = __builtin_amdgcn_readfirstlane((blockIdx.y * 4 + threadIdx.y) * kPyrRows);  // padded row, 0 = yo -19
     const int groups = (kPadLeft + lg.w + kEdge + 3) >> 2;
     const int nrows = lg.h + 2 * kEdge;
-    if (gx >= groups || row0 >= nrows) return;
+    if (row0 >= nrows) return;
+    const bool active = gx < groups;
     const LevelGeom &pg = g->lv[level - 1];
     const uint8_t *prev = level_origin((const uint8_t *)pyr, g, frame, level - 1);
-    const uint4 *txp = reinterpret_cast<const uint4 *>(taps + lg.tabX + gx * 4);
+    // rows 0 .. h-1 of the previous level (+ the right border read after the last column's taps)
+    const __amdgpu_buffer_rsrc_t src = make_buffer(prev, (unsigned)(pg.h * pg.stride));
+    // destination: the padded plane from its first byte (row -19, column -kPadLeft); lane offset gx * 4
+    const __amdgpu_buffer_rsrc_t dst = make_buffer(level_origin(pyr, g, frame, level) - kEdge * lg.stride - kPadLeft, (unsigned)(nrows * lg.stride));
+    const uint4 *txp = reinterpret_cast<const uint4 *>(taps + lg.tabX + (active ? gx : 0) * 4);
     const uint4 t01 = txp[0], t23 = txp[1];  // four ResizeTap records
-    const int ofs[4] = {(int)(short)(t01.x & 0xffff), (int)(short)(t01.z & 0xffff), (int)(short)(t23.x & 0xffff),
-                        (int)(short)(t23.z & 0xffff)};
-    const unsigned wgt[4] = {t01.y, t01.w, t23.y, t23.w};  // a0 | a1 << 16
-    const int base = min(min(ofs[0], ofs[1]), min(ofs[2], ofs[3])) & ~3;
-    unsigned sel[4], shift[4];
+    const unsigned ofs[4] = {t01.x & 0xffffu, t01.z & 0xffffu, t23.x & 0xffffu, t23.z & 0xffffu};  // source columns, >= 0
+    const ushort2v wgt[4] = {__builtin_bit_cast(ushort2v, t01.y), __builtin_bit_cast(ushort2v, t01.w),
+                             __builtin_bit_cast(ushort2v, t23.y), __builtin_bit_cast(ushort2v, t23.w)};  // a0 | a1 << 16
+    const unsigned base = min(min(ofs[0], ofs[1]), min(ofs[2], ofs[3]));  // reflected borders are not monotonic
+    unsigned sel[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const unsigned o = (unsigned)(ofs[k] - base);
-        sel[k] = o >> 2;  // 0, 1 or 2: which dword pair holds the taps
-        shift[k] = o & 3u;
+        const unsigned o = ofs[k] - base;            // 0 .. 6: byte of the first tap inside the 8-byte window
+        sel[k] = 0x0c000c00u | o | ((o + 1) << 16);  // result = (byte o) | (byte o+1) << 16
     }
-    uint8_t *dstPlane = level_origin(pyr, g, frame, level) + (gx * 4 - kPadLeft);
     const ResizeTap *tyTab = taps + lg.tabY;
+    const int pstride = pg.stride, dstride = lg.stride;
+    auto hrow = [&](int srcRow, unsigned (&H)[4]) {
+        const int so = __builtin_amdgcn_readfirstlane(__mul24(srcRow, pstride));
+        if (kWide) {
+            const uint2v w = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(src, (int)base, so, 0));
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(w.y, w.x, sel[k])), wgt[k], 0u, false);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(src, (int)ofs[k], so, 0), 0x0c010c00u)),
+                                              wgt[k], 0u, false);
+        }
+    };
+    unsigned H1[4];
+    int haveRow = -0x7fffffff;  // source row whose H values sit in H1
 #pragma unroll
     for (int r = 0; r < kPyrRows; r++) {
-        const int row = min(row0 + r, nrows - 1);  // clamped duplicate rows rewrite the same bytes
+        const int row = row0 + r;
+        if (row >= nrows) break;  // wave-uniform
         const ResizeTap ty = tyTab[row];
-        const uint32_t *S0 = reinterpret_cast<const uint32_t *>(prev + __mul24((int)ty.ofs, pg.stride) + base);
-        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(prev + __mul24((int)ty.ofs1, pg.stride) + base);
-        const unsigned d0 = S0[0], d1 = S0[1], d2 = S0[2];
-        const unsigned e0 = S1[0], e1 = S1[1], e2 = S1[2];
-        const unsigned b0 = (unsigned)ty.a0, b1 = (unsigned)ty.a1;
-        uint32_t packed = 0;
+        const int r0 = ty.ofs, r1 = ty.ofs1;
+        unsigned H0[4];
+        if (r0 == haveRow) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const unsigned lo0 = sel[k] == 0 ? d0 : (sel[k] == 1 ? d1 : d2), hi0 = sel[k] == 0 ? d1 : (sel[k] == 1 ? d2 : 0u);
-            const unsigned lo1 = sel[k] == 0 ? e0 : (sel[k] == 1 ? e1 : e2), hi1 = sel[k] == 0 ? e1 : (sel[k] == 1 ? e2 : 0u);
-            const unsigned w0 = __builtin_amdgcn_alignbyte(hi0, lo0, shift[k]);  // bytes ofs, ofs + 1 of row 0
-            const unsigned w1 = __builtin_amdgcn_alignbyte(hi1, lo1, shift[k]);
-            const ushort2v wk = __builtin_bit_cast(ushort2v, wgt[k]);
-            const unsigned h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, w0, 0x0c010c00u)), wk, 0u, false);
-            const unsigned h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, w1, 0x0c010c00u)), wk, 0u, false);
-            const unsigned v = ((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2;  // 12 x 15 bits
-            packed |= (v & 0xffu) << (8 * k);
+            for (int k = 0; k < 4; k++) H0[k] = H1[k];
+        } else {
+            hrow(r0, H0);
         }
-        *reinterpret_cast<uint32_t *>(dstPlane + __mul24(row - kEdge, lg.stride)) = packed;
+        if (r1 == r0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) H1[k] = H0[k];
+        } else {
+            hrow(r1, H1);
+        }
+        haveRow = r1;
+        const unsigned b0 = (unsigned)ty.a0 << 12, b1 = (unsigned)ty.a1 << 12;  // <= 2^23
+        unsigned v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)  // ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2, H < 2^20
+            v[k] = (mul_hi_u24(b0, H0[k] & ~15u) + mul_hi_u24(b1, H1[k] & ~15u) + 2u) >> 2;
+        const uint32_t packed = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);  // each <= 255
+        if (active) __builtin_amdgcn_raw_buffer_store_b32(packed, dst, gx * 4, __builtin_amdgcn_readfirstlane(__mul24(row, dstride)), 0);
     }
 }
 
