@@ -249,43 +249,68 @@ __global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr
     }
     const ResizeTap *tyTab = taps + lg.tabY;
     const int pstride = pg.stride, dstride = lg.stride;
-    auto hrow = [&](int srcRow, unsigned (&H)[4]) {
-        const int so = __builtin_amdgcn_readfirstlane(__mul24(srcRow, pstride));
-        if (kWide) {
-            const uint2v w = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(src, (int)base, so, 0));
+    // Row taps of all kPyrRows rows first (wave-uniform and ahead of every store: scalar loads), then
+    // every source-row load the rows need (duplicates skipped by scalar branches) so that all of them
+    // are in flight together, then the arithmetic.
+    // (the table is read through the constant address space: the compiler cannot see that the buffer
+    // stores below never touch it, and would otherwise spend a vector-memory slot per record)
+    typedef const __attribute__((address_space(4))) uint2v *ConstTapPtr;  // 8-byte aligned records
+    const ConstTapPtr tyConst = (ConstTapPtr)(uintptr_t)tyTab;
+    ResizeTap ty[kPyrRows];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(w.y, w.x, sel[k])), wgt[k], 0u, false);
-        } else {
+    for (int r = 0; r < kPyrRows; r++) {
+        const uint2v t = tyConst[min(row0 + r, nrows - 1)];
+        ty[r].ofs = (short)(t.x & 0xffffu); ty[r].ofs1 = (short)(t.x >> 16);
+        ty[r].a0 = (short)(t.y & 0xffffu); ty[r].a1 = (short)(t.y >> 16);
+    }
+    bool need0[kPyrRows], need1[kPyrRows];
+    uint2v W0[kPyrRows], W1[kPyrRows];   // kWide: 8-byte windows of the first / second source row
+    unsigned Q0[kPyrRows][4], Q1[kPyrRows][4];  // !kWide: one dword per output column
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(src, (int)ofs[k], so, 0), 0x0c010c00u)),
-                                              wgt[k], 0u, false);
+    for (int r = 0; r < kPyrRows; r++) {
+        need0[r] = r == 0 || ty[r].ofs != ty[r - 1].ofs1;
+        need1[r] = ty[r].ofs1 != ty[r].ofs;
+        if (need0[r]) {
+            const int so = __builtin_amdgcn_readfirstlane(__mul24((int)ty[r].ofs, pstride));
+            if (kWide) W0[r] = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(src, (int)base, so, 0));
+            else
+#pragma unroll
+                for (int k = 0; k < 4; k++) Q0[r][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(src, (int)ofs[k], so, 0);
+        }
+        if (need1[r]) {
+            const int so = __builtin_amdgcn_readfirstlane(__mul24((int)ty[r].ofs1, pstride));
+            if (kWide) W1[r] = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(src, (int)base, so, 0));
+            else
+#pragma unroll
+                for (int k = 0; k < 4; k++) Q1[r][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(src, (int)ofs[k], so, 0);
+        }
+    }
+    auto hsum = [&](const uint2v &w, const unsigned (&q)[4], unsigned (&H)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned pair = kWide ? __builtin_amdgcn_perm(w.y, w.x, sel[k]) : __builtin_amdgcn_perm(0u, q[k], 0x0c010c00u);
+            H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pair), wgt[k], 0u, false);
         }
     };
-    unsigned H1[4];
-    int haveRow = -0x7fffffff;  // source row whose H values sit in H1
+    unsigned H1[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < kPyrRows; r++) {
         const int row = row0 + r;
         if (row >= nrows) break;  // wave-uniform
-        const ResizeTap ty = tyTab[row];
-        const int r0 = ty.ofs, r1 = ty.ofs1;
         unsigned H0[4];
-        if (r0 == haveRow) {
+        if (need0[r]) {
+            hsum(W0[r], Q0[r], H0);
+        } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) H0[k] = H1[k];
-        } else {
-            hrow(r0, H0);
         }
-        if (r1 == r0) {
+        if (need1[r]) {
+            hsum(W1[r], Q1[r], H1);
+        } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) H1[k] = H0[k];
-        } else {
-            hrow(r1, H1);
         }
-        haveRow = r1;
-        const unsigned b0 = (unsigned)ty.a0 << 12, b1 = (unsigned)ty.a1 << 12;  // <= 2^23
+        const unsigned b0 = (unsigned)ty[r].a0 << 12, b1 = (unsigned)ty[r].a1 << 12;  // <= 2^23
         unsigned v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)  // ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2, H < 2^20

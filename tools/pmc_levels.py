@@ -5,7 +5,8 @@ import collections
 import csv
 import glob
 import sys
-f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
+import os
+f = max(glob.glob(sys.argv[1] + "/*/*counter_collection.csv"), key=os.path.getmtime)
 name, period = sys.argv[2], int(sys.argv[3])
 by_disp = collections.OrderedDict()
 for r in csv.DictReader(open(f)):

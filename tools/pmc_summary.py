@@ -4,7 +4,8 @@ import collections
 import csv
 import glob
 import sys
-f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
+import os
+f = max(glob.glob(sys.argv[1] + "/*/*counter_collection.csv"), key=os.path.getmtime)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     if "amos::" in r["Kernel_Name"]:

@@ -4,7 +4,8 @@ the repeating launch sequence (e.g. the 7 k_pyramid_level launches of a pass): t
 import csv
 import glob
 import sys
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+import os
+f = max(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"), key=os.path.getmtime)
 name, period = sys.argv[2], int(sys.argv[3])
 rows = [r for r in csv.DictReader(open(f)) if name in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
