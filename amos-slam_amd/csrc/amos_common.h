@@ -41,7 +41,7 @@ struct LevelGeom {
     int nodeCap;                     // capacity of the node list / of the level's keypoint list
     int kpOff;                       // offset of the level's keypoint list inside one frame
     int tabX, tabY;                  // offsets into the resize coefficient tables
-    int blurGroups, blurItemStart;   // blur work items: 4-px column groups x 32-row strips
+    int blurGroups, blurItemStart;   // blur work items: 8-px column groups x kBlurStrip-row strips
     float scale;                     // mvScaleFactor[level]
     float patchSize;                 // (float)(int)(31 * scale), ORBextractor.cc:1177
 };

@@ -258,7 +258,7 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
                 for (int i = 0; i < nY; i++) (*taps)[lg.tabY + i] = tyv[refl(i - kEdge, lg.h)];
             }
         }
-        lg.blurGroups = (lg.w + 3) / 4;
+        lg.blurGroups = (lg.w + 7) / 8;
         lg.blurItemStart = blurOff;
         blurOff += lg.blurGroups * ((lg.h + kBlurStrip - 1) / kBlurStrip);
     }

@@ -1080,69 +1080,104 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
 // (SURVEY A.2): dst = (sum_ij k_i k_j p + 32768) >> 16 with taps {18,34,48,56,48,34,18}/256.
 // The device planes already carry the 19-px reflect-101 border, so the 3-px halo is read directly.
 //
-// A thread owns a 4-pixel-wide column strip and marches down kBlurStrip rows keeping the last six
-// row pairs of horizontal sums in registers (no LDS).  Per row it loads three aligned dwords
-// (pixels x-4 .. x+7), forms the four 7-tap horizontal sums with v_alignbyte + 2 x v_dot4_u32_u8
-// each, and finishes one output row with 3 x v_dot2_u32_u16 + 1 mad per pixel on (row, row+1)
-// packed pairs.  Work items are linearised as (strip, group) inside a level so that consecutive
-// lanes touch consecutive dwords whatever the level width.  grid = (ceil(items/256), frames).
-constexpr int kBlurStrip = 32;
+// A thread owns an 8-pixel-wide column strip and marches down kBlurStrip rows (no LDS).  The kernel is
+// sized by instruction issue (one vector-memory instruction per 16 cycles and CU, one VALU per cycle):
+//   * per row ONE unaligned 16-byte buffer load (pixels x-4 .. x+11) and, per output row, one 8-byte
+//     store; eight rows of loads are issued together;
+//   * horizontal 7-tap sums: the twelve byte-shifted dwords of the window (v_alignbyte, three are
+//     free) feed 2 x v_dot4_u32_u8 per pixel;
+//   * vertical: the sums (< 2^16) of rows (2i, 2i+1) are kept as NON-overlapping u16 pairs in a ring of
+//     four registers per pixel; an output row is 3 x v_dot2_u32_u16 + 1 mad (even rows) or
+//     4 x v_dot2_u32_u16 (odd rows, taps shifted by one), exact integer (sum + 32768) >> 16.
+// Work items are linearised as (strip, group) inside a level so that consecutive lanes touch
+// consecutive 8-byte pieces whatever the level width.  grid = (ceil(items/256), frames).
+constexpr int kBlurStrip = 64;
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                              const Geom *__restrict__ g)
 {
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
     const int item = blockIdx.x * 256 + threadIdx.x;
     const int frame = blockIdx.y;
-    if (item >= g->blurItems) return;
+    const bool active = item < g->blurItems;
     int level = 0;
     for (int l = 1; l < g->nLevels; l++)
-        if (item >= g->lv[l].blurItemStart) level = l;
+        if (active && item >= g->lv[l].blurItemStart) level = l;
     const LevelGeom &lg = g->lv[level];
-    const int local = item - lg.blurItemStart;
+    const int local = active ? item - lg.blurItemStart : 0;
     const int strip = local / lg.blurGroups;
-    const int x = (local - strip * lg.blurGroups) * 4, y0 = strip * kBlurStrip;
-    const uint8_t *src = level_origin(pyr, g, frame, level) + x - 4;
-    uint8_t *dst = level_origin(blur, g, frame, level) + x;
-    const int lastRow = lg.h + kEdge - 1;
+    const int x = (local - strip * lg.blurGroups) * 8, y0 = strip * kBlurStrip;
+    const int stride = lg.stride, planeRows = lg.h + 2 * kEdge;
+    // both planes from their first byte (row -19, column -kPadLeft)
+    const uint8_t *srcPlane = level_origin(pyr, g, frame, level) - kEdge * stride - kPadLeft;
+    uint8_t *dstPlane = level_origin(blur, g, frame, level) - kEdge * stride - kPadLeft;
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(srcPlane), 0, planeRows * stride, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(dstPlane, 0, planeRows * stride, 0x00020000);
+    const int colIn = x - 4 + kPadLeft, colOut = x + kPadLeft;
+    const int lastOff = __mul24(planeRows - 1, stride) + colIn;   // last plane row (y = h + 18)
+    int inOff = __mul24(y0 - 3 + kEdge, stride) + colIn;          // row y0 - 3 >= -3
+    int outOff = __mul24(y0 + kEdge, stride) + colOut;
+    int rowsLeft = active ? min(kBlurStrip, lg.h - y0) : 0;        // output rows still to store
     const unsigned KA = 18u | (34u << 8) | (48u << 16) | (56u << 24);  // taps of pixels x-3 .. x
     const unsigned KB = 48u | (34u << 8) | (18u << 16);                // taps of pixels x+1 .. x+3
-    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-    const ushort2v K01 = {18, 34}, K23 = {48, 56}, K45 = {48, 34};
-    unsigned pairs[4][6];  // pairs[c][r % 6] = h[r] | h[r+1] << 16 for the last six rows
-    unsigned prev[4];
+    const ushort2v E0 = {18, 34}, E1 = {48, 56}, E2 = {48, 34};                 // even row: + 18 * current
+    const ushort2v O0 = {0, 18}, O1 = {34, 48}, O2 = {56, 48}, O3 = {34, 18};    // odd row
+    unsigned ring[8][4];  // ring[c][i % 4] = h[2i] | h[2i+1] << 16
+    unsigned even[8];     // h of the last even row
+#pragma unroll 1
+    for (int rb = 0; rb < kBlurStrip + 6; rb += 8) {
+        uint4v W[8];
 #pragma unroll
-    for (int r = 0; r < kBlurStrip + 6; r++) {
-        const int y = min(y0 + r - 3, lastRow);
-        const uint32_t *row = reinterpret_cast<const uint32_t *>(src + __mul24(y, lg.stride));  // 24-bit multiplies are full rate
-        const unsigned d0 = row[0], d1 = row[1], d2 = row[2];
-        unsigned hsum[4];
-        hsum[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KA,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KB, 0u, false), false);
-        hsum[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KA,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KB, 0u, false), false);
-        hsum[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KA,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KB, 0u, false), false);
-        hsum[3] = __builtin_amdgcn_udot4(d1, KA, __builtin_amdgcn_udot4(d2, KB, 0u, false), false);
-        unsigned acc[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if (r >= 1) pairs[c][(r - 1) % 6] = prev[c] | (hsum[c] << 16);
-            prev[c] = hsum[c];
-            if (r >= 6) {  // output row y0 + r - 6: rows r-6 .. r
-                unsigned a = __umul24(hsum[c], 18u) + 32768u;
-                a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pairs[c][(r - 6) % 6]), K01, a, false);
-                a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pairs[c][(r - 4) % 6]), K23, a, false);
-                a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pairs[c][(r - 2) % 6]), K45, a, false);
-                acc[c] = a;
-            }
+        for (int i = 0; i < 8; i++) {
+            W[i] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(src, inOff, 0, 0));
+            inOff = min(inOff + stride, lastOff);
         }
-        if (r >= 6) {
-            const int yo = y0 + r - 6;
-            if (yo < lg.h) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const unsigned d[4] = {W[i].x, W[i].y, W[i].z, W[i].w};
+            unsigned A[13];  // A[o] = window bytes o .. o+3, o = 1 .. 12
+#pragma unroll
+            for (int o = 1; o <= 12; o++) A[o] = (o & 3) == 0 ? d[o >> 2] : __builtin_amdgcn_alignbyte(d[(o >> 2) + 1], d[o >> 2], o & 3);
+            unsigned h[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) h[c] = __builtin_amdgcn_udot4(A[c + 1], KA, __builtin_amdgcn_udot4(A[c + 5], KB, 0u, false), false);
+            // rows are numbered r = rb + i from the strip's first halo row; (rb is a multiple of 8, so
+            // parity and ring slots depend on i only)
+            unsigned acc[8];
+            if ((i & 1) == 0) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    even[c] = h[c];
+                    // rows r-6 .. r-1 are pairs (r-6)/2, (r-4)/2, (r-2)/2
+                    unsigned a = __umul24(h[c], 18u) + 32768u;
+                    a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, ring[c][((i + 8 - 6) / 2) & 3]), E0, a, false);
+                    a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, ring[c][((i + 8 - 4) / 2) & 3]), E1, a, false);
+                    a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, ring[c][((i + 8 - 2) / 2) & 3]), E2, a, false);
+                    acc[c] = a;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    ring[c][((i - 1) / 2) & 3] = even[c] | (h[c] << 16);
+                    // row r-6 is the high half of pair (r-7)/2, then pairs (r-5)/2, (r-3)/2, (r-1)/2
+                    unsigned a = 32768u;
+                    a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, ring[c][((i + 8 - 7) / 2) & 3]), O0, a, false);
+                    a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, ring[c][((i + 8 - 5) / 2) & 3]), O1, a, false);
+                    a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, ring[c][((i + 8 - 3) / 2) & 3]), O2, a, false);
+                    a = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, ring[c][((i - 1) / 2) & 3]), O3, a, false);
+                    acc[c] = a;
+                }
+            }
+            if (rb + i >= 6 && rowsLeft > 0) {  // output row y0 + r - 6
                 // byte 2 of each accumulator is the pixel
-                const unsigned lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
-                const unsigned hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
-                *reinterpret_cast<uint32_t *>(dst + __mul24(yo, lg.stride)) = lo | hi;  // row pitch leaves room past w
+                uint2v o;
+                o.x = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
+                o.y = __builtin_amdgcn_perm(acc[5], acc[4], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[7], acc[6], 0x06020c0cu);
+                __builtin_amdgcn_raw_buffer_store_b64(o, dst, outOff, 0, 0);  // row pitch leaves room past w
+                outOff += stride;
+                rowsLeft--;
             }
         }
     }
