@@ -292,7 +292,9 @@ __global__ __launch_bounds__(256) void k_bf_best2(const uint8_t *__restrict__ de
     // 32 bytes arrive through the scalar data cache (s_load_dwordx8) straight into SGPR operands of the
     // v_xor -- no LDS tile, no vector registers for the train side.
     const uint4 *tv = reinterpret_cast<const uint4 *>(tb);
-    auto eval = [&](const uint4 &lo, const uint4 &hi, int jj) {
+    // key = dist << 16 | train index.  The init_dist gate ("only dist < init_dist can win") is applied
+    // once at the end: dropping every key >= init_dist << 16 from the ungated top-2 gives the gated top-2.
+    auto key_of = [&](const uint4 &lo, const uint4 &hi, int jj) -> unsigned {
         int d = __popc(qd.w[0] ^ lo.x);
         d = bcnt_acc(qd.w[1] ^ lo.y, d);
         d = bcnt_acc(qd.w[2] ^ lo.z, d);
@@ -301,26 +303,35 @@ __global__ __launch_bounds__(256) void k_bf_best2(const uint8_t *__restrict__ de
         d = bcnt_acc(qd.w[5] ^ hi.y, d);
         d = bcnt_acc(qd.w[6] ^ hi.z, d);
         d = bcnt_acc(qd.w[7] ^ hi.w, d);
-        unsigned key = ((unsigned)d << 16) | (unsigned)jj;
-        if (kGate) key = d < initDist ? key : 0xffffffffu;  // initDist >= 257 can never reject
-        top2_push(best, second, key);
+        return ((unsigned)d << 16) | (unsigned)jj;
+    };
+    // two new keys against (best <= second) in three instructions: the smallest of {best, k1, k2} is the new
+    // best, the median of the three or the old second (whichever is smaller) the new second
+    auto push2 = [&](unsigned k1, unsigned k2) {
+        unsigned mid;
+        asm("v_med3_u32 %0, %1, %2, %3" : "=v"(mid) : "v"(best), "v"(k1), "v"(k2));
+        best = min(best, min(k1, k2));  // v_min3_u32
+        second = min(second, mid);
     };
     int jj = j0;
     for (; jj + 4 <= j1; jj += 4) {  // four descriptors (eight scalar loads) in flight per trip
         const uint4 a0 = tv[2 * jj], a1 = tv[2 * jj + 1], b0 = tv[2 * jj + 2], b1 = tv[2 * jj + 3];
         const uint4 c0 = tv[2 * jj + 4], c1 = tv[2 * jj + 5], d0 = tv[2 * jj + 6], d1 = tv[2 * jj + 7];
-        eval(a0, a1, jj);
-        eval(b0, b1, jj + 1);
-        eval(c0, c1, jj + 2);
-        eval(d0, d1, jj + 3);
+        push2(key_of(a0, a1, jj), key_of(b0, b1, jj + 1));
+        push2(key_of(c0, c1, jj + 2), key_of(d0, d1, jj + 3));
     }
-    for (; jj < j1; jj++) eval(tv[2 * jj], tv[2 * jj + 1], jj);
+    for (; jj < j1; jj++) top2_push(best, second, key_of(tv[2 * jj], tv[2 * jj + 1], jj));
     mergeB[wave][lane] = best;
     mergeS[wave][lane] = second;
     __syncthreads();
     if (wave == 0 && qi < nq) {
 #pragma unroll
         for (int w = 1; w < 4; w++) top2_merge(best, second, mergeB[w][lane], mergeS[w][lane]);
+        if (kGate) {
+            const unsigned limit = (unsigned)max(initDist, 0) << 16;  // keys of distances >= init_dist
+            if (best >= limit) best = 0xffffffffu;
+            if (second >= limit) second = 0xffffffffu;
+        }
         amos_best2 r;
         r.best_idx = best == 0xffffffffu ? -1 : (int)(best & 0xffff);
         r.best_dist = best == 0xffffffffu ? initDist : (int)(best >> 16);
