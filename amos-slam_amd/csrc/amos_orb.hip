@@ -326,9 +326,8 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
         if (l == 0 && channels > 1)
             hipLaunchKernelGGL(k_pyramid_level0_color, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, channels, rgbOrder);
         else if (l == 0) {
-            const int pieces = (kPadLeft + lg.w + kEdge + 15) / 16, chunks = (lg.h + 2 * kEdge + kImportRows - 1) / kImportRows;
-            hipLaunchKernelGGL(k_pyramid_level0_wide, dim3((pieces * chunks + 255) / 256, 1, nFrames), dim3(256), 0, h->stream, dSrc, frameStride,
-                               rowStride, h->dPyr, h->dGeom);
+            hipLaunchKernelGGL(k_pyramid_level0_wide, dim3((import_threads(lg.w, lg.h) + 255) / 256, 1, nFrames), dim3(256), 0, h->stream, dSrc,
+                               frameStride, rowStride, h->dPyr, h->dGeom);
         }
         else if (h->p.scale_factor < 1.99f)  // the four taps of a thread fit one 8-byte window
             hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);

@@ -97,11 +97,19 @@ __global__ __launch_bounds__(256) void k_pyramid_level0(const uint8_t *__restric
     }
 }
 
-// Level 0, 16 bytes per lane.  A thread owns 16 consecutive bytes of the PADDED plane (column
-// -32 + 16 g) for kImportRows rows: interior pieces are one dwordx4 load (any source alignment) and
-// one aligned dwordx4 store; pieces touching the border gather byte by byte through reflect-101.
-// grid = (ceil(pieces * rowChunks / 256), 1, frames), 1-D thread -> (row chunk, piece).
+// Level 0, 16 bytes per lane.  Interior pieces (16 consecutive bytes of the padded plane whose source is
+// 16 consecutive image bytes) are one dwordx4 load (any source alignment) and one aligned dwordx4 store,
+// kImportRows rows per thread.  The pieces that touch the reflect-101 border gather byte by byte; they
+// get their OWN threads (one piece of one row each, at the end of the grid) so that no interior wave
+// waits for a lane's sixteen dependent byte loads.
+// grid = (ceil((interiorPieces * rowChunks + borderPieces * rows) / 256), 1, frames).
 constexpr int kImportRows = 4;
+
+__host__ __device__ inline int import_threads(int w, int h)
+{
+    const int pieces = (kPadLeft + w + kEdge + 15) >> 4, nInt = w >> 4, nrows = h + 2 * kEdge;
+    return nInt * ((nrows + kImportRows - 1) / kImportRows) + (pieces - nInt) * nrows;
+}
 
 __global__ __launch_bounds__(256) void k_pyramid_level0_wide(const uint8_t *__restrict__ src, size_t srcFrameStride,
                                                             size_t srcRowStride, uint8_t *__restrict__ pyr,
@@ -110,42 +118,45 @@ __global__ __launch_bounds__(256) void k_pyramid_level0_wide(const uint8_t *__re
     const LevelGeom &lg = g->lv[0];
     const int frame = blockIdx.z;
     const int pieces = (kPadLeft + lg.w + kEdge + 15) >> 4;  // stride is a multiple of 128: whole pieces fit
-    const int nrows = lg.h + 2 * kEdge;
+    const int nInt = lg.w >> 4, nrows = lg.h + 2 * kEdge;
+    const int chunks = (nrows + kImportRows - 1) / kImportRows;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const int chunk = t / pieces, piece = t - chunk * pieces;
-    const int row0 = chunk * kImportRows;
-    if (row0 >= nrows) return;
-    const int x0 = piece * 16 - kPadLeft;
-    const bool interior = x0 >= 0 && x0 + 15 < lg.w;
     uint8_t *plane = level_origin(pyr, g, frame, 0);
     const uint8_t *s0 = src + (size_t)frame * srcFrameStride;
-    uint4 v[kImportRows];
+    if (t < nInt * chunks) {
+        const int chunk = t / nInt, piece = t - chunk * nInt;
+        const int row0 = chunk * kImportRows, x0 = piece * 16;
+        uint4 v[kImportRows];
 #pragma unroll
-    for (int r = 0; r < kImportRows; r++) {
-        const int yo = min(row0 + r, nrows - 1) - kEdge;
-        const uint8_t *s = s0 + (size_t)reflect101(yo, lg.h) * srcRowStride;
-        if (interior) {
-            __builtin_memcpy(&v[r], s + x0, 16);
-        } else {
-            unsigned w[4];
+        for (int r = 0; r < kImportRows; r++) {
+            const int yo = min(row0 + r, nrows - 1) - kEdge;
+            __builtin_memcpy(&v[r], s0 + (size_t)reflect101(yo, lg.h) * srcRowStride + x0, 16);
+        }
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                w[d] = 0;
+        for (int r = 0; r < kImportRows; r++) {
+            const int yo = row0 + r - kEdge;
+            if (yo < lg.h + kEdge) *reinterpret_cast<uint4 *>(plane + __mul24(yo, lg.stride) + x0) = v[r];
+        }
+        return;
+    }
+    const int nb = pieces - nInt, b = t - nInt * chunks;
+    const int row = b / nb, bp = b - row * nb;
+    if (row >= nrows) return;
+    const int piece = bp < (kPadLeft >> 4) ? bp : bp + nInt;  // left pad pieces, then everything right of the interior
+    const int x0 = piece * 16 - kPadLeft, yo = row - kEdge;
+    const uint8_t *sr = s0 + (size_t)reflect101(yo, lg.h) * srcRowStride;
+    unsigned w[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    int xo = x0 + d * 4 + k;
-                    xo = xo < -kEdge ? -kEdge : (xo > lg.w + kEdge - 1 ? lg.w + kEdge - 1 : xo);
-                    w[d] |= (unsigned)s[reflect101(xo, lg.w)] << (8 * k);
-                }
-            }
-            v[r] = make_uint4(w[0], w[1], w[2], w[3]);
+    for (int d = 0; d < 4; d++) {
+        w[d] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int xo = x0 + d * 4 + k;
+            xo = xo < -kEdge ? -kEdge : (xo > lg.w + kEdge - 1 ? lg.w + kEdge - 1 : xo);
+            w[d] |= (unsigned)sr[reflect101(xo, lg.w)] << (8 * k);
         }
     }
-#pragma unroll
-    for (int r = 0; r < kImportRows; r++) {
-        const int yo = row0 + r - kEdge;
-        if (yo < lg.h + kEdge) *reinterpret_cast<uint4 *>(plane + __mul24(yo, lg.stride) + x0) = v[r];
-    }
+    *reinterpret_cast<uint4 *>(plane + __mul24(yo, lg.stride) + x0) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // Level 0 from interleaved colour frames: cv::cvtColor(..., CV_{BGR,RGB}[A]2GRAY) (Tracking.cc:308-321)
@@ -1024,22 +1035,25 @@ __device__ __forceinline__ int group16_sum(int v)
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
                                                amos_keypoint *__restrict__ lvKps, const int *__restrict__ lvCount, int nFrames)
 {
-    __shared__ uint2 wtab[16][16];
+    // wt[row][half][0] = weights u + 16 of the 16 bytes of that half row (0 outside the circle),
+    // wt[row][half][1] = 0/1 masks; row = v + 15, row 31 (v = 16) does not exist: all zero
+    __shared__ uint4 wt[32][2][2];
     {
-        const int step = threadIdx.x >> 4, jj = threadIdx.x & 15;
-        const int v = -kHalfPatch + 2 * step + (jj >> 3);
+        const int row = threadIdx.x >> 3, half = (threadIdx.x >> 2) & 1, d = threadIdx.x & 3;
+        const int v = row - kHalfPatch;
         const int um = v <= kHalfPatch ? c_umax[v < 0 ? -v : v] : -1;
         unsigned wu = 0, ones = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int u = -kHalfPatch + 4 * (jj & 7) + b;
+            const int u = -kHalfPatch + 16 * half + 4 * d + b;
             const int au = u < 0 ? -u : u;
             if (au <= um) {
                 wu |= (unsigned)(u + 16) << (8 * b);
                 ones |= 1u << (8 * b);
             }
         }
-        wtab[step][jj] = uint2{wu, ones};
+        reinterpret_cast<unsigned *>(&wt[row][half][0])[d] = wu;
+        reinterpret_cast<unsigned *>(&wt[row][half][1])[d] = ones;
     }
     __syncthreads();
     const int j = threadIdx.x & 15;
@@ -1053,21 +1067,32 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     amos_keypoint *kp = lvKps + (size_t)frame * g->kpLevelTotal + (active ? slot : 0);
     const int cx = active ? __float2int_rn(kp->x) : kEdge, cy = active ? __float2int_rn(kp->y) : kEdge;
     const int stride = lg.stride;
-    const uint8_t *col = level_origin(pyr, g, frame, active ? level : 0) + (ptrdiff_t)cy * stride + cx - kHalfPatch + 4 * (j & 7);
-    const int rowpar = j >> 3;
+    const int half = j & 1, rsub = j >> 1;
+    // four 16-byte pieces per lane (vector-memory instructions are the scarce resource, not bytes)
+    const uint8_t *col = level_origin(pyr, g, frame, active ? level : 0) + (ptrdiff_t)(cy - kHalfPatch) * stride + cx - kHalfPatch + 16 * half;
+    uint4 px[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int row = min(rsub + 8 * q, 2 * kHalfPatch);
+        __builtin_memcpy(&px[q], col + __mul24(row, stride), 16);  // unaligned global_load_dwordx4
+    }
     unsigned acc10 = 0, sum1 = 0;
     int m01 = 0;
 #pragma unroll
-    for (int step = 0; step < 16; step++) {
-        const int v = -kHalfPatch + 2 * step + rowpar;
-        const int vr = min(v, kHalfPatch);  // row 16 does not exist: its weights are zero
-        unsigned p;
-        __builtin_memcpy(&p, col + __mul24(vr, stride), 4);  // unaligned global_load_dword
-        const uint2 w = wtab[step][j];
-        const unsigned s1 = __builtin_amdgcn_udot4(p, w.y, 0u, false);
-        acc10 = __builtin_amdgcn_udot4(p, w.x, acc10, false);
+    for (int q = 0; q < 4; q++) {
+        const int row = rsub + 8 * q;
+        const uint4 w = wt[row][half][0], o = wt[row][half][1];
+        const uint4 p = px[q];
+        acc10 = __builtin_amdgcn_udot4(p.x, w.x, acc10, false);
+        acc10 = __builtin_amdgcn_udot4(p.y, w.y, acc10, false);
+        acc10 = __builtin_amdgcn_udot4(p.z, w.z, acc10, false);
+        acc10 = __builtin_amdgcn_udot4(p.w, w.w, acc10, false);
+        unsigned s1 = __builtin_amdgcn_udot4(p.x, o.x, 0u, false);
+        s1 = __builtin_amdgcn_udot4(p.y, o.y, s1, false);
+        s1 = __builtin_amdgcn_udot4(p.z, o.z, s1, false);
+        s1 = __builtin_amdgcn_udot4(p.w, o.w, s1, false);
         sum1 += s1;
-        m01 += v * (int)s1;
+        m01 += (row - kHalfPatch) * (int)s1;
     }
     int m10 = (int)acc10 - 16 * (int)sum1;
     m10 = group16_sum(m10);

@@ -25,7 +25,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 
 CONFIGS = {
     # BASELINE.json configs[1]: single MI355X, extract + brute-force match, mask disabled
-    "c2": dict(width=640, height=480, n_features=1000, n_levels=8, label="configs[1]: 640x480 L8 N1000 extract+match, mask off"),
+    "c2": dict(width=640, height=480, n_features=1000, n_levels=8, default_batch=512, default_streams=4, label="configs[1]: 640x480 L8 N1000 extract+match, mask off"),
     # BASELINE.json configs[2]: full front-end incl. the YOLACT mask (network on PyTorch-ROCm, random weights
     # with a biased class head so that ~100 detections exercise the whole post-processing chain)
     "c3": dict(width=640, height=480, n_features=1000, n_levels=8, mask=True, default_batch=32,
@@ -111,9 +111,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 256; 32 with the mask; 64 for c5)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 512; 32 with the mask; 64 for c5)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
-    ap.add_argument("--streams", type=int, default=2, help="independent lanes (handle + HIP streams) the batch is split over")
+    ap.add_argument("--streams", type=int, default=0, help="independent lanes (handle + HIP streams) the batch is split over (default 4 for c2, else 2)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--check", action="store_true", help="verify one frame of the batch against the oracle")
     ap.add_argument("--cpu-all-cores", type=int, default=0, help="also time the oracle on this many processes (0 = off)")
@@ -138,6 +138,8 @@ def main():
     cfg = CONFIGS[args.config]
     if args.batch <= 0:
         args.batch = cfg.get("default_batch", 256)
+    if args.streams <= 0:
+        args.streams = cfg.get("default_streams", 2)
     W, H, B = cfg["width"], cfg["height"], args.batch
     use_mask = bool(cfg.get("mask"))
     frames_np = synth.frames(shard.stream_for_rank(rank), 0, B, H, W)  # one stream per GPU
