@@ -31,7 +31,7 @@ CONFIGS = {
     "c3": dict(width=640, height=480, n_features=1000, n_levels=8, mask=True, default_batch=32,
                label="configs[2]: 640x480 L8 N1000 YOLACT-R50 mask + extract + gate + match"),
     # BASELINE.json configs[4]: synthetic HD stream
-    "c5": dict(width=1920, height=1080, n_features=4000, n_levels=12, default_batch=64,
+    "c5": dict(width=1920, height=1080, n_features=4000, n_levels=12, default_batch=128, default_streams=4,
                label="configs[4]: 1920x1080 L12 N4000 extract+match"),
 }
 
@@ -111,9 +111,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 512; 32 with the mask; 64 for c5)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 512; 32 with the mask; 128 for c5)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
-    ap.add_argument("--streams", type=int, default=0, help="independent lanes (handle + HIP streams) the batch is split over (default 4 for c2, else 2)")
+    ap.add_argument("--streams", type=int, default=0, help="independent lanes (handle + HIP streams) the batch is split over (default 4; 2 with the mask)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--check", action="store_true", help="verify one frame of the batch against the oracle")
     ap.add_argument("--cpu-all-cores", type=int, default=0, help="also time the oracle on this many processes (0 = off)")

@@ -5,6 +5,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
+rm -rf $O
 mkdir -p $O
 timeout -k 10 400 python3 $R/bench.py --steps 20 --warmup 3 --check > $O/bench.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 > $O/trace.log 2>&1 || exit 1

@@ -4,19 +4,20 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
 tag = sys.argv[1]
 src = "gpurun_out/final"
-shutil.copy(glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0], f"profiles/{tag}_kernel_stats.csv")
+shutil.copy(max(glob.glob(f"{src}/trace/*/*kernel_stats.csv"), key=os.path.getmtime), f"profiles/{tag}_kernel_stats.csv")
 line = [l for l in open(f"{src}/bench.log") if l.startswith("{")][-1]
 open(f"profiles/{tag}_bench.json", "w").write(line)
 bench = json.loads(line)
 out = {}
 for name, d in (("FETCH_SIZE_KB", "fetch"), ("WRITE_SIZE_KB", "write")):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(f"{src}/{d}/*/*counter_collection.csv")[0])):
+    for r in csv.DictReader(open(max(glob.glob(f"{src}/{d}/*/*counter_collection.csv"), key=os.path.getmtime))):
         if "amos::" in r["Kernel_Name"]:
             acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     for k, v in acc.items():
@@ -29,7 +30,7 @@ json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate p
            "correction": "FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section), re-calibrated for 4 B/lane and 16 B/lane loads with "
                          "tools/fetch_calib.hip (1 GiB stream -> 524 299 KB either way); WRITE_SIZE exact",
            "kernels": out}, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
-stage = {"import": [("amos::k_pyramid_level0", 1)], "pyramid": [("amos::k_pyramid_level", bench["config"]["n_levels"] - 1)], "fast": [("amos::k_fast_cells", 1)],
+stage = {"import": [("amos::k_pyramid_level0_wide", 1)], "pyramid": [("amos::k_pyramid_level<true>", bench["config"]["n_levels"] - 1)], "fast": [("amos::k_fast_cells", 1)],
          "octree": [("amos::k_octree", 1)], "orient": [("amos::k_orient", 1)], "blur": [("amos::k_blur", 1)],
          "describe": [("amos::k_describe", 1)], "match": [("amos::k_bf_best2<true>", 1)]}
 traffic = {"c2": {}}
