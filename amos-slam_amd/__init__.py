@@ -27,7 +27,7 @@ EXPORTS = [
     "amos_orb_set_level_keypoints", "amos_orb_level_layout", "amos_orb_fetch_levels", "amos_orb_store_levels", "amos_orb_gate", "amos_orb_closed_mask", "amos_orb_describe",
     "amos_orb_extract", "amos_orb_level_image", "amos_orb_blurred_image", "amos_orb_level_candidates",
     "amos_orb_extract_batch_device", "amos_orb_detect_batch_device", "amos_orb_gate_batch_device",
-    "amos_orb_describe_batch_device", "amos_orb_extract_batch_device_color", "amos_frame_rgbd_glue_batch_device", "amos_frame_grid_build_batch_device", "amos_match_window_best2_batch_device",
+    "amos_orb_describe_batch_device", "amos_orb_extract_batch_device_color", "amos_frame_rgbd_glue_batch_device", "amos_frame_undistort_batch_device", "amos_frame_image_bounds", "amos_frame_grid_build_batch_device", "amos_match_window_best2_batch_device",
     "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
@@ -246,13 +246,20 @@ class OrbExtractor:
                                                           C.c_int(int(rgb_order))), "amos_orb_extract_batch_device_color")
 
     def rgbd_glue_batch_device(self, d_depth, depth_is_u16, depth_map_factor, depth_frame_stride, depth_row_stride, mbf, bounds,
-                               d_u_right, d_depth_out, d_grid_cell):
+                               d_u_right, d_depth_out, d_grid_cell, d_kps_un=None):
         """ComputeStereoFromRGBD + grid cell of every keypoint of the last batch (Frame.cc:1576-1615, 1007-1030)."""
         _check(self.L.amos_frame_rgbd_glue_batch_device(self.h, C.c_void_p(d_depth), C.c_int(int(depth_is_u16)), C.c_float(depth_map_factor),
                                                         C.c_size_t(depth_frame_stride), C.c_size_t(depth_row_stride), C.c_float(mbf),
                                                         C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]),
-                                                        C.c_void_p(d_u_right), C.c_void_p(d_depth_out), C.c_void_p(d_grid_cell)),
+                                                        C.c_void_p(d_kps_un), C.c_void_p(d_u_right), C.c_void_p(d_depth_out),
+                                                        C.c_void_p(d_grid_cell)),
                "amos_frame_rgbd_glue_batch_device")
+
+    def undistort_batch_device(self, fx, fy, cx, cy, dist_coef, d_kps_un):
+        """Frame::UndistortKeyPoints for every keypoint of the last batch (Frame.cc:1052-1118)."""
+        dc = np.ascontiguousarray(dist_coef, np.float32)
+        _check(self.L.amos_frame_undistort_batch_device(self.h, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), _p(dc),
+                                                        C.c_int(len(dc)), C.c_void_p(d_kps_un)), "amos_frame_undistort_batch_device")
 
     def batch_results_device(self):
         kps, desc, cnt, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
@@ -286,6 +293,15 @@ class OrbExtractor:
     @property
     def stream(self):
         return self.L.amos_orb_stream(self.h)
+
+
+def image_bounds(width, height, fx, fy, cx, cy, dist_coef):
+    """Frame::ComputeImageBounds (Frame.cc:1121-1170): (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    dc = np.ascontiguousarray(dist_coef, np.float32)
+    out = np.zeros(4, np.float32)
+    _check(lib().amos_frame_image_bounds(C.c_int(width), C.c_int(height), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), _p(dc),
+                                         C.c_int(len(dc)), _p(out)), "amos_frame_image_bounds")
+    return tuple(float(v) for v in out)
 
 
 class WindowSearch(C.Structure):

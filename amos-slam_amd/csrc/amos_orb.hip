@@ -843,16 +843,58 @@ int amos_orb_extract_batch_device_color(amos_orb *h, const uint8_t *d_color, siz
     return launch_describe(h, n_frames);
 }
 
+static int make_undistort_args(float fx, float fy, float cx, float cy, const float *dist_coef, int n_dist, UndistortArgs &a, const char *who)
+{
+    if (!(fx != 0.f) || !(fy != 0.f) || n_dist < 0 || n_dist > 5 || (n_dist > 0 && !dist_coef)) { set_error("%s: invalid camera", who); return AMOS_ERR_INVALID; }
+    a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy;
+    for (int i = 0; i < 5; i++) a.k[i] = i < n_dist ? (double)dist_coef[i] : 0.;
+    a.identity = n_dist == 0 || dist_coef[0] == 0.0f;
+    return AMOS_OK;
+}
+
+int amos_frame_undistort_batch_device(amos_orb *h, float fx, float fy, float cx, float cy, const float *dist_coef, int n_dist,
+                                      amos_keypoint *d_kps_un)
+{
+    if (!h || !d_kps_un) { set_error("amos_frame_undistort_batch_device: invalid argument"); return AMOS_ERR_INVALID; }
+    if (!h->described) { set_error("amos_frame_undistort_batch_device before an extraction"); return AMOS_ERR_STATE; }
+    UndistortArgs a;
+    const int rc = make_undistort_args(fx, fy, cx, cy, dist_coef, n_dist, a, "amos_frame_undistort_batch_device");
+    if (rc != AMOS_OK) return rc;
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_undistort, dim3((h->geom.kpCap + 255) / 256, h->nFrames), dim3(256), 0, h->stream, h->dGeom, h->dOutKps, h->dOutCount, a,
+                       d_kps_un);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_frame_image_bounds(int width, int height, float fx, float fy, float cx, float cy, const float *dist_coef, int n_dist, float bounds[4])
+{
+    if (!bounds || width < 1 || height < 1) { set_error("amos_frame_image_bounds: invalid argument"); return AMOS_ERR_INVALID; }
+    UndistortArgs a;
+    const int rc = make_undistort_args(fx, fy, cx, cy, dist_coef, n_dist, a, "amos_frame_image_bounds");
+    if (rc != AMOS_OK) return rc;
+    if (a.identity) { bounds[0] = 0.f; bounds[1] = (float)width; bounds[2] = 0.f; bounds[3] = (float)height; return AMOS_OK; }
+    const float px[4] = {0.f, (float)width, 0.f, (float)width}, py[4] = {0.f, 0.f, (float)height, (float)height};
+    float ux[4], uy[4];
+    for (int i = 0; i < 4; i++) undistort_point(px[i], py[i], a.fx, a.fy, a.cx, a.cy, a.k, ux[i], uy[i]);
+    bounds[0] = std::min(ux[0], ux[2]);  // Frame.cc:1152-1155
+    bounds[1] = std::max(ux[1], ux[3]);
+    bounds[2] = std::min(uy[0], uy[1]);
+    bounds[3] = std::max(uy[2], uy[3]);
+    return AMOS_OK;
+}
+
 int amos_frame_rgbd_glue_batch_device(amos_orb *h, const void *d_depth, int depth_is_u16, float depth_map_factor,
                                       size_t depth_frame_stride_bytes, size_t depth_row_stride_bytes, float mbf, float min_x, float max_x,
-                                      float min_y, float max_y, float *d_u_right, float *d_depth_out, int32_t *d_grid_cell)
+                                      float min_y, float max_y, const amos_keypoint *d_kps_un, float *d_u_right, float *d_depth_out,
+                                      int32_t *d_grid_cell)
 {
     if (!h || !d_grid_cell || (d_depth && (!d_u_right || !d_depth_out)) || !(max_x > min_x) || !(max_y > min_y)) { set_error("amos_frame_rgbd_glue_batch_device: invalid argument"); return AMOS_ERR_INVALID; }
     if (!h->described) { set_error("amos_frame_rgbd_glue_batch_device before an extraction"); return AMOS_ERR_STATE; }
     AMOS_HIP_CHECK(hipSetDevice(h->device));
     const float wInv = static_cast<float>(AMOS_FRAME_GRID_COLS) / static_cast<float>(max_x - min_x);  // Frame.cc:302-303
     const float hInv = static_cast<float>(AMOS_FRAME_GRID_ROWS) / static_cast<float>(max_y - min_y);
-    hipLaunchKernelGGL(k_rgbd_glue, dim3((h->geom.kpCap + 255) / 256, h->nFrames), dim3(256), 0, h->stream, h->dGeom, h->dOutKps, h->dOutCount,
+    hipLaunchKernelGGL(k_rgbd_glue, dim3((h->geom.kpCap + 255) / 256, h->nFrames), dim3(256), 0, h->stream, h->dGeom, h->dOutKps, d_kps_un, h->dOutCount,
                        (const uint8_t *)d_depth, depth_is_u16, depth_map_factor, depth_frame_stride_bytes, depth_row_stride_bytes, mbf, min_x, min_y,
                        wInv, hInv, d_u_right, d_depth_out, d_grid_cell);
     AMOS_HIP_CHECK(hipGetLastError());

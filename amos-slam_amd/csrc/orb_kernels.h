@@ -1449,9 +1449,59 @@ __global__ __launch_bounds__(256) void k_gate(const Geom *__restrict__ g, amos_k
     if (tid == 0) nRemoved[frame] = remBase;
 }
 
+// cv::undistortPoints(pts, pts, K, distCoef, Mat(), K) for one point, as Frame::UndistortKeyPoints and
+// Frame::ComputeImageBounds call it (Frame.cc:1052-1118, 1121-1170): OpenCV 4.5 cvUndistortPointsInternal
+// with its default criteria (exactly 5 fixed-point iterations, no epsilon test), double arithmetic,
+// k = (k1, k2, p1, p2, k3) and the remaining coefficients zero, R = I, P = K.  Shared by the device
+// kernel and the host-side image bounds.
+__host__ __device__ inline void undistort_point(float u, float v, double fx, double fy, double cx, double cy, const double (&k)[5],
+                                                float &xo, float &yo)
+{
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double x = ((double)u - cx) * ifx, y = ((double)v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = 1. / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) {  // OpenCV gives up and returns the normalised input point
+            x = ((double)u - cx) * ifx;
+            y = ((double)v - cy) * ify;
+            break;
+        }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    xo = (float)(fx * x + cx);  // RR = K * I; ww = 1
+    yo = (float)(fy * y + cy);
+}
+
+struct UndistortArgs {
+    double fx, fy, cx, cy;
+    double k[5];
+    int identity;  // mDistCoef[0] == 0: mvKeysUn = mvKeys (Frame.cc:1057-1061)
+};
+
+// Frame::UndistortKeyPoints for every keypoint of the batch result.  grid = (ceil(kpCap/256), frames).
+__global__ __launch_bounds__(256) void k_undistort(const Geom *__restrict__ g, const amos_keypoint *__restrict__ outKps,
+                                                  const int *__restrict__ outCount, const UndistortArgs a,
+                                                  amos_keypoint *__restrict__ kpsUn)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
+    if (i >= outCount[frame] || i >= g->kpCap) return;
+    const size_t o = (size_t)frame * g->kpCap + i;
+    amos_keypoint kp = outKps[o];
+    if (!a.identity) undistort_point(kp.x, kp.y, a.fx, a.fy, a.cx, a.cy, a.k, kp.x, kp.y);
+    kpsUn[o] = kp;
+}
+
 // Frame::ComputeStereoFromRGBD (Frame.cc:1576-1615) + the grid cell of PosInGrid (Frame.cc:1007-1030),
-// one thread per keypoint of the batch result.  grid = (ceil(kpCap/256), frames).
+// one thread per keypoint of the batch result: the depth is looked up at the DISTORTED keypoint (mvKeys),
+// uRight and the grid cell come from the undistorted one (mvKeysUn; kpsUn == nullptr: the same).
+// grid = (ceil(kpCap/256), frames).
 __global__ __launch_bounds__(256) void k_rgbd_glue(const Geom *__restrict__ g, const amos_keypoint *__restrict__ outKps,
+                                                  const amos_keypoint *__restrict__ kpsUn,
                                                   const int *__restrict__ outCount, const uint8_t *__restrict__ depth,
                                                   int depthIsU16, float depthFactor, size_t depthFrameStride,
                                                   size_t depthRowStride, float mbf, float minX, float minY,
@@ -1462,6 +1512,7 @@ __global__ __launch_bounds__(256) void k_rgbd_glue(const Geom *__restrict__ g, c
     if (i >= outCount[frame] || i >= g->kpCap) return;
     const size_t o = (size_t)frame * g->kpCap + i;
     const amos_keypoint kp = outKps[o];
+    const amos_keypoint kpU = kpsUn ? kpsUn[o] : kp;
     const int u = (int)kp.x, v = (int)kp.y;  // imDepth.at<float>(v, u) with float arguments
     float d = -1.f;
     if (depth != nullptr && u >= 0 && v >= 0 && u < g->W && v < g->H) {
@@ -1471,9 +1522,9 @@ __global__ __launch_bounds__(256) void k_rgbd_glue(const Geom *__restrict__ g, c
     }
     const bool ok = d > 0;
     if (depthOut) depthOut[o] = ok ? d : -1.f;
-    if (uRight) uRight[o] = ok ? __fsub_rn(kp.x, __fdiv_rn(mbf, d)) : -1.f;
-    const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, minX), gridWInv));
-    const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, minY), gridHInv));
+    if (uRight) uRight[o] = ok ? __fsub_rn(kpU.x, __fdiv_rn(mbf, d)) : -1.f;
+    const int px = (int)roundf(__fmul_rn(__fsub_rn(kpU.x, minX), gridWInv));
+    const int py = (int)roundf(__fmul_rn(__fsub_rn(kpU.y, minY), gridHInv));
     gridCell[o] = (px < 0 || px >= AMOS_FRAME_GRID_COLS || py < 0 || py >= AMOS_FRAME_GRID_ROWS) ? -1 : px * AMOS_FRAME_GRID_ROWS + py;
 }
 

@@ -26,6 +26,17 @@ class MaskEngine:
             self.net.load_weights(weight_path)
             self.has_weights = True
         self.net.eval().to(self.device)
+        # NHWC activations/weights: MIOpen's fp32 convolutions run the 550x550 ResNet-50-FPN forward 29 % faster
+        # than NCHW on MI355X (22.2 vs 31.2 ms per 16 frames, tools/mask_prof.py); results agree to 3e-7.
+        self.channels_last = self.device.type == "cuda"
+        if self.channels_last:
+            self.net.to(memory_format=torch.channels_last)
+            torch.backends.cudnn.benchmark = True  # MIOpen solver search on first use of a shape
+
+    def _forward(self, x):
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        return self.net(x)
 
     @torch.no_grad()
     def network_outputs(self, image_chw):
@@ -33,7 +44,7 @@ class MaskEngine:
         x = torch.as_tensor(image_chw, dtype=torch.float32, device=self.device)
         img = x.permute(1, 2, 0) * 255            # image.transpose((1, 2, 0)) * 255
         img = resize_f32_cv(img, 640, 480)        # cv2.resize(image, (640, 480))
-        return self.net(fast_base_transform(img)), img
+        return self._forward(fast_base_transform(img)), img
 
     @torch.no_grad()
     def eval_chw(self, image_chw):
@@ -60,7 +71,7 @@ class MaskEngine:
         for b0 in range(0, B, chunk):
             chw = cxx_marshalling(frames[b0:b0 + chunk])                      # [b, 3, 640, 480]
             imgs = resize_f32_cv(chw.permute(0, 2, 3, 1) * 255, 640, 480)     # [b, 480, 640, 3]
-            pred = self.net(fast_base_transform(imgs))
+            pred = self._forward(fast_base_transform(imgs))
             masks, _found = person_mask_batch(detect_batch(pred), imgs.shape[2], imgs.shape[1])
             out[b0:b0 + imgs.shape[0]] = masks
         return out

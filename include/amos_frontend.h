@@ -173,15 +173,27 @@ int amos_orb_describe_batch_device(amos_orb *h);
 int amos_orb_extract_batch_device_color(amos_orb *h, const uint8_t *d_color, size_t frame_stride, size_t row_stride,
                                         int width, int height, int n_frames, int channels, int rgb_order);
 /* Frame::ComputeStereoFromRGBD (Frame.cc:1576-1615) and the cell of Frame::AssignFeaturesToGrid /
- * PosInGrid (Frame.cc:431-461, 1007-1030) for every keypoint of the last batch, zero-distortion cameras
- * (mvKeysUn == mvKeys, as for TUM3).  The depth map is 16-bit with Tracking's convertTo(CV_32F,
- * depth_map_factor) applied on the fly (depth_is_u16 != 0) or already float32.  Outputs are
- * [n_frames][capacity] arrays on the device (capacity from amos_orb_batch_results_device):
+ * PosInGrid (Frame.cc:431-461, 1007-1030) for every keypoint of the last batch.  The depth map is 16-bit with Tracking's convertTo(CV_32F,
+ * depth_map_factor) applied on the fly (depth_is_u16 != 0) or already float32; d_depth NULL = monocular
+ * (grid cells only).  d_kps_un = mvKeysUn from amos_frame_undistort_batch_device, or NULL for a
+ * zero-distortion camera (mvKeysUn == mvKeys, as for TUM3): the depth is read at mvKeys, uRight and the
+ * cell use mvKeysUn.  Outputs are [n_frames][capacity] arrays on the device (capacity from amos_orb_batch_results_device):
  * u_right / depth = -1 where the depth is not positive, grid_cell = col * 48 + row or -1. */
 int amos_frame_rgbd_glue_batch_device(amos_orb *h, const void *d_depth, int depth_is_u16, float depth_map_factor,
                                       size_t depth_frame_stride_bytes, size_t depth_row_stride_bytes, float mbf,
-                                      float min_x, float max_x, float min_y, float max_y, float *d_u_right,
-                                      float *d_depth_out, int32_t *d_grid_cell);
+                                      float min_x, float max_x, float min_y, float max_y,
+                                      const amos_keypoint *d_kps_un, float *d_u_right, float *d_depth_out,
+                                      int32_t *d_grid_cell);
+/* Frame::UndistortKeyPoints (Frame.cc:1052-1118) for every keypoint of the last batch:
+ * cv::undistortPoints(pts, pts, K, distCoef, Mat(), K) with OpenCV's default criteria (5 iterations, double
+ * arithmetic), distCoef = (k1, k2, p1, p2[, k3]) as Tracking reads them from the YAML (n_dist = 4 or 5;
+ * n_dist = 0 or k1 == 0 copies the keypoints, Frame.cc:1057-1061).  d_kps_un is [n_frames][capacity]. */
+int amos_frame_undistort_batch_device(amos_orb *h, float fx, float fy, float cx, float cy, const float *dist_coef,
+                                      int n_dist, amos_keypoint *d_kps_un);
+/* Frame::ComputeImageBounds (Frame.cc:1121-1170): bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY} from the four
+ * undistorted image corners (host; the same point routine as the kernel). */
+int amos_frame_image_bounds(int width, int height, float fx, float fy, float cx, float cy, const float *dist_coef,
+                            int n_dist, float bounds[4]);
 
 /* Device pointers of the batch results: keypoints [max_batch][capacity], descriptors
  * [max_batch][capacity][32], counts [max_batch].  Valid until destroy. */

@@ -1307,9 +1307,56 @@ void orc_color_to_gray(const uint8_t *src, size_t sstride, int w, int h, int cha
 
 float orc_depth_convert(uint16_t raw, float factor) { return (float)raw * factor; }
 
-void orc_rgbd_glue(const amos_keypoint *kps, int n, const float *depth, size_t depth_stride_elems, int w, int h, float mbf,
-                   float min_x, float max_x, float min_y, float max_y, float *u_right, float *depth_out, int32_t *grid_cell)
+/* cv::undistortPoints(pts, pts, K, distCoef, Mat(), K) as Frame::UndistortKeyPoints / ComputeImageBounds call
+ * it (Frame.cc:1052-1118, 1121-1170).  OpenCV 4.5 cvUndistortPointsInternal restated (PARITY UNPINNED, like the
+ * other OpenCV stages): default criteria = exactly 5 iterations, double arithmetic, coefficients beyond k3 zero,
+ * R = I, P = K.  dist = (k1, k2, p1, p2[, k3]); n_dist == 0 or k1 == 0 copies the input (Frame.cc:1057). */
+void orc_undistort_points(const float *xy, int n, float fx_, float fy_, float cx_, float cy_, const float *dist, int n_dist,
+                          float *out)
 {
+    double k[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < n_dist && i < 5; i++) k[i] = dist[i];
+    if (n_dist == 0 || dist[0] == 0.0f) {
+        memcpy(out, xy, sizeof(float) * 2 * (size_t)n);
+        return;
+    }
+    const double fx = fx_, fy = fy_, cx = cx_, cy = cy_, ifx = 1. / fx, ify = 1. / fy;
+    for (int i = 0; i < n; i++) {
+        const double u = xy[2 * i], v = xy[2 * i + 1];
+        double x = (u - cx) * ifx, y = (v - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + 0 * r2 + 0 * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + 0 * r2 + 0 * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+        out[2 * i] = (float)(xx * ww);
+        out[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+/* Frame::ComputeImageBounds, Frame.cc:1121-1170: bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}. */
+void orc_image_bounds(int width, int height, float fx, float fy, float cx, float cy, const float *dist, int n_dist, float *bounds)
+{
+    if (n_dist == 0 || dist[0] == 0.0f) { bounds[0] = 0.f; bounds[1] = (float)width; bounds[2] = 0.f; bounds[3] = (float)height; return; }
+    const float c[8] = {0.f, 0.f, (float)width, 0.f, 0.f, (float)height, (float)width, (float)height};
+    float u[8];
+    orc_undistort_points(c, 4, fx, fy, cx, cy, dist, n_dist, u);
+    bounds[0] = u[0] < u[4] ? u[0] : u[4];
+    bounds[1] = u[2] > u[6] ? u[2] : u[6];
+    bounds[2] = u[1] < u[3] ? u[1] : u[3];
+    bounds[3] = u[5] > u[7] ? u[5] : u[7];
+}
+
+void orc_rgbd_glue(const amos_keypoint *kps, const amos_keypoint *kps_un, int n, const float *depth, size_t depth_stride_elems, int w, int h,
+                   float mbf, float min_x, float max_x, float min_y, float max_y, float *u_right, float *depth_out, int32_t *grid_cell)
+{
+    if (!kps_un) kps_un = kps; /* zero-distortion camera: mvKeysUn == mvKeys */
     const float winv = (float)AMOS_FRAME_GRID_COLS / (float)(max_x - min_x);
     const float hinv = (float)AMOS_FRAME_GRID_ROWS / (float)(max_y - min_y);
     for (int i = 0; i < n; i++) {
@@ -1320,10 +1367,10 @@ void orc_rgbd_glue(const amos_keypoint *kps, int n, const float *depth, size_t d
             const float d = depth[(size_t)(int)v * depth_stride_elems + (int)u];
             if (d > 0) {
                 depth_out[i] = d;
-                u_right[i] = kps[i].x - mbf / d;
+                u_right[i] = kps_un[i].x - mbf / d; /* kpU.pt.x - mbf/d, Frame.cc:1607 */
             }
         }
-        const int px = (int)roundf((kps[i].x - min_x) * winv), py = (int)roundf((kps[i].y - min_y) * hinv);
+        const int px = (int)roundf((kps_un[i].x - min_x) * winv), py = (int)roundf((kps_un[i].y - min_y) * hinv);
         grid_cell[i] = (px < 0 || px >= AMOS_FRAME_GRID_COLS || py < 0 || py >= AMOS_FRAME_GRID_ROWS) ? -1 : px * AMOS_FRAME_GRID_ROWS + py;
     }
 }

@@ -98,8 +98,10 @@ void orc_color_to_gray(const uint8_t *src, size_t sstride, int w, int h, int cha
 /* Tracking's imDepth.convertTo(CV_32F, factor) on one 16-bit value */
 float orc_depth_convert(uint16_t raw, float factor);
 /* Frame::ComputeStereoFromRGBD (Frame.cc:1576-1615) + PosInGrid cell (Frame.cc:1007-1030), mvKeysUn == mvKeys */
-void orc_rgbd_glue(const amos_keypoint *kps, int n, const float *depth, size_t depth_stride_elems, int w, int h, float mbf,
-                   float min_x, float max_x, float min_y, float max_y, float *u_right, float *depth_out, int32_t *grid_cell);
+void orc_undistort_points(const float *xy, int n, float fx, float fy, float cx, float cy, const float *dist, int n_dist, float *out);
+void orc_image_bounds(int width, int height, float fx, float fy, float cx, float cy, const float *dist, int n_dist, float *bounds);
+void orc_rgbd_glue(const amos_keypoint *kps, const amos_keypoint *kps_un, int n, const float *depth, size_t depth_stride_elems, int w, int h,
+                   float mbf, float min_x, float max_x, float min_y, float max_y, float *u_right, float *depth_out, int32_t *grid_cell);
 
 /* ---- gated searches of the tracking thread, over plain frame views ---- */
 /* Frame::GetFeaturesInArea (Frame.cc:894-1003) on a grid built as Frame::AssignFeaturesToGrid does

@@ -275,12 +275,30 @@ def depth_convert(raw_u16, factor):
     return np.array([f(int(v), factor) for v in np.asarray(raw_u16).ravel()], np.float32).reshape(np.shape(raw_u16))
 
 
-def rgbd_glue(kps, depth_f32, mbf, bounds):
+def rgbd_glue(kps, depth_f32, mbf, bounds, kps_un=None):
     kps = np.ascontiguousarray(kps, KP_DTYPE)
+    kun = None if kps_un is None else np.ascontiguousarray(kps_un, KP_DTYPE)
     depth_f32 = np.ascontiguousarray(depth_f32, np.float32)
     n = len(kps)
     ur, dep, cell = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
-    lib().orc_rgbd_glue(_p(kps), C.c_int(n), _p(depth_f32), C.c_size_t(depth_f32.shape[1]), C.c_int(depth_f32.shape[1]),
+    lib().orc_rgbd_glue(_p(kps), _p(kun), C.c_int(n), _p(depth_f32), C.c_size_t(depth_f32.shape[1]), C.c_int(depth_f32.shape[1]),
                         C.c_int(depth_f32.shape[0]), C.c_float(mbf), C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]),
                         C.c_float(bounds[3]), _p(ur), _p(dep), _p(cell))
     return ur, dep, cell
+
+
+def undistort_points(xy, fx, fy, cx, cy, dist):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    dist = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros_like(xy)
+    lib().orc_undistort_points(_p(xy), C.c_int(len(xy)), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), _p(dist),
+                               C.c_int(len(dist)), _p(out))
+    return out
+
+
+def image_bounds(width, height, fx, fy, cx, cy, dist):
+    dist = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros(4, np.float32)
+    lib().orc_image_bounds(C.c_int(width), C.c_int(height), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), _p(dist),
+                           C.c_int(len(dist)), _p(out))
+    return tuple(float(v) for v in out)

@@ -315,6 +315,56 @@ def test_color_import_and_rgbd_glue(gpu_lib, ob, synth, channels, rgb):
         assert (ur > 0).sum() > m // 2
 
 
+def test_undistort_bounds_and_glue_with_distortion(gpu_lib, ob, synth):
+    """8f-1: UndistortKeyPoints + ComputeImageBounds + ComputeStereoFromRGBD / grid cells with a distorted camera (TUM1)."""
+    import torch
+    n = 2
+    fx, fy, cx, cy = 517.306408, 516.469215, 318.643040, 255.313989
+    dist = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+    rng = np.random.default_rng(31)
+    frames = synth.frames(11, 0, n)
+    depth = (0.5 + 3.0 * rng.random((n, 480, 640))).astype(np.float32)
+    depth[rng.random(depth.shape) < 0.2] = 0
+    bounds = gpu_lib.image_bounds(640, 480, fx, fy, cx, cy, dist)
+    assert bounds == ob.image_bounds(640, 480, fx, fy, cx, cy, dist)
+    assert gpu_lib.image_bounds(640, 480, fx, fy, cx, cy, dist[:0]) == (0.0, 640.0, 0.0, 480.0)
+    ext = gpu_lib.OrbExtractor(max_batch=n)
+    d_frames, d_depth = torch.from_numpy(frames).cuda(), torch.from_numpy(depth).cuda()
+    torch.cuda.synchronize()
+    ext.extract_batch_device(d_frames.data_ptr(), 480 * 640, 640, 640, 480, n)
+    _, _, _, cap = ext.batch_results_device()
+    d_un = torch.zeros((n, cap, 7), dtype=torch.float32, device="cuda")
+    d_ur = torch.zeros((n, cap), dtype=torch.float32, device="cuda")
+    d_dep = torch.zeros_like(d_ur)
+    d_cell = torch.zeros((n, cap), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ext.undistort_batch_device(fx, fy, cx, cy, dist, d_un.data_ptr())
+    ext.rgbd_glue_batch_device(d_depth.data_ptr(), False, 1.0, 480 * 640 * 4, 640 * 4, 40.0, bounds, d_ur.data_ptr(), d_dep.data_ptr(),
+                               d_cell.data_ptr(), d_kps_un=d_un.data_ptr())
+    ext.sync()
+    torch.cuda.synchronize()
+    un = d_un.cpu().numpy().view(np.uint8).reshape(n, cap, 28)
+    for f in range(n):
+        kps, _ = ext.batch_fetch(f)
+        m = len(kps)
+        want = kps.copy()
+        xy = ob.undistort_points(np.stack([kps["x"], kps["y"]], 1), fx, fy, cx, cy, dist)
+        want["x"], want["y"] = xy[:, 0], xy[:, 1]
+        got = np.frombuffer(un[f, :m].tobytes(), ob.KP_DTYPE)
+        _same(got, want, "mvKeysUn")
+        assert np.abs(want["x"] - kps["x"]).max() > 0.5
+        ur, dep, cell = ob.rgbd_glue(kps, depth[f], 40.0, bounds, kps_un=want)
+        _same(d_ur[f, :m].cpu().numpy(), ur, "mvuRight")
+        _same(d_dep[f, :m].cpu().numpy(), dep, "mvDepth")
+        _same(d_cell[f, :m].cpu().numpy(), cell, "grid cell")
+    # k1 == 0: mvKeysUn = mvKeys
+    ext.undistort_batch_device(fx, fy, cx, cy, np.zeros(5, np.float32), d_un.data_ptr())
+    ext.sync()
+    torch.cuda.synchronize()
+    kps, _ = ext.batch_fetch(0)
+    _same(np.frombuffer(d_un.cpu().numpy().view(np.uint8).reshape(n, cap, 28)[0, :len(kps)].tobytes(), ob.KP_DTYPE), kps, "identity")
+
+
 def test_hd_config(gpu_lib, ob, synth):
     """BASELINE.json configs[4] geometry: 1920x1080, 4000 features, 12 levels."""
     img = synth.frame(21, 0, 1080, 1920)

@@ -533,6 +533,31 @@ def test_rgbd_glue_definition(ob):
         assert cell[i] == (px * 48 + py if px < 64 and py < 48 else -1)
 
 
+def test_undistort_points_inverts_the_distortion_model(ob):
+    """cv::undistortPoints restatement: distorting the result with the forward Brown model returns the input
+    (5 fixed-point iterations converge to < 1e-3 px for TUM1-like coefficients), k1 == 0 is the identity."""
+    fx, fy, cx, cy = 517.306408, 516.469215, 318.643040, 255.313989         # TUM1.yaml
+    dist = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+    rng = np.random.default_rng(3)
+    pts = np.stack([rng.uniform(0, 640, 500), rng.uniform(0, 480, 500)], 1).astype(np.float32)
+    und = ob.undistort_points(pts, fx, fy, cx, cy, dist)
+    k1, k2, p1, p2, k3 = (float(v) for v in dist)
+    x, y = (und[:, 0].astype(np.float64) - np.float32(cx)) / np.float32(fx), (und[:, 1].astype(np.float64) - np.float32(cy)) / np.float32(fy)
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 ** 3
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    back = np.stack([xd * np.float32(fx) + np.float32(cx), yd * np.float32(fy) + np.float32(cy)], 1)
+    assert np.abs(back - pts).max() < 0.05
+    assert np.abs(und - pts).max() > 1.0                                      # the coefficients do something
+    assert np.array_equal(ob.undistort_points(pts, fx, fy, cx, cy, np.zeros(5, np.float32)), pts)
+    assert np.array_equal(ob.undistort_points(pts, fx, fy, cx, cy, np.zeros(0, np.float32)), pts)
+    b = ob.image_bounds(640, 480, fx, fy, cx, cy, dist)
+    c = ob.undistort_points(np.array([[0, 0], [640, 0], [0, 480], [640, 480]], np.float32), fx, fy, cx, cy, dist)
+    assert b == (min(c[0, 0], c[2, 0]), max(c[1, 0], c[3, 0]), min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1]))
+    assert ob.image_bounds(640, 480, fx, fy, cx, cy, np.zeros(5, np.float32)) == (0.0, 640.0, 0.0, 480.0)
+
+
 # ------------------------------------------------------------------------------------ golden fixtures
 
 

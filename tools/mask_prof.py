@@ -29,3 +29,17 @@ with torch.no_grad():
     print("detect x16              ms", round(T(lambda: [mask.detect(pred, k) for k in range(16)]), 2))
     dets = [mask.detect(pred, k) for k in range(16)]
     print("person_mask x16         ms", round(T(lambda: [mask.person_mask(d, 640, 480) for d in dets]), 2))
+    # memory-format / MIOpen search / batch-size experiments for the fp32 forward
+    for bs in (16, 32):
+        xb = torch.randn(bs, 3, 550, 550, device="cuda:0")
+        print(f"net fwd {bs} fp32 nchw       ms", round(T(lambda: eng.net(xb)), 2), flush=True)
+    torch.backends.cudnn.benchmark = True
+    xb = torch.randn(16, 3, 550, 550, device="cuda:0")
+    print("net fwd 16 fp32 benchmark  ms", round(T(lambda: eng.net(xb)), 2), flush=True)
+    eng.net.to(memory_format=torch.channels_last)
+    xcl = xb.contiguous(memory_format=torch.channels_last)
+    print("net fwd 16 fp32 NHWC+bench ms", round(T(lambda: eng.net(xcl)), 2), flush=True)
+    ref = eng.net.to(memory_format=torch.contiguous_format)(xb)
+    out = eng.net.to(memory_format=torch.channels_last)(xcl)
+    for k in ("loc", "conf", "mask", "proto"):
+        print("  NHWC vs NCHW max abs diff", k, float((ref[k].float() - out[k].float()).abs().max()), flush=True)
