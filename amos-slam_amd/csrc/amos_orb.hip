@@ -346,7 +346,8 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
     AMOS_HIP_CHECK(hipEventRecord(h->evJoin, h->streamB));
     h->blurDone = true;
     if (ev) (void)hipEventRecord(ev[3], h->stream);
-    hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid((g.totalCells + 3) / 4, nFrames)), dim3(256), 4 * (size_t)g.fastWaveBytes, h->stream,
+    hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid((g.totalCells + kFastCellsPerGroup - 1) / kFastCellsPerGroup, nFrames)), dim3(64 * kFastCellsPerGroup),
+                       kFastCellsPerGroup * (size_t)g.fastWaveBytes, h->stream,
                        h->dPyr, h->dGeom, h->dCells, h->dSlotCount, h->dSlots, nFrames);
     if (ev) (void)hipEventRecord(ev[4], h->stream);
     const size_t lds = oct_lds_bytes(h->octNC, h->octSC);
@@ -369,7 +370,7 @@ static int launch_describe(amos_orb *h, int nFrames)
     hipEvent_t *ev = (h->maxRecords > 0 && h->nRecords < h->maxRecords) ? &h->events[(size_t)h->nRecords * (kTimingEvents)] : nullptr;
     AMOS_HIP_CHECK(hipStreamWaitEvent(h->stream, h->evJoin, 0));  // join: blurred planes ready
     if (ev) (void)hipEventRecord(ev[7], h->stream);
-    hipLaunchKernelGGL(k_describe, dim3(xcd_grid((g.kpLevelTotal + 15) / 16, nFrames)), dim3(256), 0, h->stream, h->dBlur, h->dGeom,
+    hipLaunchKernelGGL(k_describe, dim3(xcd_grid((g.kpLevelTotal + kDescKps - 1) / kDescKps, nFrames)), dim3(kDescKps * 16), 0, h->stream, h->dBlur, h->dGeom,
                        h->dLvKps, h->dLvCount, h->dOutKps, h->dOutDesc, h->dOutCount, nFrames);
     if (ev) { (void)hipEventRecord(ev[8], h->stream); h->nRecords++; }
     AMOS_HIP_CHECK(hipGetLastError());

@@ -436,7 +436,12 @@ __device__ __forceinline__ void fast_score_chunk(const uint8_t *tile, int tileSt
     }
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
+#ifndef AMOS_FAST_CELLS_PER_GROUP
+#define AMOS_FAST_CELLS_PER_GROUP 4
+#endif
+constexpr int kFastCellsPerGroup = AMOS_FAST_CELLS_PER_GROUP;  // waves (= cells) per work-group
+
+__global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
                                                    const Cell *__restrict__ cells, int *__restrict__ slotCount,
                                                    uint32_t *__restrict__ slots, int nFrames)
 {
@@ -445,8 +450,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     // bases live in SGPRs and the per-cell loops are scalar loops
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int frame, chunk;
-    if (!xcd_frame_chunk(blockIdx.x, (g->totalCells + 3) >> 2, nFrames, frame, chunk)) return;
-    const int cellIdx = chunk * 4 + wave;
+    if (!xcd_frame_chunk(blockIdx.x, (g->totalCells + kFastCellsPerGroup - 1) / kFastCellsPerGroup, nFrames, frame, chunk)) return;
+    const int cellIdx = chunk * kFastCellsPerGroup + wave;
     if (cellIdx >= g->totalCells) return;  // wave-uniform; no work-group barrier below
     const Cell c = cells[cellIdx];
     const LevelGeom &lg = g->lv[c.level];
@@ -1135,12 +1140,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const int strip = local / lg.blurGroups;
     const int x = (local - strip * lg.blurGroups) * 8, y0 = strip * kBlurStrip;
     const int stride = lg.stride, planeRows = lg.h + 2 * kEdge;
-    // both planes from their first byte (row -19, column -kPadLeft)
-    const uint8_t *srcPlane = level_origin(pyr, g, frame, level) - kEdge * stride - kPadLeft;
-    uint8_t *dstPlane = level_origin(blur, g, frame, level) - kEdge * stride - kPadLeft;
-    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(srcPlane), 0, planeRows * stride, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(dstPlane, 0, planeRows * stride, 0x00020000);
-    const int colIn = x - 4 + kPadLeft, colOut = x + kPadLeft;
+    // One descriptor per frame (wave-uniform: a wave may straddle two levels, so the level's plane offset
+    // travels in the per-lane byte offset instead).  Offsets count from the frame's first pyramid byte.
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(pyr) + (size_t)frame * g->frameBytes, 0, (int)g->frameBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(blur + (size_t)frame * g->frameBytes, 0, (int)g->frameBytes, 0x00020000);
+    const int colIn = lg.planeOff + x - 4 + kPadLeft, colOut = lg.planeOff + x + kPadLeft;
     const int lastOff = __mul24(planeRows - 1, stride) + colIn;   // last plane row (y = h + 18)
     int inOff = __mul24(y0 - 3 + kEdge, stride) + colIn;          // row y0 - 3 >= -3
     int outOff = __mul24(y0 + kEdge, stride) + colOut;
@@ -1277,22 +1281,24 @@ constexpr int kDescR = 18;          // |rotated offset| <= sqrt(13^2 + 13^2) = 1
 constexpr int kDescRowBytes = 48;   // columns -18 .. +29 as three 16-byte pieces
 constexpr int kDescRows = 2 * kDescR + 1;
 
-__global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ blur, const Geom *__restrict__ g,
-                                                 const amos_keypoint *__restrict__ lvKps,
-                                                 const int *__restrict__ lvCount,
-                                                 amos_keypoint *__restrict__ outKps, uint8_t *__restrict__ outDesc,
-                                                 int *__restrict__ outCount, int nFrames)
+constexpr int kDescKps = 16;  // keypoints per work-group (16 lanes each): 18 KB of LDS, so several groups share a CU with FAST's tiles
+
+__global__ __launch_bounds__(kDescKps * 16) void k_describe(const uint8_t *__restrict__ blur, const Geom *__restrict__ g,
+                                                           const amos_keypoint *__restrict__ lvKps,
+                                                           const int *__restrict__ lvCount,
+                                                           amos_keypoint *__restrict__ outKps, uint8_t *__restrict__ outDesc,
+                                                           int *__restrict__ outCount, int nFrames)
 {
     __shared__ float4 pat[256];
-    __shared__ uint4 patch[16][kDescRows * 3];
+    __shared__ uint4 patch[kDescKps][kDescRows * 3];
     int frame, chunk;
-    if (!xcd_frame_chunk(blockIdx.x, (g->kpLevelTotal + 15) >> 4, nFrames, frame, chunk)) return;
-    {
-        const signed char *p = &c_pattern[threadIdx.x * 4];
-        pat[threadIdx.x] = float4{(float)p[0], (float)p[1], (float)p[2], (float)p[3]};
+    if (!xcd_frame_chunk(blockIdx.x, (g->kpLevelTotal + kDescKps - 1) / kDescKps, nFrames, frame, chunk)) return;
+    for (int e = threadIdx.x; e < 256; e += kDescKps * 16) {
+        const signed char *p = &c_pattern[e * 4];
+        pat[e] = float4{(float)p[0], (float)p[1], (float)p[2], (float)p[3]};
     }
     const int lane = threadIdx.x & 63, j = threadIdx.x & 15, sub = lane >> 4, grp = threadIdx.x >> 4;
-    const int slot = chunk * 16 + grp;
+    const int slot = chunk * kDescKps + grp;
     const int *cnt = lvCount + frame * g->nLevels;
     if (slot == 0 && j == 0) {
         int total = 0;
