@@ -112,6 +112,14 @@ void ORBmatcher::ListDistances(const amos_frame_view &train, const uint8_t *quer
           "amos_match_list_distances");
 }
 
+void ORBmatcher::ListDistances(const uint8_t *train, int nt, const uint8_t *queries, int nq, const std::vector<int> &off,
+                               const std::vector<int> &idx, std::vector<uint16_t> &dist)
+{
+    dist.resize(idx.size());
+    if (idx.empty()) return;
+    Check(amos_match_list_distances(mpMatch, queries, nq, train, nt, off.data(), idx.data(), dist.data()), "amos_match_list_distances");
+}
+
 float ORBmatcher::RadiusByViewingCos(const float &viewCos)
 {
     if (viewCos > 0.998)
@@ -255,6 +263,154 @@ int ORBmatcher::SearchByProjection(const FeatureGrid &Fg, const vector<amos_map_
             vnCurMatch[bestIdx] = iMP;
             vbCurHasObs[bestIdx] = mp.has_obs != 0;
             nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+// ORBmatcher.cc:1731-1863 (relocalisation): window nPredictedLevel-1 .. +1, ANY occupied feature is skipped,
+// best only, accepted at bestDist <= ORBdist, rotation histogram pruning unconditional.
+int ORBmatcher::SearchByProjection(const FeatureGrid &CurrentFrame, const vector<amos_kf_query> &vKFPoints, vector<int> &vnCurMatch,
+                                   const vector<float> &mvScaleFactors, const float th, const int ORBdist)
+{
+    const amos_frame_view &F = CurrentFrame.Frame();
+    const int nq = (int)vKFPoints.size();
+    vector<int> off(nq + 1, 0), idx;
+    vector<uint8_t> qdesc((size_t)nq * 32);
+    for (int i = 0; i < nq; i++) {
+        const amos_kf_query &p = vKFPoints[i];
+        memcpy(&qdesc[(size_t)i * 32], p.desc, 32);
+        const int nPredictedLevel = p.level;
+        const float radius = th * mvScaleFactors[nPredictedLevel];
+        const vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(p.u, p.v, radius, nPredictedLevel - 1, nPredictedLevel + 1);
+        for (size_t k = 0; k < vIndices2.size(); k++) idx.push_back((int)vIndices2[k]);
+        off[i + 1] = (int)idx.size();
+    }
+    vector<uint16_t> dist;
+    ListDistances(F, qdesc.data(), nq, off, idx, dist);
+    int nmatches = 0;
+    vector<int> rotHist[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+    const float factor = HISTO_LENGTH / 360.0f;
+    for (int i = 0; i < nq; i++) {
+        if (off[i] == off[i + 1]) continue;  // :1802-1803
+        int bestDist = 256;
+        int bestIdx2 = -1;
+        for (int k = off[i]; k < off[i + 1]; k++) {
+            const int i2 = idx[k];
+            if (vnCurMatch[i2] != AMOS_MATCH_FREE) continue;  // :1816-1817
+            const int d = dist[k];
+            if (d < bestDist) {
+                bestDist = d;
+                bestIdx2 = i2;
+            }
+        }
+        if (bestDist <= ORBdist) {
+            vnCurMatch[bestIdx2] = i;
+            nmatches++;
+            if (mbCheckOrientation) {
+                float rot = vKFPoints[i].angle - F.keys_un[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i != ind1 && i != ind2 && i != ind3) {
+                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                    vnCurMatch[rotHist[i][j]] = AMOS_MATCH_FREE;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    return nmatches;
+}
+
+// ORBmatcher.cc:230-382.  Candidates of a keyframe feature = the frame's features in the same vocabulary node,
+// in the FeatureVector's order; the two-iterator merge over the ascending node ids is the reference's
+// (lower_bound on a std::map = first node id >= the other side's).
+int ORBmatcher::SearchByBoW(const amos_bow_view &KF, const amos_bow_view &F, vector<int> &vnMatchesF)
+{
+    vnMatchesF.assign(F.n, -1);
+    // 1. candidate lists, in the order the reference visits the keyframe features
+    vector<int> qKF, off(1, 0), idx;
+    {
+        int a = 0, b = 0;
+        while (a < KF.n_nodes && b < F.n_nodes) {
+            if (KF.node_ids[a] == F.node_ids[b]) {
+                for (int k = KF.node_off[a]; k < KF.node_off[a + 1]; k++) {
+                    const int realIdxKF = KF.node_idx[k];
+                    if (KF.has_point && !KF.has_point[realIdxKF]) continue;  // !pMP || pMP->isBad()
+                    qKF.push_back(realIdxKF);
+                    for (int m = F.node_off[b]; m < F.node_off[b + 1]; m++) idx.push_back(F.node_idx[m]);
+                    off.push_back((int)idx.size());
+                }
+                a++;
+                b++;
+            } else if (KF.node_ids[a] < F.node_ids[b]) {
+                while (a < KF.n_nodes && KF.node_ids[a] < F.node_ids[b]) a++;  // lower_bound(Fit->first)
+            } else {
+                while (b < F.n_nodes && F.node_ids[b] < KF.node_ids[a]) b++;
+            }
+        }
+    }
+    const int nq = (int)qKF.size();
+    vector<uint8_t> qdesc((size_t)nq * 32);
+    for (int i = 0; i < nq; i++) memcpy(&qdesc[(size_t)i * 32], KF.descriptors + (size_t)qKF[i] * 32, 32);
+    // 2. all candidate distances in one GPU call
+    vector<uint16_t> dist;
+    ListDistances(F.descriptors, F.n, qdesc.data(), nq, off, idx, dist);
+    // 3. the reference's greedy loop
+    int nmatches = 0;
+    vector<int> rotHist[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+    const float factor = HISTO_LENGTH / 360.0f;
+    for (int i = 0; i < nq; i++) {
+        const int realIdxKF = qKF[i];
+        int bestDist1 = 256;
+        int bestIdxF = -1;
+        int bestDist2 = 256;
+        for (int k = off[i]; k < off[i + 1]; k++) {
+            const int realIdxF = idx[k];
+            if (vnMatchesF[realIdxF] >= 0) continue;  // :288-289
+            const int d = dist[k];
+            if (d < bestDist1) {
+                bestDist2 = bestDist1;
+                bestDist1 = d;
+                bestIdxF = realIdxF;
+            } else if (d < bestDist2) {
+                bestDist2 = d;
+            }
+        }
+        if (bestDist1 <= TH_LOW) {
+            if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+                vnMatchesF[bestIdxF] = realIdxKF;
+                if (mbCheckOrientation) {
+                    float rot = KF.keys[realIdxKF].angle - F.keys[bestIdxF].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(bestIdxF);
+                }
+                nmatches++;
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                vnMatchesF[rotHist[i][j]] = -1;
+                nmatches--;
+            }
         }
     }
     return nmatches;

@@ -64,6 +64,16 @@ public:
     int SearchByProjection(const FeatureGrid &F, const std::vector<amos_map_query> &vpMapPoints, std::vector<int> &vnCurMatch,
                            std::vector<bool> &vbCurHasObs, const std::vector<float> &mvScaleFactors, const float th = 3);
 
+    // ORBmatcher.cc:1731-1863, SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist)
+    // (relocalisation).  vnCurMatch[i2]: AMOS_MATCH_FREE, AMOS_MATCH_TAKEN (CurrentFrame.mvpMapPoints[i2] set on
+    // entry) or, on return, the index of the query assigned to feature i2.
+    int SearchByProjection(const FeatureGrid &CurrentFrame, const std::vector<amos_kf_query> &vKFPoints, std::vector<int> &vnCurMatch,
+                           const std::vector<float> &mvScaleFactors, const float th, const int ORBdist);
+
+    // ORBmatcher.cc:230-382, SearchByBoW(KeyFrame *pKF, Frame &F, vpMapPointMatches) (TrackReferenceKeyFrame,
+    // Relocalization).  vnMatchesF[iF] = index of the keyframe feature whose map point F's feature iF receives, or -1.
+    int SearchByBoW(const amos_bow_view &KF, const amos_bow_view &F, std::vector<int> &vnMatchesF);
+
     // ORBmatcher.cc:515-643, SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
     int SearchForInitialization(const amos_frame_view &F1, const FeatureGrid &F2, std::vector<cv::Point2f> &vbPrevMatched,
                                 std::vector<int> &vnMatches12, int windowSize = 10);
@@ -78,6 +88,8 @@ public:
 protected:
     float RadiusByViewingCos(const float &viewCos);
     void ListDistances(const amos_frame_view &train, const uint8_t *queries, int nq, const std::vector<int> &off, const std::vector<int> &idx,
+                       std::vector<uint16_t> &dist);
+    void ListDistances(const uint8_t *train, int nt, const uint8_t *queries, int nq, const std::vector<int> &off, const std::vector<int> &idx,
                        std::vector<uint16_t> &dist);
 
     float mfNNratio;

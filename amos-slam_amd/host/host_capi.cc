@@ -141,6 +141,32 @@ int amos_host_search_by_projection_points(const amos_frame_view *f, const amos_m
     AMOS_HOST_CATCH
 }
 
+int amos_host_search_by_projection_kf(const amos_frame_view *cur, const amos_kf_query *q, int nq, int32_t *cur_match, const float *scale_factors,
+                                      int nsf, float th, int orb_dist, float nnratio, int check_orientation)
+{
+    AMOS_HOST_TRY
+    FeatureGrid grid(*cur);
+    ORBmatcher matcher(nnratio, check_orientation != 0);
+    std::vector<amos_kf_query> pts(q, q + nq);
+    std::vector<int> match(cur_match, cur_match + cur->n);
+    std::vector<float> sf(scale_factors, scale_factors + nsf);
+    const int r = matcher.SearchByProjection(grid, pts, match, sf, th, orb_dist);
+    std::memcpy(cur_match, match.data(), sizeof(int) * cur->n);
+    return r;
+    AMOS_HOST_CATCH
+}
+
+int amos_host_search_by_bow(const amos_bow_view *kf, const amos_bow_view *f, int32_t *matches_f, float nnratio, int check_orientation)
+{
+    AMOS_HOST_TRY
+    ORBmatcher matcher(nnratio, check_orientation != 0);
+    std::vector<int> m;
+    const int r = matcher.SearchByBoW(*kf, *f, m);
+    for (int i = 0; i < f->n; i++) matches_f[i] = m[i];
+    return r;
+    AMOS_HOST_CATCH
+}
+
 int amos_host_search_for_initialization(const amos_frame_view *f1, const amos_frame_view *f2, float *prev_matched, int32_t *matches12,
                                         int window_size, float nnratio, int check_orientation)
 {

@@ -49,6 +49,33 @@ typedef struct amos_map_query {
     uint8_t desc[32];
 } amos_map_query;
 
+/* One map point of a keyframe projected into the current frame by
+ * ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) -- the
+ * relocalisation search (ORBmatcher.cc:1731-1863): already filtered for !isBad(), !sAlreadyFound, image bounds
+ * and the distance-invariance range (:1758-1790). */
+typedef struct amos_kf_query {
+    float u, v;        /* projection (:1769-1770) */
+    int32_t level;     /* nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame) */
+    float angle;       /* pKF->mvKeysUn[i].angle */
+    uint8_t desc[32];  /* pMP->GetDescriptor() */
+} amos_kf_query;
+#define AMOS_MATCH_FREE (-1)   /* CurrentFrame.mvpMapPoints[i2] == NULL */
+#define AMOS_MATCH_TAKEN (-2)  /* occupied on entry by a map point that is not one of the queries */
+
+/* What ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vpMapPointMatches) reads of either side
+ * (ORBmatcher.cc:230-382): descriptors, keypoint angles, the DBoW2::FeatureVector (node id -> feature indices,
+ * node ids ascending as std::map iterates them) and, for the keyframe, which features carry a good map point. */
+typedef struct amos_bow_view {
+    int32_t n;                    /* features */
+    const amos_keypoint *keys;    /* KF: mvKeysUn, F: mvKeys (only .angle is read) */
+    const uint8_t *descriptors;   /* n x 32 */
+    const uint8_t *has_point;     /* KF: vpMapPointsKF[i] && !isBad(); NULL = all; ignored for F */
+    int32_t n_nodes;
+    const uint32_t *node_ids;     /* ascending */
+    const int32_t *node_off;      /* n_nodes + 1 */
+    const int32_t *node_idx;      /* feature indices, in the FeatureVector's order */
+} amos_bow_view;
+
 #ifdef __cplusplus
 }
 #endif

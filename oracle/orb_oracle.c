@@ -1410,3 +1410,112 @@ void orc_window_best2(const amos_frame_view *train, const amos_keypoint *qk, con
     free(cand);
     grid_free(&g);
 }
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist), ORBmatcher.cc:1731-1863,
+ * from the candidate search on (the projection / filtering of :1745-1795 is the caller's, see amos_kf_query). */
+int orc_search_by_projection_kf(const amos_frame_view *cur, const amos_kf_query *q, int nq, int32_t *cur_match,
+                                const float *scale_factors, float th, int orb_dist, int check_orientation)
+{
+    ogrid g = grid_build(cur);
+    int nmatches = 0;
+    int *hist[AMOS_HISTO_LENGTH], hn[AMOS_HISTO_LENGTH];
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) { hist[i] = (int *)malloc(sizeof(int) * (nq + 1)); hn[i] = 0; }
+    const float factor = AMOS_HISTO_LENGTH / 360.0f;
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (cur->n + 1));
+    for (int i = 0; i < nq; i++) {
+        const int lvl = q[i].level;
+        const float radius = th * scale_factors[lvl];
+        const int nc = grid_area(&g, cur, q[i].u, q[i].v, radius, lvl - 1, lvl + 1, cand, cur->n);
+        if (nc == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            if (cur_match[i2] != AMOS_MATCH_FREE) continue; /* :1816-1817 */
+            const int dist = orc_descriptor_distance(q[i].desc, cur->descriptors + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= orb_dist) {
+            cur_match[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                float rot = q[i].angle - cur->keys_un[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)round(rot * factor);
+                if (bin == AMOS_HISTO_LENGTH) bin = 0;
+                hist[bin][hn[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_orientation) {
+        int32_t sizes[AMOS_HISTO_LENGTH];
+        for (int i = 0; i < AMOS_HISTO_LENGTH; i++) sizes[i] = hn[i];
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(sizes, AMOS_HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < AMOS_HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < hn[i]; j++) { cur_match[hist[i][j]] = AMOS_MATCH_FREE; nmatches--; }
+        }
+    }
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) free(hist[i]);
+    free(cand);
+    grid_free(&g);
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vpMapPointMatches), ORBmatcher.cc:230-382. */
+int orc_search_by_bow(const amos_bow_view *kf, const amos_bow_view *f, int32_t *matches_f, float nn_ratio, int check_orientation)
+{
+    for (int i = 0; i < f->n; i++) matches_f[i] = -1;
+    int nmatches = 0;
+    int *hist[AMOS_HISTO_LENGTH], hn[AMOS_HISTO_LENGTH];
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) { hist[i] = (int *)malloc(sizeof(int) * (f->n + 1)); hn[i] = 0; }
+    const float factor = AMOS_HISTO_LENGTH / 360.0f;
+    int a = 0, b = 0;
+    while (a < kf->n_nodes && b < f->n_nodes) {
+        if (kf->node_ids[a] == f->node_ids[b]) {
+            for (int ik = kf->node_off[a]; ik < kf->node_off[a + 1]; ik++) {
+                const int realIdxKF = kf->node_idx[ik];
+                if (kf->has_point && !kf->has_point[realIdxKF]) continue;
+                const uint8_t *dKF = kf->descriptors + (size_t)realIdxKF * 32;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int jf = f->node_off[b]; jf < f->node_off[b + 1]; jf++) {
+                    const int realIdxF = f->node_idx[jf];
+                    if (matches_f[realIdxF] >= 0) continue;
+                    const int dist = orc_descriptor_distance(dKF, f->descriptors + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= AMOS_TH_LOW) {
+                    if ((float)bestDist1 < nn_ratio * (float)bestDist2) {
+                        matches_f[bestIdxF] = realIdxKF;
+                        if (check_orientation) {
+                            float rot = kf->keys[realIdxKF].angle - f->keys[bestIdxF].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)round(rot * factor);
+                            if (bin == AMOS_HISTO_LENGTH) bin = 0;
+                            hist[bin][hn[bin]++] = bestIdxF;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (kf->node_ids[a] < f->node_ids[b]) {
+            while (a < kf->n_nodes && kf->node_ids[a] < f->node_ids[b]) a++;
+        } else {
+            while (b < f->n_nodes && f->node_ids[b] < kf->node_ids[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int32_t sizes[AMOS_HISTO_LENGTH];
+        for (int i = 0; i < AMOS_HISTO_LENGTH; i++) sizes[i] = hn[i];
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(sizes, AMOS_HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < AMOS_HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < hn[i]; j++) { matches_f[hist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) free(hist[i]);
+    return nmatches;
+}

@@ -123,6 +123,10 @@ void orc_window_best2(const amos_frame_view *train, const amos_keypoint *qk, con
                       const float *query_invz, const float *scale_factors, float th, float mbf, int mode, int init_dist,
                       amos_best2 *out);
 
+int orc_search_by_projection_kf(const amos_frame_view *cur, const amos_kf_query *q, int nq, int32_t *cur_match,
+                                const float *scale_factors, float th, int orb_dist, int check_orientation);
+int orc_search_by_bow(const amos_bow_view *kf, const amos_bow_view *f, int32_t *matches_f, float nn_ratio, int check_orientation);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,32 @@ MAP_QUERY = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), 
                       ("has_obs", "<i4"), ("desc", "u1", (32,))])
 
 
+KF_QUERY = np.dtype([("u", "<f4"), ("v", "<f4"), ("level", "<i4"), ("angle", "<f4"), ("desc", "u1", (32,))])
+MATCH_FREE, MATCH_TAKEN = -1, -2
+
+
+class BowView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("keys", C.c_void_p), ("descriptors", C.c_void_p), ("has_point", C.c_void_p), ("n_nodes", C.c_int32),
+                ("node_ids", C.c_void_p), ("node_off", C.c_void_p), ("node_idx", C.c_void_p)]
+
+
+def bow_view(kps, desc, nodes, has_point=None):
+    """nodes: dict node id -> list of feature indices (a DBoW2::FeatureVector).  Returns (view, keepalive)."""
+    kps = np.ascontiguousarray(kps, KP)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    ids = np.array(sorted(nodes), np.uint32)
+    off = np.zeros(len(ids) + 1, np.int32)
+    idx = []
+    for k, nid in enumerate(ids):
+        idx.extend(nodes[int(nid)])
+        off[k + 1] = len(idx)
+    idx = np.array(idx if idx else [0], np.int32)
+    hp = None if has_point is None else np.ascontiguousarray(has_point, np.uint8)
+    v = BowView(len(kps), kps.ctypes.data, desc.ctypes.data, hp.ctypes.data if hp is not None else None, len(ids), ids.ctypes.data,
+                off.ctypes.data, idx.ctypes.data)
+    return v, (kps, desc, ids, off, idx, hp)
+
+
 class FrameView(C.Structure):
     _fields_ = [("n", C.c_int32), ("keys_un", C.c_void_p), ("descriptors", C.c_void_p), ("u_right", C.c_void_p),
                 ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
@@ -144,6 +170,28 @@ def search_points(which, view, queries, cur_match, cur_has_obs, scale_factors, t
         r = ob.lib().orc_search_by_projection_points(C.byref(view), _p(queries), C.c_int(len(queries)), _p(match), _p(obs), _p(sf),
                                                      C.c_float(th), C.c_float(nnratio))
     return r, match, obs
+
+
+def search_kf(which, view, queries, cur_match, scale_factors, th, orb_dist, nnratio=0.9, check_ori=True):
+    queries = np.ascontiguousarray(queries, KF_QUERY)
+    match = np.ascontiguousarray(cur_match, np.int32).copy()
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    if which == "host":
+        r = _chk(host().amos_host_search_by_projection_kf(C.byref(view), _p(queries), C.c_int(len(queries)), _p(match), _p(sf), C.c_int(len(sf)),
+                                                          C.c_float(th), C.c_int(orb_dist), C.c_float(nnratio), C.c_int(check_ori)))
+    else:
+        r = ob.lib().orc_search_by_projection_kf(C.byref(view), _p(queries), C.c_int(len(queries)), _p(match), _p(sf), C.c_float(th),
+                                                 C.c_int(orb_dist), C.c_int(check_ori))
+    return r, match
+
+
+def search_bow(which, kf_view, f_view, nnratio=0.7, check_ori=True):
+    m = np.zeros(max(f_view.n, 1), np.int32)
+    if which == "host":
+        r = _chk(host().amos_host_search_by_bow(C.byref(kf_view), C.byref(f_view), _p(m), C.c_float(nnratio), C.c_int(check_ori)))
+    else:
+        r = ob.lib().orc_search_by_bow(C.byref(kf_view), C.byref(f_view), _p(m), C.c_float(nnratio), C.c_int(check_ori))
+    return r, m[:f_view.n]
 
 
 def search_init(which, view1, view2, prev_matched, window=100, nnratio=0.9, check_ori=True):

@@ -154,6 +154,52 @@ def test_search_for_initialization(hb, ob, synth):
     assert (mh[k0["octave"] > 0] == -1).all()  # only level-0 features take part
 
 
+def test_search_by_projection_keyframe(hb, ob, synth):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) -- relocalisation."""
+    orc = ob.Oracle()
+    k0, d0 = orc.extract(synth.frame(21, 2))
+    k1, d1 = orc.extract(synth.frame(21, 3))
+    sf = orc.tables()["scale"]
+    rng = np.random.default_rng(5)
+    view, keep = hb.frame_view(k1, d1)
+    q = np.zeros(len(k0), hb.KF_QUERY)
+    q["u"] = k0["x"] - 2 + rng.normal(0, 1.5, len(k0)).astype(np.float32)
+    q["v"] = k0["y"] - 1 + rng.normal(0, 1.5, len(k0)).astype(np.float32)
+    q["level"], q["angle"], q["desc"] = k0["octave"], k0["angle"], d0
+    m0 = np.where(rng.random(len(k1)) < 0.1, hb.MATCH_TAKEN, hb.MATCH_FREE).astype(np.int32)
+    for th, orb_dist in ((10.0, 100), (3.0, 64)):
+        n_h, m_h = hb.search_kf("host", view, q, m0, sf, th, orb_dist)
+        n_o, m_o = hb.search_kf("oracle", view, q, m0, sf, th, orb_dist)
+        assert n_h == n_o and np.array_equal(m_h, m_o)
+    assert n_o > 50
+
+
+def test_search_by_bow(hb, ob, synth):
+    """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) over feature vectors (stand-in vocabulary)."""
+    orc = ob.Oracle()
+    k0, d0 = orc.extract(synth.frame(22, 2))
+    k1, d1 = orc.extract(synth.frame(22, 3))
+    rng = np.random.default_rng(6)
+
+    def nodes(desc):
+        ids = (desc[:, 0].astype(np.uint32) >> 2) * 3 + 5
+        out = {}
+        for i in rng.permutation(len(desc)):
+            out.setdefault(int(ids[i]), []).append(int(i))
+        return out
+    n0, n1 = nodes(d0), nodes(d1)
+    for drop in list(n1)[::6]:
+        del n1[drop]
+    has = (rng.random(len(k0)) < 0.85).astype(np.uint8)
+    vkf, keep0 = hb.bow_view(k0, d0, n0, has)
+    vf, keep1 = hb.bow_view(k1, d1, n1)
+    for ratio, ori in ((0.7, True), (0.9, False)):
+        n_h, m_h = hb.search_bow("host", vkf, vf, ratio, ori)
+        n_o, m_o = hb.search_bow("oracle", vkf, vf, ratio, ori)
+        assert n_h == n_o and np.array_equal(m_h, m_o)
+    assert n_o > 30
+
+
 @pytest.mark.parametrize("mode,stereo,shifted", [(0, False, False), (0, True, True), (1, False, True), (2, True, False)])
 def test_resident_grid_and_window_search(gpu_lib, ob, synth, mode, stereo, shifted):
     """8f-1: AssignFeaturesToGrid + GetFeaturesInArea + best/second loop on resident batch results."""

@@ -154,3 +154,120 @@ def test_search_by_projection_frame_vs_python(frames, fwd, bwd):
     n_p, m_p = py_search_frame(k1, d1, ur, q, m0, sf, 40.0, 12.0, fwd, bwd)
     assert n_o == n_p and np.array_equal(m_o, m_p)
     assert n_o > 20
+
+
+def py_search_kf(kps, desc, q, match, sf, th, orb_dist):
+    """Independent restatement of ORBmatcher.cc:1796-1860."""
+    grid = PyGrid(kps)
+    match = match.copy()
+    n = 0
+    hist = [[] for _ in range(30)]
+    factor = F32(30) / F32(360.0)
+    for i, p in enumerate(q):
+        lvl = int(p["level"])
+        cand = grid.area(p["u"], p["v"], F32(th) * F32(sf[lvl]), lvl - 1, lvl + 1)
+        best, bi = 256, -1
+        for i2 in cand:
+            if match[i2] != -1:
+                continue
+            d = _dist(p["desc"], desc[i2])
+            if d < best:
+                best, bi = d, i2
+        if cand and best <= orb_dist:
+            match[bi] = i
+            n += 1
+            rot = F32(p["angle"]) - F32(kps[bi]["angle"])
+            if rot < 0:
+                rot = F32(rot + F32(360.0))
+            b = _round_half_away(F32(rot * factor))
+            hist[0 if b == 30 else b].append(bi)
+    i1, i2, i3 = _three_maxima([len(h) for h in hist])
+    for b in range(30):
+        if b not in (i1, i2, i3):
+            for j in hist[b]:
+                match[j] = -1
+                n -= 1
+    return n, match
+
+
+def test_search_by_projection_kf_vs_python(frames):
+    k0, d0, k1, d1, sf = frames
+    rng = np.random.default_rng(8)
+    view, keep = hb.frame_view(k1, d1)
+    q = np.zeros(len(k0), hb.KF_QUERY)
+    q["u"] = k0["x"] - 2 + rng.normal(0, 1.5, len(k0)).astype(np.float32)
+    q["v"] = k0["y"] - 1 + rng.normal(0, 1.5, len(k0)).astype(np.float32)
+    q["level"], q["angle"], q["desc"] = k0["octave"], k0["angle"], d0
+    m0 = np.where(rng.random(len(k1)) < 0.15, hb.MATCH_TAKEN, hb.MATCH_FREE).astype(np.int32)
+    for orb_dist in (64, 100):
+        n_o, m_o = hb.search_kf("oracle", view, q, m0, sf, 10.0, orb_dist)
+        n_p, m_p = py_search_kf(k1, d1, q, m0, sf, 10.0, orb_dist)
+        assert n_o == n_p and np.array_equal(m_o, m_p)
+        assert n_o > 20 and (m_o[m0 == hb.MATCH_TAKEN] == hb.MATCH_TAKEN).all()
+
+
+def _fake_vocabulary(desc, bits=7):
+    """A stand-in for DBoW2 node ids: the first `bits` descriptor bits (close descriptors often share a node)."""
+    return (desc[:, 0].astype(np.uint32) >> (8 - bits)) * 3 + 5
+
+
+def _nodes(desc, order_rng):
+    ids = _fake_vocabulary(desc)
+    nodes = {}
+    for i in order_rng.permutation(len(desc)):      # FeatureVector lists are in insertion order, not sorted
+        nodes.setdefault(int(ids[i]), []).append(int(i))
+    return nodes
+
+
+def py_search_bow(kkf, dkf, nkf, has_point, kf_, df, nf, ratio):
+    """Independent restatement of ORBmatcher.cc:230-382 over dict-shaped feature vectors."""
+    match = np.full(len(kf_), -1, np.int32)
+    n = 0
+    hist = [[] for _ in range(30)]
+    factor = F32(30) / F32(360.0)
+    for nid in sorted(set(nkf) & set(nf)):
+        for ikf in nkf[nid]:
+            if not has_point[ikf]:
+                continue
+            b1, b2, bi = 256, 256, -1
+            for i_f in nf[nid]:
+                if match[i_f] >= 0:
+                    continue
+                d = _dist(dkf[ikf], df[i_f])
+                if d < b1:
+                    b2, b1, bi = b1, d, i_f
+                elif d < b2:
+                    b2 = d
+            if b1 <= 50 and F32(b1) < F32(ratio) * F32(b2):
+                match[bi] = ikf
+                rot = F32(kkf[ikf]["angle"]) - F32(kf_[bi]["angle"])
+                if rot < 0:
+                    rot = F32(rot + F32(360.0))
+                b = _round_half_away(F32(rot * factor))
+                hist[0 if b == 30 else b].append(bi)
+                n += 1
+    i1, i2, i3 = _three_maxima([len(h) for h in hist])
+    for b in range(30):
+        if b not in (i1, i2, i3):
+            for j in hist[b]:
+                match[j] = -1
+                n -= 1
+    return n, match
+
+
+def test_search_by_bow_vs_python(frames):
+    k0, d0, k1, d1, _ = frames
+    rng = np.random.default_rng(9)
+    has = (rng.random(len(k0)) < 0.8).astype(np.uint8)
+    n0, n1 = _nodes(d0, rng), _nodes(d1, rng)
+    for drop in list(n1)[::7]:                       # nodes present on one side only exercise the lower_bound branches
+        del n1[drop]
+    for drop in list(n0)[3::9]:
+        del n0[drop]
+    vkf, keep0 = hb.bow_view(k0, d0, n0, has)
+    vf, keep1 = hb.bow_view(k1, d1, n1)
+    for ratio in (0.7, 0.9):
+        n_o, m_o = hb.search_bow("oracle", vkf, vf, ratio)
+        n_p, m_p = py_search_bow(k0, d0, n0, has, k1, d1, n1, ratio)
+        assert n_o == n_p and np.array_equal(m_o, m_p)
+    assert n_o > 10
