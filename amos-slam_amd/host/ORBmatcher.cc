@@ -416,6 +416,351 @@ int ORBmatcher::SearchByBoW(const amos_bow_view &KF, const amos_bow_view &F, vec
     return nmatches;
 }
 
+// Candidate lists of a node-by-node search between two feature vectors (the merge of :673-760 / :835-935):
+// for every feature of side 1 that `take1` accepts, the features of side 2 in the same node, in list order.
+template <typename Take1>
+static void BowCandidates(const amos_bow_view &A, const amos_bow_view &B, Take1 take1, vector<int> &q1, vector<int> &off, vector<int> &idx)
+{
+    q1.clear();
+    idx.clear();
+    off.assign(1, 0);
+    int a = 0, b = 0;
+    while (a < A.n_nodes && b < B.n_nodes) {
+        if (A.node_ids[a] == B.node_ids[b]) {
+            for (int k = A.node_off[a]; k < A.node_off[a + 1]; k++) {
+                const int idx1 = A.node_idx[k];
+                if (!take1(idx1)) continue;
+                q1.push_back(idx1);
+                for (int m = B.node_off[b]; m < B.node_off[b + 1]; m++) idx.push_back(B.node_idx[m]);
+                off.push_back((int)idx.size());
+            }
+            a++;
+            b++;
+        } else if (A.node_ids[a] < B.node_ids[b]) {
+            while (a < A.n_nodes && A.node_ids[a] < B.node_ids[b]) a++;
+        } else {
+            while (b < B.n_nodes && B.node_ids[b] < A.node_ids[a]) b++;
+        }
+    }
+}
+
+// ORBmatcher.cc:656-808
+int ORBmatcher::SearchByBoW(const amos_bow_view &KF1, const amos_bow_view &KF2, vector<int> &vnMatches12, const bool bBothKeyFrames)
+{
+    if (!bBothKeyFrames) return SearchByBoW(KF1, KF2, vnMatches12);
+    vnMatches12.assign(KF1.n, -1);
+    vector<bool> vbMatched2(KF2.n, false);
+    vector<int> q1, off, idx;
+    BowCandidates(KF1, KF2, [&](int i1) { return !KF1.has_point || KF1.has_point[i1]; }, q1, off, idx);
+    const int nq = (int)q1.size();
+    vector<uint8_t> qdesc((size_t)nq * 32);
+    for (int i = 0; i < nq; i++) memcpy(&qdesc[(size_t)i * 32], KF1.descriptors + (size_t)q1[i] * 32, 32);
+    vector<uint16_t> dist;
+    ListDistances(KF2.descriptors, KF2.n, qdesc.data(), nq, off, idx, dist);
+    vector<int> rotHist[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+    const float factor = HISTO_LENGTH / 360.0f;
+    int nmatches = 0;
+    for (int i = 0; i < nq; i++) {
+        const int idx1 = q1[i];
+        int bestDist1 = 256;
+        int bestIdx2 = -1;
+        int bestDist2 = 256;
+        for (int k = off[i]; k < off[i + 1]; k++) {
+            const int idx2 = idx[k];
+            if (vbMatched2[idx2] || (KF2.has_point && !KF2.has_point[idx2])) continue;  // :704-708
+            const int d = dist[k];
+            if (d < bestDist1) {
+                bestDist2 = bestDist1;
+                bestDist1 = d;
+                bestIdx2 = idx2;
+            } else if (d < bestDist2) {
+                bestDist2 = d;
+            }
+        }
+        if (bestDist1 < TH_LOW) {  // strict here, <= in SearchByBoW(KF, F)
+            if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+                vnMatches12[idx1] = bestIdx2;
+                vbMatched2[bestIdx2] = true;
+                if (mbCheckOrientation) {
+                    float rot = KF1.keys[idx1].angle - KF2.keys[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(idx1);
+                }
+                nmatches++;
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                vnMatches12[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
+// ORBmatcher.cc:188-215 (no fused multiply-add: every product and sum rounds to float as written)
+bool ORBmatcher::CheckDistEpipolarLine(const amos_keypoint &kp1, const amos_keypoint &kp2, const float F12[9], float sigma2_kp2)
+{
+    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+    const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+    const float num = a * kp2.x + b * kp2.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2_kp2;
+}
+
+// ORBmatcher.cc:810-1018
+int ORBmatcher::SearchForTriangulation(const amos_bow_view &KF1, const amos_bow_view &KF2, const float F12[9], float ex, float ey,
+                                       const vector<float> &mvScaleFactors2, const vector<float> &mvLevelSigma2_2,
+                                       vector<pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo)
+{
+    auto stereo = [](const amos_bow_view &v, int i) { return v.u_right ? v.u_right[i] >= 0 : false; };
+    vector<int> q1, off, idx;
+    BowCandidates(KF1, KF2,
+                  [&](int i1) {
+                      if (KF1.has_point && KF1.has_point[i1]) return false;  // pMP1 exists: nothing to triangulate (:846-849)
+                      if (bOnlyStereo && !stereo(KF1, i1)) return false;
+                      return true;
+                  },
+                  q1, off, idx);
+    const int nq = (int)q1.size();
+    vector<uint8_t> qdesc((size_t)nq * 32);
+    for (int i = 0; i < nq; i++) memcpy(&qdesc[(size_t)i * 32], KF1.descriptors + (size_t)q1[i] * 32, 32);
+    vector<uint16_t> dist;
+    ListDistances(KF2.descriptors, KF2.n, qdesc.data(), nq, off, idx, dist);
+    int nmatches = 0;
+    vector<bool> vbMatched2(KF2.n, false);
+    vector<int> vMatches12(KF1.n, -1);
+    vector<int> rotHist[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+    const float factor = HISTO_LENGTH / 360.0f;
+    for (int i = 0; i < nq; i++) {
+        const int idx1 = q1[i];
+        const bool bStereo1 = stereo(KF1, idx1);
+        const amos_keypoint &kp1 = KF1.keys[idx1];
+        int bestDist = TH_LOW;
+        int bestIdx2 = -1;
+        for (int k = off[i]; k < off[i + 1]; k++) {
+            const int idx2 = idx[k];
+            if (vbMatched2[idx2] || (KF2.has_point && KF2.has_point[idx2])) continue;  // :866-869
+            const bool bStereo2 = stereo(KF2, idx2);
+            if (bOnlyStereo)
+                if (!bStereo2) continue;
+            const int d = dist[k];
+            if (d > TH_LOW || d > bestDist) continue;
+            const amos_keypoint &kp2 = KF2.keys[idx2];
+            if (!bStereo1 && !bStereo2) {
+                const float distex = ex - kp2.x;
+                const float distey = ey - kp2.y;
+                if (distex * distex + distey * distey < 100 * mvScaleFactors2[kp2.octave]) continue;
+            }
+            if (CheckDistEpipolarLine(kp1, kp2, F12, mvLevelSigma2_2[kp2.octave])) {
+                bestIdx2 = idx2;
+                bestDist = d;
+            }
+        }
+        if (bestIdx2 >= 0) {
+            const amos_keypoint &kp2 = KF2.keys[bestIdx2];
+            vMatches12[idx1] = bestIdx2;
+            vbMatched2[bestIdx2] = true;
+            nmatches++;
+            if (mbCheckOrientation) {
+                float rot = kp1.angle - kp2.angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(idx1);
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                vMatches12[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    vMatchedPairs.clear();
+    vMatchedPairs.reserve(nmatches);
+    for (size_t i = 0, iend = vMatches12.size(); i < iend; i++) {
+        if (vMatches12[i] < 0) continue;
+        vMatchedPairs.push_back(make_pair(i, (size_t)vMatches12[i]));
+    }
+    return nmatches;
+}
+
+// The candidate loop shared by Fuse (:1086-1127, :1252-1272), SearchByProjection(pKF, Scw, ...) (:466-494) and
+// SearchBySim3 (:1396-1420, :1476-1500): KeyFrame::GetFeaturesInArea(u, v, radius) has no level filter; the level
+// gate  kpLevel < nPredictedLevel-1 || kpLevel > nPredictedLevel  and Fuse's reprojection gate follow per candidate.
+void ORBmatcher::WindowCandidates(const FeatureGrid &KF, const vector<amos_window_query> &q, const vector<float> &mvScaleFactors, const float th,
+                                  const vector<float> *mvInvLevelSigma2, vector<int> &off, vector<int> &idx, vector<uint16_t> &dist)
+{
+    const amos_frame_view &F = KF.Frame();
+    const int nq = (int)q.size();
+    off.assign(nq + 1, 0);
+    idx.clear();
+    vector<uint8_t> qdesc((size_t)nq * 32);
+    for (int i = 0; i < nq; i++) {
+        const amos_window_query &p = q[i];
+        memcpy(&qdesc[(size_t)i * 32], p.desc, 32);
+        const int nPredictedLevel = p.level;
+        const float radius = th * mvScaleFactors[nPredictedLevel];
+        const vector<size_t> vIndices = KF.GetFeaturesInArea(p.u, p.v, radius);
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const size_t i2 = vIndices[k];
+            const amos_keypoint &kp = F.keys_un[i2];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (mvInvLevelSigma2) {
+                if (F.u_right && F.u_right[i2] >= 0) {  // :1102-1116
+                    const float ex = p.u - kp.x;
+                    const float ey = p.v - kp.y;
+                    const float er = p.ur - F.u_right[i2];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * (*mvInvLevelSigma2)[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = p.u - kp.x;
+                    const float ey = p.v - kp.y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * (*mvInvLevelSigma2)[kpLevel] > 5.99) continue;
+                }
+            }
+            idx.push_back((int)i2);
+        }
+        off[i + 1] = (int)idx.size();
+    }
+    ListDistances(F, qdesc.data(), nq, off, idx, dist);
+}
+
+static int BestOfList(const vector<int> &off, const vector<int> &idx, const vector<uint16_t> &dist, int i, int &bestDist)
+{
+    bestDist = 256;
+    int bestIdx = -1;
+    for (int k = off[i]; k < off[i + 1]; k++)
+        if (dist[k] < bestDist) {
+            bestDist = dist[k];
+            bestIdx = idx[k];
+        }
+    return bestIdx;
+}
+
+// ORBmatcher.cc:1020-1177
+int ORBmatcher::Fuse(const FeatureGrid &KF, const vector<amos_window_query> &vpMapPoints, const vector<float> &mvScaleFactors,
+                     const vector<float> &mvInvLevelSigma2, const float th, vector<int> &vnBestIdx)
+{
+    vector<int> off, idx;
+    vector<uint16_t> dist;
+    WindowCandidates(KF, vpMapPoints, mvScaleFactors, th, &mvInvLevelSigma2, off, idx, dist);
+    int nFused = 0;
+    vnBestIdx.assign(vpMapPoints.size(), -1);
+    for (int i = 0; i < (int)vpMapPoints.size(); i++) {
+        int bestDist;
+        const int bestIdx = BestOfList(off, idx, dist, i, bestDist);
+        if (bestDist <= TH_LOW) {
+            vnBestIdx[i] = bestIdx;
+            nFused++;
+        }
+    }
+    return nFused;
+}
+
+// ORBmatcher.cc:1179-1312
+int ORBmatcher::Fuse(const FeatureGrid &KF, const vector<amos_window_query> &vpPoints, const vector<float> &mvScaleFactors, const float th,
+                     vector<int> &vnBestIdx)
+{
+    vector<int> off, idx;
+    vector<uint16_t> dist;
+    WindowCandidates(KF, vpPoints, mvScaleFactors, th, nullptr, off, idx, dist);
+    int nFused = 0;
+    vnBestIdx.assign(vpPoints.size(), -1);
+    for (int i = 0; i < (int)vpPoints.size(); i++) {
+        int bestDist;
+        const int bestIdx = BestOfList(off, idx, dist, i, bestDist);
+        if (bestDist <= TH_LOW) {
+            vnBestIdx[i] = bestIdx;
+            nFused++;
+        }
+    }
+    return nFused;
+}
+
+// ORBmatcher.cc:388-512
+int ORBmatcher::SearchByProjection(const FeatureGrid &KF, const vector<amos_window_query> &vpPoints, vector<int> &vnMatched,
+                                   const vector<float> &mvScaleFactors, const int th)
+{
+    vector<int> off, idx;
+    vector<uint16_t> dist;
+    WindowCandidates(KF, vpPoints, mvScaleFactors, (float)th, nullptr, off, idx, dist);
+    int nmatches = 0;
+    for (int i = 0; i < (int)vpPoints.size(); i++) {
+        int bestDist = 256;
+        int bestIdx = -1;
+        for (int k = off[i]; k < off[i + 1]; k++) {
+            if (vnMatched[idx[k]] != AMOS_MATCH_FREE) continue;  // :470-471
+            if (dist[k] < bestDist) {
+                bestDist = dist[k];
+                bestIdx = idx[k];
+            }
+        }
+        if (bestDist <= TH_LOW) {
+            vnMatched[bestIdx] = i;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+// ORBmatcher.cc:1314-1565
+int ORBmatcher::SearchBySim3(const FeatureGrid &KF1, const FeatureGrid &KF2, const vector<amos_window_query> &v1in2,
+                             const vector<amos_window_query> &v2in1, const vector<float> &mvScaleFactors1, const vector<float> &mvScaleFactors2,
+                             vector<int> &vnMatches12, const float th)
+{
+    const int N1 = KF1.Frame().n, N2 = KF2.Frame().n;
+    vector<int> vnMatch1(N1, -1), vnMatch2(N2, -1);
+    vector<int> off, idx;
+    vector<uint16_t> dist;
+    WindowCandidates(KF2, v1in2, mvScaleFactors2, th, nullptr, off, idx, dist);  // KF1's points searched in KF2
+    for (int i = 0; i < (int)v1in2.size(); i++) {
+        int bestDist;
+        const int bestIdx = BestOfList(off, idx, dist, i, bestDist);
+        if (bestDist <= TH_HIGH) vnMatch1[v1in2[i].src] = bestIdx;
+    }
+    WindowCandidates(KF1, v2in1, mvScaleFactors1, th, nullptr, off, idx, dist);  // KF2's points searched in KF1
+    for (int i = 0; i < (int)v2in1.size(); i++) {
+        int bestDist;
+        const int bestIdx = BestOfList(off, idx, dist, i, bestDist);
+        if (bestDist <= TH_HIGH) vnMatch2[v2in1[i].src] = bestIdx;
+    }
+    vnMatches12.assign(N1, -1);
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {  // :1540-1556: keep what both directions agree on
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) {
+                vnMatches12[i1] = idx2;
+                nFound++;
+            }
+        }
+    }
+    return nFound;
+}
+
 // ORBmatcher.cc:515-643
 int ORBmatcher::SearchForInitialization(const amos_frame_view &F1, const FeatureGrid &F2g, vector<cv::Point2f> &vbPrevMatched,
                                         vector<int> &vnMatches12, int windowSize)

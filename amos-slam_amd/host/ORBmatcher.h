@@ -11,6 +11,7 @@
 #define ORBMATCHER_H
 
 #include <cstddef>
+#include <utility>
 #include <vector>
 
 #include "../../include/amos_host_types.h"
@@ -74,6 +75,38 @@ public:
     // Relocalization).  vnMatchesF[iF] = index of the keyframe feature whose map point F's feature iF receives, or -1.
     int SearchByBoW(const amos_bow_view &KF, const amos_bow_view &F, std::vector<int> &vnMatchesF);
 
+    // ORBmatcher.cc:656-808, SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (loop closing).
+    // vnMatches12[idx1] = the feature of KF2 whose map point KF1's feature idx1 is matched to, or -1.
+    int SearchByBoW(const amos_bow_view &KF1, const amos_bow_view &KF2, std::vector<int> &vnMatches12, const bool bBothKeyFrames);
+
+    // ORBmatcher.cc:810-1018, SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (local mapping).
+    //   F12: row-major 3x3;  ex, ey: the epipole in KF2 (:818-826);  mvScaleFactors2 / mvLevelSigma2_2: pKF2's tables
+    int SearchForTriangulation(const amos_bow_view &KF1, const amos_bow_view &KF2, const float F12[9], float ex, float ey,
+                               const std::vector<float> &mvScaleFactors2, const std::vector<float> &mvLevelSigma2_2,
+                               std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo);
+    // ORBmatcher.cc:188-215 (takes the three numbers it reads of pKF2 / F12 instead of the objects)
+    static bool CheckDistEpipolarLine(const amos_keypoint &kp1, const amos_keypoint &kp2, const float F12[9], float sigma2_kp2);
+
+    // ORBmatcher.cc:1020-1177, Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th): the search of every map
+    // point (window th * scale, levels nPredictedLevel-1 .. nPredictedLevel, chi2 gate 5.99 / 7.8 on the reprojection
+    // error, best <= TH_LOW).  vnBestIdx[q] = feature of pKF the point fuses with or -1; the MapPoint bookkeeping of
+    // :1150-1172 (Replace / AddObservation) is the caller's.  KF.Frame().u_right = pKF->mvuRight.
+    int Fuse(const FeatureGrid &KF, const std::vector<amos_window_query> &vpMapPoints, const std::vector<float> &mvScaleFactors,
+             const std::vector<float> &mvInvLevelSigma2, const float th, std::vector<int> &vnBestIdx);
+    // ORBmatcher.cc:1179-1312, Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (loop closing): no chi2 gate.
+    int Fuse(const FeatureGrid &KF, const std::vector<amos_window_query> &vpPoints, const std::vector<float> &mvScaleFactors, const float th,
+             std::vector<int> &vnBestIdx);
+    // ORBmatcher.cc:388-512, SearchByProjection(pKF, Scw, vpPoints, vpMatched, th).  vnMatched[idx]: AMOS_MATCH_FREE,
+    // AMOS_MATCH_TAKEN (vpMatched[idx] set on entry) or, on return, the index of the query assigned to feature idx.
+    int SearchByProjection(const FeatureGrid &KF, const std::vector<amos_window_query> &vpPoints, std::vector<int> &vnMatched,
+                           const std::vector<float> &mvScaleFactors, const int th);
+    // ORBmatcher.cc:1314-1565, SearchBySim3.  v1in2: the map points of KF1 (src = i1) projected into KF2 with S21, v2in1 the
+    // other way (src = i2), both already filtered as :1361-1393 / :1441-1473 do.  vnMatches12[i1] = i2 where both
+    // directions agree, else -1.
+    int SearchBySim3(const FeatureGrid &KF1, const FeatureGrid &KF2, const std::vector<amos_window_query> &v1in2,
+                     const std::vector<amos_window_query> &v2in1, const std::vector<float> &mvScaleFactors1,
+                     const std::vector<float> &mvScaleFactors2, std::vector<int> &vnMatches12, const float th);
+
     // ORBmatcher.cc:515-643, SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
     int SearchForInitialization(const amos_frame_view &F1, const FeatureGrid &F2, std::vector<cv::Point2f> &vbPrevMatched,
                                 std::vector<int> &vnMatches12, int windowSize = 10);
@@ -87,6 +120,11 @@ public:
 
 protected:
     float RadiusByViewingCos(const float &viewCos);
+    // candidates of every query in pKF->GetFeaturesInArea(u, v, th * scale) order that pass the level gate (and the chi2
+    // gate when mvInvLevelSigma2 is given), with their distances (one GPU call)
+    void WindowCandidates(const FeatureGrid &KF, const std::vector<amos_window_query> &q, const std::vector<float> &mvScaleFactors,
+                          const float th, const std::vector<float> *mvInvLevelSigma2, std::vector<int> &off, std::vector<int> &idx,
+                          std::vector<uint16_t> &dist);
     void ListDistances(const amos_frame_view &train, const uint8_t *queries, int nq, const std::vector<int> &off, const std::vector<int> &idx,
                        std::vector<uint16_t> &dist);
     void ListDistances(const uint8_t *train, int nt, const uint8_t *queries, int nq, const std::vector<int> &off, const std::vector<int> &idx,

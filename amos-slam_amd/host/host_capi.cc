@@ -167,6 +167,84 @@ int amos_host_search_by_bow(const amos_bow_view *kf, const amos_bow_view *f, int
     AMOS_HOST_CATCH
 }
 
+int amos_host_search_by_bow_kf(const amos_bow_view *kf1, const amos_bow_view *kf2, int32_t *matches12, float nnratio, int check_orientation)
+{
+    AMOS_HOST_TRY
+    ORBmatcher matcher(nnratio, check_orientation != 0);
+    std::vector<int> m;
+    const int r = matcher.SearchByBoW(*kf1, *kf2, m, true);
+    for (int i = 0; i < kf1->n; i++) matches12[i] = m[i];
+    return r;
+    AMOS_HOST_CATCH
+}
+
+int amos_host_search_for_triangulation(const amos_bow_view *kf1, const amos_bow_view *kf2, const float *f12, float ex, float ey,
+                                       const float *scale_factors2, const float *level_sigma2_2, int nlevels, int only_stereo, float nnratio,
+                                       int check_orientation, int32_t *pairs, int cap)
+{
+    AMOS_HOST_TRY
+    ORBmatcher matcher(nnratio, check_orientation != 0);
+    std::vector<float> sf(scale_factors2, scale_factors2 + nlevels), sg(level_sigma2_2, level_sigma2_2 + nlevels);
+    std::vector<std::pair<size_t, size_t> > out;
+    const int r = matcher.SearchForTriangulation(*kf1, *kf2, f12, ex, ey, sf, sg, out, only_stereo != 0);
+    if ((int)out.size() > cap) return -3;
+    for (size_t i = 0; i < out.size(); i++) { pairs[2 * i] = (int32_t)out[i].first; pairs[2 * i + 1] = (int32_t)out[i].second; }
+    return r;
+    AMOS_HOST_CATCH
+}
+
+int amos_host_fuse(const amos_frame_view *kf, const amos_window_query *q, int nq, const float *scale_factors, const float *inv_level_sigma2,
+                   int nlevels, float th, int32_t *best_idx)
+{
+    AMOS_HOST_TRY
+    FeatureGrid grid(*kf);
+    ORBmatcher matcher;
+    std::vector<amos_window_query> pts(q, q + nq);
+    std::vector<float> sf(scale_factors, scale_factors + nlevels);
+    std::vector<int> best;
+    int r;
+    if (inv_level_sigma2) {
+        std::vector<float> is2(inv_level_sigma2, inv_level_sigma2 + nlevels);
+        r = matcher.Fuse(grid, pts, sf, is2, th, best);
+    } else {
+        r = matcher.Fuse(grid, pts, sf, th, best);
+    }
+    for (int i = 0; i < nq; i++) best_idx[i] = best[i];
+    return r;
+    AMOS_HOST_CATCH
+}
+
+int amos_host_search_by_projection_sim(const amos_frame_view *kf, const amos_window_query *q, int nq, int32_t *matched, const float *scale_factors,
+                                       int nlevels, int th)
+{
+    AMOS_HOST_TRY
+    FeatureGrid grid(*kf);
+    ORBmatcher matcher;
+    std::vector<amos_window_query> pts(q, q + nq);
+    std::vector<float> sf(scale_factors, scale_factors + nlevels);
+    std::vector<int> m(matched, matched + kf->n);
+    const int r = matcher.SearchByProjection(grid, pts, m, sf, th);
+    std::memcpy(matched, m.data(), sizeof(int) * kf->n);
+    return r;
+    AMOS_HOST_CATCH
+}
+
+int amos_host_search_by_sim3(const amos_frame_view *kf1, const amos_frame_view *kf2, const amos_window_query *q12, int n12,
+                             const amos_window_query *q21, int n21, const float *scale_factors1, const float *scale_factors2, int nlevels,
+                             float th, int32_t *matches12)
+{
+    AMOS_HOST_TRY
+    FeatureGrid g1(*kf1), g2(*kf2);
+    ORBmatcher matcher;
+    std::vector<amos_window_query> a(q12, q12 + n12), b(q21, q21 + n21);
+    std::vector<float> sf1(scale_factors1, scale_factors1 + nlevels), sf2(scale_factors2, scale_factors2 + nlevels);
+    std::vector<int> m;
+    const int r = matcher.SearchBySim3(g1, g2, a, b, sf1, sf2, m, th);
+    for (int i = 0; i < kf1->n; i++) matches12[i] = m[i];
+    return r;
+    AMOS_HOST_CATCH
+}
+
 int amos_host_search_for_initialization(const amos_frame_view *f1, const amos_frame_view *f2, float *prev_matched, int32_t *matches12,
                                         int window_size, float nnratio, int check_orientation)
 {

@@ -59,17 +59,30 @@ typedef struct amos_kf_query {
     float angle;       /* pKF->mvKeysUn[i].angle */
     uint8_t desc[32];  /* pMP->GetDescriptor() */
 } amos_kf_query;
+/* One map point projected into a KEYFRAME by the mapping / loop-closing searches -- Fuse (ORBmatcher.cc:1020-1177,
+ * 1179-1312), SearchByProjection(pKF, Scw, ...) (:388-512), SearchBySim3 (:1314-1565) -- after the caller's geometric
+ * filtering (depth, image bounds, distance invariance, viewing angle). */
+typedef struct amos_window_query {
+    float u, v;        /* projection */
+    float ur;          /* Fuse #1 only: u - bf * invz (:1064) */
+    int32_t level;     /* nPredictedLevel */
+    int32_t src;       /* SearchBySim3: index of the source feature (i1 or i2); free otherwise */
+    uint8_t desc[32];  /* pMP->GetDescriptor() */
+} amos_window_query;
 #define AMOS_MATCH_FREE (-1)   /* CurrentFrame.mvpMapPoints[i2] == NULL */
 #define AMOS_MATCH_TAKEN (-2)  /* occupied on entry by a map point that is not one of the queries */
 
 /* What ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vpMapPointMatches) reads of either side
  * (ORBmatcher.cc:230-382): descriptors, keypoint angles, the DBoW2::FeatureVector (node id -> feature indices,
- * node ids ascending as std::map iterates them) and, for the keyframe, which features carry a good map point. */
+ * node ids ascending as std::map iterates them) and, for the keyframe, which features carry a good map point.
+ * The keyframe-keyframe searches (SearchByBoW(KF,KF) :656-808, SearchForTriangulation :810-1018) read the same. */
 typedef struct amos_bow_view {
     int32_t n;                    /* features */
     const amos_keypoint *keys;    /* KF: mvKeysUn, F: mvKeys (only .angle is read) */
     const uint8_t *descriptors;   /* n x 32 */
-    const uint8_t *has_point;     /* KF: vpMapPointsKF[i] && !isBad(); NULL = all; ignored for F */
+    const uint8_t *has_point;     /* KF: vpMapPointsKF[i] && !isBad(); NULL = all; ignored for F.  SearchForTriangulation:
+                                     GetMapPoint(i) != NULL (those features are skipped) */
+    const float *u_right;         /* mvuRight (SearchForTriangulation only), or NULL: monocular, all -1 */
     int32_t n_nodes;
     const uint32_t *node_ids;     /* ascending */
     const int32_t *node_off;      /* n_nodes + 1 */

@@ -1519,3 +1519,225 @@ int orc_search_by_bow(const amos_bow_view *kf, const amos_bow_view *f, int32_t *
     for (int i = 0; i < AMOS_HISTO_LENGTH; i++) free(hist[i]);
     return nmatches;
 }
+
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12), ORBmatcher.cc:656-808. */
+int orc_search_by_bow_kf(const amos_bow_view *k1, const amos_bow_view *k2, int32_t *matches12, float nn_ratio, int check_orientation)
+{
+    for (int i = 0; i < k1->n; i++) matches12[i] = -1;
+    uint8_t *matched2 = (uint8_t *)calloc(k2->n + 1, 1);
+    int nmatches = 0;
+    int *hist[AMOS_HISTO_LENGTH], hn[AMOS_HISTO_LENGTH];
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) { hist[i] = (int *)malloc(sizeof(int) * (k1->n + 1)); hn[i] = 0; }
+    const float factor = AMOS_HISTO_LENGTH / 360.0f;
+    int a = 0, b = 0;
+    while (a < k1->n_nodes && b < k2->n_nodes) {
+        if (k1->node_ids[a] == k2->node_ids[b]) {
+            for (int i1 = k1->node_off[a]; i1 < k1->node_off[a + 1]; i1++) {
+                const int idx1 = k1->node_idx[i1];
+                if (k1->has_point && !k1->has_point[idx1]) continue;
+                const uint8_t *d1 = k1->descriptors + (size_t)idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int i2 = k2->node_off[b]; i2 < k2->node_off[b + 1]; i2++) {
+                    const int idx2 = k2->node_idx[i2];
+                    if (matched2[idx2] || (k2->has_point && !k2->has_point[idx2])) continue;
+                    const int dist = orc_descriptor_distance(d1, k2->descriptors + (size_t)idx2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < AMOS_TH_LOW) {
+                    if ((float)bestDist1 < nn_ratio * (float)bestDist2) {
+                        matches12[idx1] = bestIdx2;
+                        matched2[bestIdx2] = 1;
+                        if (check_orientation) {
+                            float rot = k1->keys[idx1].angle - k2->keys[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)round(rot * factor);
+                            if (bin == AMOS_HISTO_LENGTH) bin = 0;
+                            hist[bin][hn[bin]++] = idx1;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (k1->node_ids[a] < k2->node_ids[b]) {
+            while (a < k1->n_nodes && k1->node_ids[a] < k2->node_ids[b]) a++;
+        } else {
+            while (b < k2->n_nodes && k2->node_ids[b] < k1->node_ids[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int32_t sizes[AMOS_HISTO_LENGTH];
+        for (int i = 0; i < AMOS_HISTO_LENGTH; i++) sizes[i] = hn[i];
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(sizes, AMOS_HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < AMOS_HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < hn[i]; j++) { matches12[hist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) free(hist[i]);
+    free(matched2);
+    return nmatches;
+}
+
+/* ORBmatcher::CheckDistEpipolarLine, ORBmatcher.cc:188-215 (plain float arithmetic, no fused multiply-add). */
+static int check_dist_epipolar_line(const amos_keypoint *kp1, const amos_keypoint *kp2, const float *F12, float sigma2)
+{
+    const float a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];
+    const float b = kp1->x * F12[1] + kp1->y * F12[4] + F12[7];
+    const float c = kp1->x * F12[2] + kp1->y * F12[5] + F12[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2;
+}
+
+/* ORBmatcher::SearchForTriangulation, ORBmatcher.cc:810-1018.  pairs: (idx1, idx2) in ascending idx1. */
+int orc_search_for_triangulation(const amos_bow_view *k1, const amos_bow_view *k2, const float *F12, float ex, float ey,
+                                 const float *scale_factors2, const float *level_sigma2_2, int only_stereo, int check_orientation,
+                                 int32_t *pairs, int cap)
+{
+    int nmatches = 0;
+    uint8_t *matched2 = (uint8_t *)calloc(k2->n + 1, 1);
+    int32_t *m12 = (int32_t *)malloc(sizeof(int32_t) * (k1->n + 1));
+    for (int i = 0; i < k1->n; i++) m12[i] = -1;
+    int *hist[AMOS_HISTO_LENGTH], hn[AMOS_HISTO_LENGTH];
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) { hist[i] = (int *)malloc(sizeof(int) * (k1->n + 1)); hn[i] = 0; }
+    const float factor = AMOS_HISTO_LENGTH / 360.0f;
+    int a = 0, b = 0;
+    while (a < k1->n_nodes && b < k2->n_nodes) {
+        if (k1->node_ids[a] == k2->node_ids[b]) {
+            for (int i1 = k1->node_off[a]; i1 < k1->node_off[a + 1]; i1++) {
+                const int idx1 = k1->node_idx[i1];
+                if (k1->has_point && k1->has_point[idx1]) continue;
+                const int bStereo1 = k1->u_right ? k1->u_right[idx1] >= 0 : 0;
+                if (only_stereo && !bStereo1) continue;
+                const amos_keypoint *kp1 = &k1->keys[idx1];
+                const uint8_t *d1 = k1->descriptors + (size_t)idx1 * 32;
+                int bestDist = AMOS_TH_LOW, bestIdx2 = -1;
+                for (int i2 = k2->node_off[b]; i2 < k2->node_off[b + 1]; i2++) {
+                    const int idx2 = k2->node_idx[i2];
+                    if (matched2[idx2] || (k2->has_point && k2->has_point[idx2])) continue;
+                    const int bStereo2 = k2->u_right ? k2->u_right[idx2] >= 0 : 0;
+                    if (only_stereo && !bStereo2) continue;
+                    const int dist = orc_descriptor_distance(d1, k2->descriptors + (size_t)idx2 * 32);
+                    if (dist > AMOS_TH_LOW || dist > bestDist) continue;
+                    const amos_keypoint *kp2 = &k2->keys[idx2];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - kp2->x, distey = ey - kp2->y;
+                        if (distex * distex + distey * distey < 100 * scale_factors2[kp2->octave]) continue;
+                    }
+                    if (check_dist_epipolar_line(kp1, kp2, F12, level_sigma2_2[kp2->octave])) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    m12[idx1] = bestIdx2;
+                    matched2[bestIdx2] = 1;
+                    nmatches++;
+                    if (check_orientation) {
+                        float rot = kp1->angle - k2->keys[bestIdx2].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)round(rot * factor);
+                        if (bin == AMOS_HISTO_LENGTH) bin = 0;
+                        hist[bin][hn[bin]++] = idx1;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (k1->node_ids[a] < k2->node_ids[b]) {
+            while (a < k1->n_nodes && k1->node_ids[a] < k2->node_ids[b]) a++;
+        } else {
+            while (b < k2->n_nodes && k2->node_ids[b] < k1->node_ids[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int32_t sizes[AMOS_HISTO_LENGTH];
+        for (int i = 0; i < AMOS_HISTO_LENGTH; i++) sizes[i] = hn[i];
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(sizes, AMOS_HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < AMOS_HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < hn[i]; j++) { m12[hist[i][j]] = -1; nmatches--; }
+        }
+    }
+    int np = 0;
+    for (int i = 0; i < k1->n; i++)
+        if (m12[i] >= 0 && np < cap) { pairs[2 * np] = i; pairs[2 * np + 1] = m12[i]; np++; }
+    for (int i = 0; i < AMOS_HISTO_LENGTH; i++) free(hist[i]);
+    free(matched2); free(m12);
+    return nmatches;
+}
+
+/* The per-map-point search of Fuse (ORBmatcher.cc:1085-1132 with the chi2 gate, :1251-1273 without),
+ * SearchByProjection(pKF, Scw, ...) (:455-500, greedy on `occupied`) and both passes of SearchBySim3
+ * (:1394-1425, :1474-1505): window th * scale[level] with KeyFrame::GetFeaturesInArea (no level filter), level gate
+ * nPredictedLevel-1 .. nPredictedLevel, best by strict <, accepted at bestDist <= max_dist.
+ * best_idx[q] = accepted feature or -1; occupied (may be NULL): AMOS_MATCH_FREE entries only are eligible and an
+ * accepted feature becomes the query's index.  Returns the number of accepted queries. */
+int orc_window_search(const amos_frame_view *kf, const amos_window_query *q, int nq, const float *scale_factors,
+                      const float *inv_level_sigma2, float th, int max_dist, int32_t *occupied, int32_t *best_idx)
+{
+    ogrid g = grid_build(kf);
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (kf->n + 1));
+    int naccepted = 0;
+    for (int i = 0; i < nq; i++) {
+        const int lvl = q[i].level;
+        const float radius = th * scale_factors[lvl];
+        const float u = q[i].u, v = q[i].v, ur = q[i].ur;
+        const int nc = grid_area(&g, kf, u, v, radius, -1, -1, cand, kf->n);
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (occupied && occupied[idx] != AMOS_MATCH_FREE) continue;
+            const amos_keypoint *kp = &kf->keys_un[idx];
+            const int kpLevel = kp->octave;
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+            if (inv_level_sigma2) {
+                if (kf->u_right && kf->u_right[idx] >= 0) {
+                    const float ex = u - kp->x, ey = v - kp->y, er = ur - kf->u_right[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = u - kp->x, ey = v - kp->y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = orc_descriptor_distance(q[i].desc, kf->descriptors + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[i] = -1;
+        if (bestDist <= max_dist) {
+            best_idx[i] = bestIdx;
+            if (occupied) occupied[bestIdx] = i;
+            naccepted++;
+        }
+    }
+    free(cand);
+    grid_free(&g);
+    return naccepted;
+}
+
+/* ORBmatcher::SearchBySim3, ORBmatcher.cc:1314-1565, from the two projected point sets on. */
+int orc_search_by_sim3(const amos_frame_view *kf1, const amos_frame_view *kf2, const amos_window_query *q12, int n12,
+                       const amos_window_query *q21, int n21, const float *scale_factors1, const float *scale_factors2, float th,
+                       int32_t *matches12)
+{
+    int32_t *m1 = (int32_t *)malloc(sizeof(int32_t) * (kf1->n + 1)), *m2 = (int32_t *)malloc(sizeof(int32_t) * (kf2->n + 1));
+    int32_t *b12 = (int32_t *)malloc(sizeof(int32_t) * (n12 + 1)), *b21 = (int32_t *)malloc(sizeof(int32_t) * (n21 + 1));
+    for (int i = 0; i < kf1->n; i++) m1[i] = -1;
+    for (int i = 0; i < kf2->n; i++) m2[i] = -1;
+    orc_window_search(kf2, q12, n12, scale_factors2, NULL, th, AMOS_TH_HIGH, NULL, b12);
+    for (int i = 0; i < n12; i++) if (b12[i] >= 0) m1[q12[i].src] = b12[i];
+    orc_window_search(kf1, q21, n21, scale_factors1, NULL, th, AMOS_TH_HIGH, NULL, b21);
+    for (int i = 0; i < n21; i++) if (b21[i] >= 0) m2[q21[i].src] = b21[i];
+    int nFound = 0;
+    for (int i1 = 0; i1 < kf1->n; i1++) {
+        matches12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { matches12[i1] = idx2; nFound++; }
+    }
+    free(m1); free(m2); free(b12); free(b21);
+    return nFound;
+}

@@ -127,6 +127,17 @@ int orc_search_by_projection_kf(const amos_frame_view *cur, const amos_kf_query 
                                 const float *scale_factors, float th, int orb_dist, int check_orientation);
 int orc_search_by_bow(const amos_bow_view *kf, const amos_bow_view *f, int32_t *matches_f, float nn_ratio, int check_orientation);
 
+int orc_search_by_bow_kf(const amos_bow_view *k1, const amos_bow_view *k2, int32_t *matches12, float nn_ratio, int check_orientation);
+int orc_search_for_triangulation(const amos_bow_view *k1, const amos_bow_view *k2, const float *F12, float ex, float ey,
+                                 const float *scale_factors2, const float *level_sigma2_2, int only_stereo, int check_orientation,
+                                 int32_t *pairs, int cap);
+
+int orc_window_search(const amos_frame_view *kf, const amos_window_query *q, int nq, const float *scale_factors,
+                      const float *inv_level_sigma2, float th, int max_dist, int32_t *occupied, int32_t *best_idx);
+int orc_search_by_sim3(const amos_frame_view *kf1, const amos_frame_view *kf2, const amos_window_query *q12, int n12,
+                       const amos_window_query *q21, int n21, const float *scale_factors1, const float *scale_factors2, float th,
+                       int32_t *matches12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,15 +18,16 @@ MAP_QUERY = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), 
 
 
 KF_QUERY = np.dtype([("u", "<f4"), ("v", "<f4"), ("level", "<i4"), ("angle", "<f4"), ("desc", "u1", (32,))])
+WINDOW_QUERY = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("level", "<i4"), ("src", "<i4"), ("desc", "u1", (32,))])
 MATCH_FREE, MATCH_TAKEN = -1, -2
 
 
 class BowView(C.Structure):
-    _fields_ = [("n", C.c_int32), ("keys", C.c_void_p), ("descriptors", C.c_void_p), ("has_point", C.c_void_p), ("n_nodes", C.c_int32),
-                ("node_ids", C.c_void_p), ("node_off", C.c_void_p), ("node_idx", C.c_void_p)]
+    _fields_ = [("n", C.c_int32), ("keys", C.c_void_p), ("descriptors", C.c_void_p), ("has_point", C.c_void_p), ("u_right", C.c_void_p),
+                ("n_nodes", C.c_int32), ("node_ids", C.c_void_p), ("node_off", C.c_void_p), ("node_idx", C.c_void_p)]
 
 
-def bow_view(kps, desc, nodes, has_point=None):
+def bow_view(kps, desc, nodes, has_point=None, u_right=None):
     """nodes: dict node id -> list of feature indices (a DBoW2::FeatureVector).  Returns (view, keepalive)."""
     kps = np.ascontiguousarray(kps, KP)
     desc = np.ascontiguousarray(desc, np.uint8)
@@ -38,9 +39,10 @@ def bow_view(kps, desc, nodes, has_point=None):
         off[k + 1] = len(idx)
     idx = np.array(idx if idx else [0], np.int32)
     hp = None if has_point is None else np.ascontiguousarray(has_point, np.uint8)
-    v = BowView(len(kps), kps.ctypes.data, desc.ctypes.data, hp.ctypes.data if hp is not None else None, len(ids), ids.ctypes.data,
-                off.ctypes.data, idx.ctypes.data)
-    return v, (kps, desc, ids, off, idx, hp)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    v = BowView(len(kps), kps.ctypes.data, desc.ctypes.data, hp.ctypes.data if hp is not None else None,
+                ur.ctypes.data if ur is not None else None, len(ids), ids.ctypes.data, off.ctypes.data, idx.ctypes.data)
+    return v, (kps, desc, ids, off, idx, hp, ur)
 
 
 class FrameView(C.Structure):
@@ -192,6 +194,67 @@ def search_bow(which, kf_view, f_view, nnratio=0.7, check_ori=True):
     else:
         r = ob.lib().orc_search_by_bow(C.byref(kf_view), C.byref(f_view), _p(m), C.c_float(nnratio), C.c_int(check_ori))
     return r, m[:f_view.n]
+
+
+def search_bow_kf(which, v1, v2, nnratio=0.75, check_ori=True):
+    m = np.zeros(max(v1.n, 1), np.int32)
+    if which == "host":
+        r = _chk(host().amos_host_search_by_bow_kf(C.byref(v1), C.byref(v2), _p(m), C.c_float(nnratio), C.c_int(check_ori)))
+    else:
+        r = ob.lib().orc_search_by_bow_kf(C.byref(v1), C.byref(v2), _p(m), C.c_float(nnratio), C.c_int(check_ori))
+    return r, m[:v1.n]
+
+
+def search_triangulation(which, v1, v2, f12, ex, ey, scale_factors2, level_sigma2_2, only_stereo, check_ori=True, nnratio=0.6):
+    f12 = np.ascontiguousarray(f12, np.float32).reshape(9)
+    sf, sg = np.ascontiguousarray(scale_factors2, np.float32), np.ascontiguousarray(level_sigma2_2, np.float32)
+    pairs = np.zeros((max(v1.n, 1), 2), np.int32)
+    if which == "host":
+        r = _chk(host().amos_host_search_for_triangulation(C.byref(v1), C.byref(v2), _p(f12), C.c_float(ex), C.c_float(ey), _p(sf), _p(sg),
+                                                           C.c_int(len(sf)), C.c_int(only_stereo), C.c_float(nnratio), C.c_int(check_ori),
+                                                           _p(pairs), C.c_int(len(pairs))))
+    else:
+        r = ob.lib().orc_search_for_triangulation(C.byref(v1), C.byref(v2), _p(f12), C.c_float(ex), C.c_float(ey), _p(sf), _p(sg),
+                                                  C.c_int(only_stereo), C.c_int(check_ori), _p(pairs), C.c_int(len(pairs)))
+    return r, pairs[:max(r, 0)].copy()
+
+
+def fuse(which, view, queries, scale_factors, th, inv_level_sigma2=None):
+    """Fuse #1 (inv_level_sigma2 given: chi2 gate) / Fuse #2.  Returns (nFused, best feature per query)."""
+    q = np.ascontiguousarray(queries, WINDOW_QUERY)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    is2 = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+    best = np.zeros(max(len(q), 1), np.int32)
+    if which == "host":
+        r = _chk(host().amos_host_fuse(C.byref(view), _p(q), C.c_int(len(q)), _p(sf), _p(is2), C.c_int(len(sf)), C.c_float(th), _p(best)))
+    else:
+        r = ob.lib().orc_window_search(C.byref(view), _p(q), C.c_int(len(q)), _p(sf), _p(is2), C.c_float(th), C.c_int(50), None, _p(best))
+    return r, best[:len(q)]
+
+
+def search_projection_sim(which, view, queries, matched, scale_factors, th):
+    q = np.ascontiguousarray(queries, WINDOW_QUERY)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    m = np.ascontiguousarray(matched, np.int32).copy()
+    if which == "host":
+        r = _chk(host().amos_host_search_by_projection_sim(C.byref(view), _p(q), C.c_int(len(q)), _p(m), _p(sf), C.c_int(len(sf)), C.c_int(th)))
+    else:
+        best = np.zeros(max(len(q), 1), np.int32)
+        r = ob.lib().orc_window_search(C.byref(view), _p(q), C.c_int(len(q)), _p(sf), None, C.c_float(th), C.c_int(50), _p(m), _p(best))
+    return r, m
+
+
+def search_sim3(which, v1, v2, q12, q21, sf1, sf2, th):
+    q12, q21 = np.ascontiguousarray(q12, WINDOW_QUERY), np.ascontiguousarray(q21, WINDOW_QUERY)
+    sf1, sf2 = np.ascontiguousarray(sf1, np.float32), np.ascontiguousarray(sf2, np.float32)
+    m = np.zeros(max(v1.n, 1), np.int32)
+    if which == "host":
+        r = _chk(host().amos_host_search_by_sim3(C.byref(v1), C.byref(v2), _p(q12), C.c_int(len(q12)), _p(q21), C.c_int(len(q21)), _p(sf1),
+                                                 _p(sf2), C.c_int(len(sf1)), C.c_float(th), _p(m)))
+    else:
+        r = ob.lib().orc_search_by_sim3(C.byref(v1), C.byref(v2), _p(q12), C.c_int(len(q12)), _p(q21), C.c_int(len(q21)), _p(sf1), _p(sf2),
+                                        C.c_float(th), _p(m))
+    return r, m[:v1.n]
 
 
 def search_init(which, view1, view2, prev_matched, window=100, nnratio=0.9, check_ori=True):

@@ -200,6 +200,87 @@ def test_search_by_bow(hb, ob, synth):
     assert n_o > 30
 
 
+def _bow_nodes(desc, rng):
+    ids = (desc[:, 0].astype(np.uint32) >> 2) * 3 + 5
+    out = {}
+    for i in rng.permutation(len(desc)):
+        out.setdefault(int(ids[i]), []).append(int(i))
+    return out
+
+
+def test_search_by_bow_keyframes(hb, ob, synth):
+    """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (loop closing)."""
+    orc = ob.Oracle()
+    k0, d0 = orc.extract(synth.frame(23, 2))
+    k1, d1 = orc.extract(synth.frame(23, 3))
+    rng = np.random.default_rng(7)
+    has0, has1 = (rng.random(len(k0)) < 0.85).astype(np.uint8), (rng.random(len(k1)) < 0.85).astype(np.uint8)
+    v0, keep0 = hb.bow_view(k0, d0, _bow_nodes(d0, rng), has0)
+    v1, keep1 = hb.bow_view(k1, d1, _bow_nodes(d1, rng), has1)
+    for ratio, ori in ((0.75, True), (0.95, False)):
+        n_h, m_h = hb.search_bow_kf("host", v0, v1, ratio, ori)
+        n_o, m_o = hb.search_bow_kf("oracle", v0, v1, ratio, ori)
+        assert n_h == n_o and np.array_equal(m_h, m_o)
+    assert n_o > 30
+
+
+@pytest.mark.parametrize("only_stereo", [0, 1])
+def test_search_for_triangulation(hb, ob, synth, only_stereo):
+    """ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (local mapping)."""
+    orc = ob.Oracle()
+    k0, d0 = orc.extract(synth.frame(24, 2))
+    k1, d1 = orc.extract(synth.frame(24, 3))
+    sf = orc.tables()["scale"]
+    sg = orc.tables()["sigma2"]
+    rng = np.random.default_rng(8 + only_stereo)
+    has0, has1 = (rng.random(len(k0)) < 0.3).astype(np.uint8), (rng.random(len(k1)) < 0.3).astype(np.uint8)
+    ur0 = np.where(rng.random(len(k0)) < 0.5, k0["x"] - 10, -1).astype(np.float32)
+    ur1 = np.where(rng.random(len(k1)) < 0.5, k1["x"] - 10, -1).astype(np.float32)
+    f12 = np.array([[0, 0, 1.0], [0, 0, -2.0], [-1.0, 2.0, 0]], np.float32)   # pure image translation by (2, 1)
+    v0, keep0 = hb.bow_view(k0, d0, _bow_nodes(d0, rng), has0, ur0)
+    v1, keep1 = hb.bow_view(k1, d1, _bow_nodes(d1, rng), has1, ur1)
+    n_h, p_h = hb.search_triangulation("host", v0, v1, f12, 320.0, 200.0, sf, sg, only_stereo)
+    n_o, p_o = hb.search_triangulation("oracle", v0, v1, f12, 320.0, 200.0, sf, sg, only_stereo)
+    assert n_h == n_o and np.array_equal(p_h, p_o)
+    assert n_o > 10
+
+
+def _win_queries(hb, k_src, d_src, rng, dx=-2.0, dy=-1.0):
+    q = np.zeros(len(k_src), hb.WINDOW_QUERY)
+    q["u"] = k_src["x"] + dx + rng.normal(0, 1.5, len(k_src)).astype(np.float32)
+    q["v"] = k_src["y"] + dy + rng.normal(0, 1.5, len(k_src)).astype(np.float32)
+    q["ur"] = q["u"] - rng.uniform(5, 30, len(k_src)).astype(np.float32)
+    q["level"] = np.minimum(k_src["octave"] + (rng.random(len(k_src)) < 0.3), 7)
+    q["src"], q["desc"] = np.arange(len(k_src)), d_src
+    return q
+
+
+def test_fuse_and_sim3_searches(hb, ob, synth):
+    """ORBmatcher::Fuse (both), SearchByProjection(pKF, Scw, ...) and SearchBySim3 (mapping / loop-closing threads)."""
+    orc = ob.Oracle()
+    k0, d0 = orc.extract(synth.frame(25, 2))
+    k1, d1 = orc.extract(synth.frame(25, 3))
+    t = orc.tables()
+    sf, inv_s2 = t["scale"], t["inv_sigma2"]
+    rng = np.random.default_rng(9)
+    ur1 = np.where(rng.random(len(k1)) < 0.6, k1["x"] - rng.uniform(5, 30, len(k1)), -1).astype(np.float32)
+    view, keep = hb.frame_view(k1, d1, ur1)
+    q = _win_queries(hb, k0, d0, rng)
+    for args in ((3.0, inv_s2), (4.0, None)):
+        n_h, b_h = hb.fuse("host", view, q, sf, *args)
+        n_o, b_o = hb.fuse("oracle", view, q, sf, *args)
+        assert n_h == n_o and np.array_equal(b_h, b_o) and n_o > 50
+    m0 = np.where(rng.random(len(k1)) < 0.2, hb.MATCH_TAKEN, hb.MATCH_FREE).astype(np.int32)
+    n_h, m_h = hb.search_projection_sim("host", view, q, m0, sf, 10)
+    n_o, m_o = hb.search_projection_sim("oracle", view, q, m0, sf, 10)
+    assert n_h == n_o and np.array_equal(m_h, m_o) and n_o > 50
+    v0, keep0 = hb.frame_view(k0, d0)
+    q21 = _win_queries(hb, k1, d1, rng, 2.0, 1.0)
+    n_h, s_h = hb.search_sim3("host", v0, view, q, q21, sf, sf, 7.5)
+    n_o, s_o = hb.search_sim3("oracle", v0, view, q, q21, sf, sf, 7.5)
+    assert n_h == n_o and np.array_equal(s_h, s_o) and n_o > 50
+
+
 @pytest.mark.parametrize("mode,stereo,shifted", [(0, False, False), (0, True, True), (1, False, True), (2, True, False)])
 def test_resident_grid_and_window_search(gpu_lib, ob, synth, mode, stereo, shifted):
     """8f-1: AssignFeaturesToGrid + GetFeaturesInArea + best/second loop on resident batch results."""

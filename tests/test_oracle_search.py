@@ -271,3 +271,240 @@ def test_search_by_bow_vs_python(frames):
         n_p, m_p = py_search_bow(k0, d0, n0, has, k1, d1, n1, ratio)
         assert n_o == n_p and np.array_equal(m_o, m_p)
     assert n_o > 10
+
+
+def py_search_bow_kf(k1, d1, n1, has1, k2, d2, n2, has2, ratio):
+    """Independent restatement of ORBmatcher.cc:656-808."""
+    m12 = np.full(len(k1), -1, np.int32)
+    matched2 = np.zeros(len(k2), bool)
+    n = 0
+    hist = [[] for _ in range(30)]
+    factor = F32(30) / F32(360.0)
+    for nid in sorted(set(n1) & set(n2)):
+        for i1 in n1[nid]:
+            if not has1[i1]:
+                continue
+            b1, b2, bi = 256, 256, -1
+            for i2 in n2[nid]:
+                if matched2[i2] or not has2[i2]:
+                    continue
+                d = _dist(d1[i1], d2[i2])
+                if d < b1:
+                    b2, b1, bi = b1, d, i2
+                elif d < b2:
+                    b2 = d
+            if b1 < 50 and F32(b1) < F32(ratio) * F32(b2):
+                m12[i1] = bi
+                matched2[bi] = True
+                rot = F32(k1[i1]["angle"]) - F32(k2[bi]["angle"])
+                if rot < 0:
+                    rot = F32(rot + F32(360.0))
+                b = _round_half_away(F32(rot * factor))
+                hist[0 if b == 30 else b].append(i1)
+                n += 1
+    i1_, i2_, i3_ = _three_maxima([len(h) for h in hist])
+    for b in range(30):
+        if b not in (i1_, i2_, i3_):
+            for j in hist[b]:
+                m12[j] = -1
+                n -= 1
+    return n, m12
+
+
+def test_search_by_bow_keyframes_vs_python(frames):
+    k0, d0, k1, d1, _ = frames
+    rng = np.random.default_rng(10)
+    has0, has1 = (rng.random(len(k0)) < 0.8).astype(np.uint8), (rng.random(len(k1)) < 0.8).astype(np.uint8)
+    n0, n1 = _nodes(d0, rng), _nodes(d1, rng)
+    for drop in list(n1)[::5]:
+        del n1[drop]
+    v0, keep0 = hb.bow_view(k0, d0, n0, has0)
+    v1, keep1 = hb.bow_view(k1, d1, n1, has1)
+    for ratio in (0.75, 0.95):
+        n_o, m_o = hb.search_bow_kf("oracle", v0, v1, ratio)
+        n_p, m_p = py_search_bow_kf(k0, d0, n0, has0, k1, d1, n1, has1, ratio)
+        assert n_o == n_p and np.array_equal(m_o, m_p)
+    assert n_o > 10
+
+
+def py_search_triangulation(k1, d1, n1, has1, ur1, k2, d2, n2, has2, ur2, f12, ex, ey, sf2, sg2, only_stereo):
+    """Independent restatement of ORBmatcher.cc:810-1018 + :188-215 in float32 steps."""
+    F = [F32(v) for v in np.asarray(f12, np.float32).reshape(9)]
+    m12 = np.full(len(k1), -1, np.int32)
+    matched2 = np.zeros(len(k2), bool)
+    n = 0
+    hist = [[] for _ in range(30)]
+    factor = F32(30) / F32(360.0)
+
+    def epi(kp1, kp2):
+        x1, y1, x2, y2 = F32(kp1["x"]), F32(kp1["y"]), F32(kp2["x"]), F32(kp2["y"])
+        a = F32(F32(F32(x1 * F[0]) + F32(y1 * F[3])) + F[6])
+        b = F32(F32(F32(x1 * F[1]) + F32(y1 * F[4])) + F[7])
+        c = F32(F32(F32(x1 * F[2]) + F32(y1 * F[5])) + F[8])
+        num = F32(F32(F32(a * x2) + F32(b * y2)) + c)
+        den = F32(F32(a * a) + F32(b * b))
+        if den == 0:
+            return False
+        dsqr = F32(F32(num * num) / den)
+        return float(dsqr) < 3.84 * float(F32(sg2[int(kp2["octave"])]))
+    for nid in sorted(set(n1) & set(n2)):
+        for i1 in n1[nid]:
+            if has1[i1]:
+                continue
+            st1 = ur1[i1] >= 0
+            if only_stereo and not st1:
+                continue
+            best, bi = 50, -1
+            for i2 in n2[nid]:
+                if matched2[i2] or has2[i2]:
+                    continue
+                st2 = ur2[i2] >= 0
+                if only_stereo and not st2:
+                    continue
+                d = _dist(d1[i1], d2[i2])
+                if d > 50 or d > best:
+                    continue
+                if not st1 and not st2:
+                    dx, dy = F32(F32(ex) - F32(k2[i2]["x"])), F32(F32(ey) - F32(k2[i2]["y"]))
+                    if F32(F32(dx * dx) + F32(dy * dy)) < F32(F32(100) * F32(sf2[int(k2[i2]["octave"])])):
+                        continue
+                if epi(k1[i1], k2[i2]):
+                    bi, best = i2, d
+            if bi >= 0:
+                m12[i1] = bi
+                matched2[bi] = True
+                n += 1
+                rot = F32(k1[i1]["angle"]) - F32(k2[bi]["angle"])
+                if rot < 0:
+                    rot = F32(rot + F32(360.0))
+                b = _round_half_away(F32(rot * factor))
+                hist[0 if b == 30 else b].append(i1)
+    a1, a2, a3 = _three_maxima([len(h) for h in hist])
+    for b in range(30):
+        if b not in (a1, a2, a3):
+            for j in hist[b]:
+                m12[j] = -1
+                n -= 1
+    return n, np.array([(i, m12[i]) for i in range(len(k1)) if m12[i] >= 0], np.int32).reshape(-1, 2)
+
+
+def translation_fundamental(tx=2.0, ty=1.0):
+    """F12 of a pure image translation (x2 = x1 - tx, y2 = y1 - ty): epipolar lines through (x1,y1)-(tx,ty) along (tx,ty)."""
+    # line through p2 = p1 - t with direction t: normal n = (-ty, tx); a = n.x, b = n.y, c = -(n . (p1 - t))
+    # [a b c] = [x1 y1 1] * F12  with  F12 = [[0, 0, ty], [0, 0, -tx], [-ty, tx, 0]]
+    return np.array([[0, 0, ty], [0, 0, -tx], [-ty, tx, 0]], np.float32)
+
+
+@pytest.mark.parametrize("only_stereo", [0, 1])
+def test_search_for_triangulation_vs_python(frames, only_stereo):
+    k0, d0, k1, d1, sf = frames
+    rng = np.random.default_rng(12 + only_stereo)
+    has0, has1 = (rng.random(len(k0)) < 0.3).astype(np.uint8), (rng.random(len(k1)) < 0.3).astype(np.uint8)
+    ur0 = np.where(rng.random(len(k0)) < 0.5, k0["x"] - 10, -1).astype(np.float32)
+    ur1 = np.where(rng.random(len(k1)) < 0.5, k1["x"] - 10, -1).astype(np.float32)
+    n0, n1 = _nodes(d0, rng), _nodes(d1, rng)
+    for drop in list(n0)[::6]:
+        del n0[drop]
+    sg = (sf * sf).astype(np.float32)
+    f12 = translation_fundamental()
+    ex, ey = 320.0, 200.0
+    v0, keep0 = hb.bow_view(k0, d0, n0, has0, ur0)
+    v1, keep1 = hb.bow_view(k1, d1, n1, has1, ur1)
+    n_o, p_o = hb.search_triangulation("oracle", v0, v1, f12, ex, ey, sf, sg, only_stereo)
+    n_p, p_p = py_search_triangulation(k0, d0, n0, has0, ur0, k1, d1, n1, has1, ur1, f12, ex, ey, sf, sg, only_stereo)
+    assert n_o == n_p and np.array_equal(p_o, p_p)
+    assert n_o > 5
+
+
+def py_window_search(kps, desc, ur_kf, q, sf, th, max_dist, inv_sigma2=None, occupied=None):
+    """Independent restatement of the candidate loop of Fuse / SearchByProjection(KF,Scw) / SearchBySim3."""
+    grid = PyGrid(kps)
+    occ = None if occupied is None else occupied.copy()
+    best = np.full(len(q), -1, np.int32)
+    n = 0
+    for i, p in enumerate(q):
+        lvl = int(p["level"])
+        u, v, ur = F32(p["u"]), F32(p["v"]), F32(p["ur"])
+        b, bi = 256, -1
+        for idx in grid.area(u, v, F32(th) * F32(sf[lvl]), -1, -1):
+            if occ is not None and occ[idx] != -1:
+                continue
+            kl = int(kps[idx]["octave"])
+            if kl < lvl - 1 or kl > lvl:
+                continue
+            if inv_sigma2 is not None:
+                ex, ey = F32(u - F32(kps[idx]["x"])), F32(v - F32(kps[idx]["y"]))
+                if ur_kf is not None and ur_kf[idx] >= 0:
+                    er = F32(ur - F32(ur_kf[idx]))
+                    e2 = F32(F32(F32(ex * ex) + F32(ey * ey)) + F32(er * er))
+                    if float(F32(e2 * F32(inv_sigma2[kl]))) > 7.8:
+                        continue
+                else:
+                    e2 = F32(F32(ex * ex) + F32(ey * ey))
+                    if float(F32(e2 * F32(inv_sigma2[kl]))) > 5.99:
+                        continue
+            d = _dist(p["desc"], desc[idx])
+            if d < b:
+                b, bi = d, idx
+        if b <= max_dist:
+            best[i] = bi
+            n += 1
+            if occ is not None:
+                occ[bi] = i
+    return n, best, occ
+
+
+def _window_queries(k_src, d_src, rng, jitter=1.5):
+    q = np.zeros(len(k_src), hb.WINDOW_QUERY)
+    q["u"] = k_src["x"] - 2 + rng.normal(0, jitter, len(k_src)).astype(np.float32)
+    q["v"] = k_src["y"] - 1 + rng.normal(0, jitter, len(k_src)).astype(np.float32)
+    q["ur"] = q["u"] - rng.uniform(5, 30, len(k_src)).astype(np.float32)
+    q["level"] = np.minimum(k_src["octave"] + (rng.random(len(k_src)) < 0.3), 3)
+    q["src"], q["desc"] = np.arange(len(k_src)), d_src
+    return q
+
+
+def test_fuse_searches_vs_python(frames):
+    k0, d0, k1, d1, sf = frames
+    rng = np.random.default_rng(14)
+    ur1 = np.where(rng.random(len(k1)) < 0.6, k1["x"] - rng.uniform(5, 30, len(k1)), -1).astype(np.float32)
+    view, keep = hb.frame_view(k1, d1, ur1)
+    q = _window_queries(k0, d0, rng)
+    inv_s2 = (1.0 / (sf * sf)).astype(np.float32)
+    n_o, b_o = hb.fuse("oracle", view, q, sf, 3.0, inv_s2)          # Fuse(pKF, vpMapPoints, th = 3)
+    n_p, b_p, _ = py_window_search(k1, d1, ur1, q, sf, 3.0, 50, inv_s2)
+    assert n_o == n_p and np.array_equal(b_o, b_p) and n_o > 20
+    n_o2, b_o2 = hb.fuse("oracle", view, q, sf, 4.0)                # Fuse(pKF, Scw, vpPoints, th = 4)
+    n_p2, b_p2, _ = py_window_search(k1, d1, ur1, q, sf, 4.0, 50)
+    assert n_o2 == n_p2 and np.array_equal(b_o2, b_p2) and n_o2 >= n_o
+
+
+def test_search_by_projection_sim_vs_python(frames):
+    k0, d0, k1, d1, sf = frames
+    rng = np.random.default_rng(15)
+    view, keep = hb.frame_view(k1, d1)
+    q = _window_queries(k0, d0, rng)
+    m0 = np.where(rng.random(len(k1)) < 0.2, hb.MATCH_TAKEN, hb.MATCH_FREE).astype(np.int32)
+    n_o, m_o = hb.search_projection_sim("oracle", view, q, m0, sf, 10)
+    n_p, _, m_p = py_window_search(k1, d1, None, q, sf, 10.0, 50, occupied=m0)
+    assert n_o == n_p and np.array_equal(m_o, m_p) and n_o > 20
+
+
+def test_search_by_sim3_vs_python(frames):
+    k0, d0, k1, d1, sf = frames
+    rng = np.random.default_rng(16)
+    v0, keep0 = hb.frame_view(k0, d0)
+    v1, keep1 = hb.frame_view(k1, d1)
+    q12 = _window_queries(k0, d0, rng)[rng.random(len(k0)) < 0.8]
+    q21 = _window_queries(k1, d1, rng)
+    q21["u"] += 4
+    q21["v"] += 2                                                     # frame 1 -> frame 0 is the opposite shift
+    q21 = q21[rng.random(len(k1)) < 0.8]
+    n_o, m_o = hb.search_sim3("oracle", v0, v1, q12, q21, sf, sf, 7.5)
+    _, b12, _ = py_window_search(k1, d1, None, q12, sf, 7.5, 100)
+    _, b21, _ = py_window_search(k0, d0, None, q21, sf, 7.5, 100)
+    m1, m2 = np.full(len(k0), -1), np.full(len(k1), -1)
+    m1[q12["src"][b12 >= 0]] = b12[b12 >= 0]
+    m2[q21["src"][b21 >= 0]] = b21[b21 >= 0]
+    want = np.array([m1[i] if m1[i] >= 0 and m2[m1[i]] == i else -1 for i in range(len(k0))], np.int32)
+    assert np.array_equal(m_o, want) and n_o == (want >= 0).sum() and n_o > 20
