@@ -418,7 +418,7 @@ int amos_orb_create(const amos_orb_params *params, int max_width, int max_height
 {
     if (!params || !out || max_width < 1 || max_height < 1 || max_batch < 1 || params->n_levels < 1 ||
         params->n_levels > AMOS_MAX_LEVELS || params->n_features < 1 || !(params->scale_factor > 1.0f) ||
-        !(params->scale_factor <= 2.0f)) {  // k_pyramid_level's 12-byte source window needs scaleFactor <= 2
+        !(params->scale_factor <= 2.0f)) {  // k_pyramid_level: scaleFactor < 2 uses the 8-byte tap window, 2.0 the four-load variant
         set_error("amos_orb_create: invalid argument");
         return AMOS_ERR_INVALID;
     }

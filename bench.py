@@ -338,6 +338,8 @@ def main():
             "stage_frac_of_hbm_peak": {k: (round(alg[k] * Bl / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if v > 0 else None)
                                        for k, v in stage_ms.items()},
             "digest_per_rank": digest_all,
+            # Hamming throughput of the N x N match as N_q * N_t * 256 bit comparisons per second
+            "hamming_bitops_per_s": round(fps * mean_kp * mean_kp * 256.0, 1),
         }
         if gated:
             out["gated_match"] = gated

@@ -58,6 +58,20 @@ def test_stages_bit_exact(gpu_lib, ob, synth, w, h, nf, nl):
     assert len(kg) >= nf * 0.9
 
 
+@pytest.mark.parametrize("sf,nl", [(1.5, 5), (2.0, 3), (1.1, 6)])
+def test_other_scale_factors(gpu_lib, ob, synth, sf, nl):
+    """scaleFactor 2.0 takes the four-loads-per-row pyramid kernel (the 8-byte tap window needs scaleFactor < 2)."""
+    img = synth.frame(17, 1)
+    ext = gpu_lib.OrbExtractor(n_features=800, scale_factor=sf, n_levels=nl)
+    orc = ob.Oracle(n_features=800, scale_factor=sf, n_levels=nl)
+    kg, dg = ext.extract(img)
+    ko, do = orc.extract(img)
+    _same(kg, ko, "keypoints")
+    _same(dg, do, "descriptors")
+    for l in range(nl):
+        _same(ext.level_image(l, padded=True), orc.level_image(l, padded=True), f"level {l} incl. border")
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_extract_many_frames(gpu_lib, ob, synth, seed):
     ext, orc = _pair(gpu_lib, ob, 640, 480, 1000, 8)
