@@ -61,42 +61,6 @@ __device__ __forceinline__ uint8_t *level_origin(uint8_t *pyr, const Geom *g, in
 // grid = (ceil(groups/64), ceil((h+38)/4), frames), block = (64, 4).
 constexpr int kPyrRows = 8;  // padded rows per thread (x taps are loaded once; consecutive rows share source rows)
 
-__global__ __launch_bounds__(256) void k_pyramid_level0(const uint8_t *__restrict__ src, size_t srcFrameStride,
-                                                       size_t srcRowStride, uint8_t *__restrict__ pyr,
-                                                       const Geom *__restrict__ g, int srcAligned)
-{
-    const LevelGeom &lg = g->lv[0];
-    const int frame = blockIdx.z;
-    const int gx = blockIdx.x * 64 + threadIdx.x;  // dword column, starts at x = -kPadLeft
-    const int row0 = (blockIdx.y * 4 + threadIdx.y) * kPyrRows;
-    const int groups = (kPadLeft + lg.w + kEdge + 3) >> 2;
-    if (gx >= groups) return;
-    const int x0 = gx * 4 - kPadLeft;
-    const bool interior = srcAligned && x0 >= 0 && x0 + 3 < lg.w;  // one aligned source dword
-    int xi[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int xo = x0 + k;
-        xo = xo < -kEdge ? -kEdge : (xo > lg.w + kEdge - 1 ? lg.w + kEdge - 1 : xo);
-        xi[k] = reflect101(xo, lg.w);
-    }
-    uint8_t *plane = level_origin(pyr, g, frame, 0);
-    const uint8_t *s0 = src + (size_t)frame * srcFrameStride;
-#pragma unroll
-    for (int r = 0; r < kPyrRows; r++) {
-        const int yo = row0 + r - kEdge;
-        if (yo >= lg.h + kEdge) break;
-        const uint8_t *s = s0 + (size_t)reflect101(yo, lg.h) * srcRowStride;  // caller's stride: may exceed 24 bits
-        uint32_t packed;
-        if (interior) {
-            packed = *reinterpret_cast<const uint32_t *>(s + x0);
-        } else {
-            packed = (uint32_t)s[xi[0]] | ((uint32_t)s[xi[1]] << 8) | ((uint32_t)s[xi[2]] << 16) | ((uint32_t)s[xi[3]] << 24);
-        }
-        *reinterpret_cast<uint32_t *>(plane + __mul24(yo, lg.stride) + x0) = packed;
-    }
-}
-
 // Level 0, 16 bytes per lane.  Interior pieces (16 consecutive bytes of the padded plane whose source is
 // 16 consecutive image bytes) are one dwordx4 load (any source alignment) and one aligned dwordx4 store,
 // kImportRows rows per thread.  The pieces that touch the reflect-101 border gather byte by byte; they

@@ -13,7 +13,12 @@ from .pre import cxx_marshalling, fast_base_transform, resize_f32_cv
 
 
 class MaskEngine:
-    def __init__(self, weight_path=None, device=None, seed=0):
+    def __init__(self, weight_path=None, device=None, seed=0, conv_dtype=None):
+        """conv_dtype: None = float32 everywhere (the default, what every parity statement refers to), or
+        torch.float16 / torch.bfloat16 to run the network's convolutions under autocast (fp32 accumulation; the
+        detection and mask post-processing stay float32).  The reference runs its cuDNN convolutions in TF32 on the
+        GPUs it targets (10-bit mantissa, PyTorch's default), so float16 is the same precision class; it is an
+        explicit opt-in because its mask IoU against the reference cannot be pinned without the trained weights."""
         if device is None:
             if not torch.cuda.is_available():
                 raise RuntimeError("MaskEngine needs a GPU (PyTorch-ROCm); pass device='cpu' explicitly for CPU tests")
@@ -28,6 +33,7 @@ class MaskEngine:
         self.net.eval().to(self.device)
         # NHWC activations/weights: MIOpen's fp32 convolutions run the 550x550 ResNet-50-FPN forward 29 % faster
         # than NCHW on MI355X (22.2 vs 31.2 ms per 16 frames, tools/mask_prof.py); results agree to 3e-7.
+        self.conv_dtype = conv_dtype
         self.channels_last = self.device.type == "cuda"
         if self.channels_last:
             self.net.to(memory_format=torch.channels_last)
@@ -36,7 +42,11 @@ class MaskEngine:
     def _forward(self, x):
         if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
-        return self.net(x)
+        if self.conv_dtype is None:
+            return self.net(x)
+        with torch.autocast(self.device.type, dtype=self.conv_dtype):
+            pred = self.net(x)
+        return {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in pred.items()}
 
     @torch.no_grad()
     def network_outputs(self, image_chw):

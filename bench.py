@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--streams", type=int, default=0, help="independent lanes (handle + HIP streams) the batch is split over (default 4; 2 with the mask)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--mask-conv-dtype", choices=["fp32", "fp16", "bf16"], default="fp32",
+                    help="precision of the mask network's convolutions (c3 only; fp32 is the parity configuration)")
     ap.add_argument("--check", action="store_true", help="verify one frame of the batch against the oracle")
     ap.add_argument("--cpu-all-cores", type=int, default=0, help="also time the oracle on this many processes (0 = off)")
     args = ap.parse_args()
@@ -158,7 +160,8 @@ def main():
     engine = None
     if use_mask:
         mask_mod = importlib.import_module("amos_slam_amd.mask")
-        engine = mask_mod.MaskEngine(device=f"cuda:{local_rank}", seed=0)
+        engine = mask_mod.MaskEngine(device=f"cuda:{local_rank}", seed=0,
+                                     conv_dtype={"fp32": None, "fp16": torch.float16, "bf16": torch.bfloat16}[args.mask_conv_dtype])
         with torch.no_grad():
             head = engine.net.prediction_layers[0].conf_layer.bias
             b = head.detach().cpu().view(3, 81).clone()
@@ -320,7 +323,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8",
+            "dtype": "u8" if not use_mask else "u8 (ORB, matcher) + %s (mask network)" % args.mask_conv_dtype,
             "data": "synthetic",
             "config": {"workload": cfg["label"], "frames_per_step_per_gpu": B, "lanes_per_gpu": S, "frames_per_launch": Bl, "width": W, "height": H,
                        "n_features": cfg["n_features"], "n_levels": cfg["n_levels"], "ini_th_fast": 20, "min_th_fast": 7,

@@ -43,3 +43,16 @@ with torch.no_grad():
     out = eng.net.to(memory_format=torch.channels_last)(xcl)
     for k in ("loc", "conf", "mask", "proto"):
         print("  NHWC vs NCHW max abs diff", k, float((ref[k].float() - out[k].float()).abs().max()), flush=True)
+    # reduced-precision convolutions (opt-in): speed and agreement of the final person masks with fp32
+    eng.net.to(memory_format=torch.channels_last)
+    e32 = eng
+    masks32 = e32.eval_bgr_batch(frames)
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        e32.conv_dtype = dt
+        print(f"eval_bgr_batch(32) {name}  ms", round(T(lambda: e32.eval_bgr_batch(frames)), 2), flush=True)
+        m = e32.eval_bgr_batch(frames)
+        a, b = masks32 > 0, m > 0
+        inter, union = (a & b).flatten(1).sum(1).float(), (a | b).flatten(1).sum(1).float().clamp(min=1)
+        print(f"  mask IoU vs fp32 ({name}): min {float((inter / union).min()):.4f} mean {float((inter / union).mean()):.4f}", flush=True)
+    e32.conv_dtype = None
+    print("eval_bgr_batch(32) fp32  ms", round(T(lambda: e32.eval_bgr_batch(frames)), 2), flush=True)
