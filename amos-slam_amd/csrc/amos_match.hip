@@ -206,14 +206,19 @@ struct WindowArgs {
     int capacity, mode, initDist;
 };
 
+constexpr int kWindowLanes = 8;  // lanes per query: each takes every 8th grid column of the window
+
 __global__ __launch_bounds__(256) void k_window_best2(const WindowArgs a, amos_best2 *__restrict__ out)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, pair = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x, pair = blockIdx.y;
+    const int i = t / kWindowLanes, sub = t % kWindowLanes;
     const int fq = a.pairsQ[pair], ft = a.pairsT[pair];
-    if (i >= min(a.counts[fq], a.capacity)) return;
-    const amos_keypoint qk = a.kps[(size_t)fq * a.capacity + i];
-    const Desc qd = load_desc(a.desc + ((size_t)fq * a.capacity + i) * 32);
-    const size_t po = (size_t)pair * a.capacity + i;
+    const int nq = min(a.counts[fq], a.capacity);
+    const bool active = i < nq;
+    const int iq = active ? i : 0;  // idle lanes shadow query 0 so that the group shuffles stay convergent
+    const amos_keypoint qk = a.kps[(size_t)fq * a.capacity + iq];
+    const Desc qd = load_desc(a.desc + ((size_t)fq * a.capacity + iq) * 32);
+    const size_t po = (size_t)pair * a.capacity + iq;
     const float u = a.queryUv ? a.queryUv[2 * po] : qk.x, v = a.queryUv ? a.queryUv[2 * po + 1] : qk.y;
     const int oct = qk.octave;
     const float r = __fmul_rn(a.th, a.scale[oct]);
@@ -222,7 +227,6 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowArgs a, amos_b
     const bool checkLevels = minLevel > 0 || maxLevel >= 0;
     const bool gateRight = a.uRight != nullptr && a.queryInvZ != nullptr;
     const float ur = gateRight ? __fsub_rn(u, __fmul_rn(a.mbf, a.queryInvZ[po])) : 0.f;
-    amos_best2 res = {-1, a.initDist, -1, a.initDist};
     int x0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(u, a.minX), r), a.wInv));
     int x1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(u, a.minX), r), a.wInv));
     int y0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(v, a.minY), r), a.hInv));
@@ -235,7 +239,11 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowArgs a, amos_b
     const amos_keypoint *tk = a.kps + (size_t)ft * a.capacity;
     const uint8_t *td = a.desc + (size_t)ft * a.capacity * 32;
     const float *tr = gateRight ? a.uRight + (size_t)ft * a.capacity : nullptr;
-    for (int ix = x0; ix <= x1; ix++) {
+    // The reference walks the cells x-major, then y, then insertion order = ascending CSR position, and its
+    // strict-< updates keep the FIRST of equal distances: a min-reduction over keys (dist << 16 | CSR position)
+    // gives the same best and second best whatever the evaluation order.
+    unsigned best = 0xffffffffu, second = 0xffffffffu;
+    for (int ix = x0 + sub; ix <= x1; ix += kWindowLanes) {
         // cells (ix, y0..y1) are consecutive in the CSR: one item range per column
         const int b = cs[ix * AMOS_FRAME_GRID_ROWS + y0], e = y1 >= y0 ? cs[ix * AMOS_FRAME_GRID_ROWS + y1 + 1] : b;
         for (int j = b; j < e; j++) {
@@ -244,19 +252,26 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowArgs a, amos_b
             if (checkLevels && (k.octave < minLevel || (maxLevel >= 0 && k.octave > maxLevel))) continue;
             if (!(fabsf(__fsub_rn(k.x, u)) < r && fabsf(__fsub_rn(k.y, v)) < r)) continue;
             if (gateRight) {
-                const float t = tr[idx];
-                if (t > 0 && fabsf(__fsub_rn(ur, t)) > r) continue;
+                const float tt = tr[idx];
+                if (tt > 0 && fabsf(__fsub_rn(ur, tt)) > r) continue;
             }
             const int d = hamming256(qd, load_desc(td + (size_t)idx * 32));
-            if (d < res.best_dist) {
-                res.second_dist = res.best_dist; res.second_idx = res.best_idx;
-                res.best_dist = d; res.best_idx = idx;
-            } else if (d < res.second_dist) {
-                res.second_dist = d; res.second_idx = idx;
-            }
+            if (d < a.initDist) top2_push(best, second, ((unsigned)d << 16) | (unsigned)j);
         }
     }
-    out[po] = res;
+#pragma unroll
+    for (int off = kWindowLanes / 2; off > 0; off >>= 1) {
+        const unsigned ob = __shfl_xor(best, off, kWindowLanes), os = __shfl_xor(second, off, kWindowLanes);
+        top2_merge(best, second, ob, os);
+    }
+    if (active && sub == 0) {
+        amos_best2 res;
+        res.best_idx = best == 0xffffffffu ? -1 : it[best & 0xffffu];
+        res.best_dist = best == 0xffffffffu ? a.initDist : (int)(best >> 16);
+        res.second_idx = second == 0xffffffffu ? -1 : it[second & 0xffffu];
+        res.second_dist = second == 0xffffffffu ? a.initDist : (int)(second >> 16);
+        out[po] = res;
+    }
 }
 
 // ---- brute-force best / second best over ALL train descriptors, for a batch of (query set,
@@ -564,7 +579,7 @@ int amos_frame_grid_build_batch_device(amos_match *m, const int32_t *d_grid_cell
 int amos_match_window_best2_batch_device(amos_match *m, const amos_window_search *w, amos_best2 *d_out)
 {
     if (!m || !w || !d_out || !w->d_kps || !w->d_desc || !w->d_counts || !w->d_cell_start || !w->d_items || !w->d_pairs_q ||
-        !w->d_pairs_t || w->n_pairs < 1 || w->capacity < 1 || w->n_levels < 1 || w->n_levels > AMOS_MAX_LEVELS || !w->scale_factors ||
+        !w->d_pairs_t || w->n_pairs < 1 || w->capacity < 1 || w->capacity > 65535 || w->n_levels < 1 || w->n_levels > AMOS_MAX_LEVELS || !w->scale_factors ||
         !(w->max_x > w->min_x) || !(w->max_y > w->min_y) || w->mode < 0 || w->mode > 2 || !(w->th > 0)) {
         set_error("amos_match_window_best2_batch_device: invalid argument");
         return AMOS_ERR_INVALID;
@@ -578,7 +593,7 @@ int amos_match_window_best2_batch_device(amos_match *m, const amos_window_search
     a.wInv = static_cast<float>(AMOS_FRAME_GRID_COLS) / static_cast<float>(w->max_x - w->min_x);  // Frame.cc:302-303
     a.hInv = static_cast<float>(AMOS_FRAME_GRID_ROWS) / static_cast<float>(w->max_y - w->min_y);
     a.capacity = w->capacity; a.mode = w->mode; a.initDist = w->init_dist;
-    hipLaunchKernelGGL(k_window_best2, dim3((w->capacity + 255) / 256, w->n_pairs), dim3(256), 0, m->stream, a, d_out);
+    hipLaunchKernelGGL(k_window_best2, dim3((w->capacity * kWindowLanes + 255) / 256, w->n_pairs), dim3(256), 0, m->stream, a, d_out);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }
