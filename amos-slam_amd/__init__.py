@@ -31,7 +31,7 @@ EXPORTS = [
     "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
-    "amos_match_bruteforce_best2_batch_device",
+    "amos_match_bruteforce_best2_batch_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device",
 ]
 
 
@@ -293,6 +293,32 @@ class OrbExtractor:
     @property
     def stream(self):
         return self.L.amos_orb_stream(self.h)
+
+
+class MaskPreprocessor:
+    """amos_mask_pre_*: BGR frames -> the mask network's [n, 3, 550, 550] input tensor in three HIP kernels
+    (yolact.cc:220, 385-451; yolact_interface.py:862-866; utils/augmentations.py:616-657)."""
+
+    def __init__(self, width=640, height=480, max_batch=16, device=0, stream=None):
+        self.L = lib()
+        p = C.c_void_p()
+        _check(self.L.amos_mask_pre_create(C.c_int(device), C.c_void_p(stream), C.c_int(width), C.c_int(height), C.c_int(max_batch),
+                                           C.byref(p)), "amos_mask_pre_create")
+        self.p, self.max_batch, self.shape = p, max_batch, (height, width)
+        self.L.amos_mask_pre_stream.restype = C.c_void_p
+        self.stream_ptr = self.L.amos_mask_pre_stream(self.p)
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.amos_mask_pre_destroy(self.p)
+            self.p = None
+
+    def __del__(self):
+        self.close()
+
+    def run(self, d_bgr, n_frames, d_out):
+        _check(self.L.amos_mask_preprocess_batch_device(self.p, C.c_void_p(d_bgr), C.c_int(n_frames), C.c_void_p(d_out)),
+               "amos_mask_preprocess_batch_device")
 
 
 def image_bounds(width, height, fx, fy, cx, cy, dist_coef):

@@ -1,0 +1,202 @@
+// amos_mask_pre.hip -- the mask pass's pre-processing chain on the device: from the raw BGR
+// frame to the network's input tensor in three small kernels, numerically what the reference does in three
+// places:
+//   A  yolact::evalImage (yolact.cc:220, 385-451): cv::resize(BGR u8 -> W480 x H640) [sic, swapped], u8 / 255.0
+//      as CHW float, and eval_image's "* 255" (yolact_interface.py:862-864)            -> float HWC 640 x 480
+//   B  eval_image's cv2.resize(float32, (640, 480)) (yolact_interface.py:865)          -> float HWC 480 x 640
+//   C  FastBaseTransform (utils/augmentations.py:616-657): bilinear to 550 x 550 (align_corners=False),
+//      (x - MEANS) / STD in BGR order, channels swapped to RGB                         -> float CHW 3 x 550 x 550
+// The two OpenCV resizes use host-built tap tables (8-bit: 11-bit fixed point; float32: float
+// weights), the u8 -> float step is a 256-entry table made on the host with the reference's double division.
+// PyTorch is not involved: the network consumes d_out directly.
+#include "amos_common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace amos {
+
+constexpr int kNetSize = 550;            // cfg.max_size
+constexpr int kMidW = 480, kMidH = 640;  // yolact.cc:220  cv::Size(480, 640)
+constexpr int kBackW = 640, kBackH = 480;  // yolact_interface.py:865
+
+struct FixTap { int s0, s1, a0, a1; };      // 8-bit cv::resize: source indices and 11-bit weights
+struct FltTap { int s0, s1; float f0, f1; };  // float cv::resize: source indices, (1 - f) and f
+
+// A: grid = (ceil(480 * 640 / 256), frames); one thread per intermediate pixel, three channels
+__global__ __launch_bounds__(256) void k_mask_pre_a(const uint8_t *__restrict__ bgr, int srcW, int srcH, const FixTap *__restrict__ tx,
+                                                   const FixTap *__restrict__ ty, const float *__restrict__ lut, float *__restrict__ mid)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
+    if (p >= kMidW * kMidH) return;
+    const int y = p / kMidW, x = p - y * kMidW;
+    const FixTap ax = tx[x], ay = ty[y];
+    const uint8_t *r0 = bgr + ((size_t)frame * srcH + ay.s0) * srcW * 3, *r1 = bgr + ((size_t)frame * srcH + ay.s1) * srcW * 3;
+    float *o = mid + ((size_t)frame * kMidH * kMidW + p) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int h0 = r0[ax.s0 * 3 + c] * ax.a0 + r0[ax.s1 * 3 + c] * ax.a1;
+        const int h1 = r1[ax.s0 * 3 + c] * ax.a0 + r1[ax.s1 * 3 + c] * ax.a1;
+        const int v = (((ay.a0 * (h0 >> 4)) >> 16) + ((ay.a1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        o[c] = lut[v];  // float(double(v) / 255.0) * 255.0f
+    }
+}
+
+// B: grid = (ceil(640 * 480 / 256), frames); cv::resize float INTER_LINEAR, horizontal then vertical, no FMA
+__global__ __launch_bounds__(256) void k_mask_pre_b(const float *__restrict__ mid, const FltTap *__restrict__ tx, const FltTap *__restrict__ ty,
+                                                   float *__restrict__ back)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
+    if (p >= kBackW * kBackH) return;
+    const int y = p / kBackW, x = p - y * kBackW;
+    const FltTap ax = tx[x], ay = ty[y];
+    const float *r0 = mid + ((size_t)frame * kMidH + ay.s0) * kMidW * 3, *r1 = mid + ((size_t)frame * kMidH + ay.s1) * kMidW * 3;
+    float *o = back + ((size_t)frame * kBackH * kBackW + p) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float h0 = __fadd_rn(__fmul_rn(r0[ax.s0 * 3 + c], ax.f0), __fmul_rn(r0[ax.s1 * 3 + c], ax.f1));
+        const float h1 = __fadd_rn(__fmul_rn(r1[ax.s0 * 3 + c], ax.f0), __fmul_rn(r1[ax.s1 * 3 + c], ax.f1));
+        o[c] = __fadd_rn(__fmul_rn(h0, ay.f0), __fmul_rn(h1, ay.f1));
+    }
+}
+
+// C: grid = (ceil(550 * 550 / 256), frames); torch.nn.functional.interpolate(bilinear, align_corners=False),
+// normalisation and the BGR -> RGB swap; writes planar CHW
+__global__ __launch_bounds__(256) void k_mask_pre_c(const float *__restrict__ back, float *__restrict__ out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
+    if (p >= kNetSize * kNetSize) return;
+    const int oy = p / kNetSize, ox = p - oy * kNetSize;
+    const float sh = (float)kBackH / (float)kNetSize, sw = (float)kBackW / (float)kNetSize;
+    const float hr = fmaxf(__fsub_rn(__fmul_rn(sh, __fadd_rn((float)oy, 0.5f)), 0.5f), 0.f);
+    const float wr = fmaxf(__fsub_rn(__fmul_rn(sw, __fadd_rn((float)ox, 0.5f)), 0.5f), 0.f);
+    const int h1 = (int)hr, w1 = (int)wr;
+    const int h1p = h1 < kBackH - 1 ? 1 : 0, w1p = w1 < kBackW - 1 ? 1 : 0;
+    const float hl1 = __fsub_rn(hr, (float)h1), hl0 = __fsub_rn(1.f, hl1);
+    const float wl1 = __fsub_rn(wr, (float)w1), wl0 = __fsub_rn(1.f, wl1);
+    const float *b = back + (size_t)frame * kBackH * kBackW * 3;
+    const float *p00 = b + ((size_t)h1 * kBackW + w1) * 3, *p01 = p00 + w1p * 3, *p10 = p00 + (size_t)h1p * kBackW * 3, *p11 = p10 + w1p * 3;
+    const float mean[3] = {103.94f, 116.78f, 123.68f}, stdv[3] = {57.38f, 57.12f, 58.40f};  // BGR, data/config.py:28-29
+    float *o = out + (size_t)frame * 3 * kNetSize * kNetSize + p;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float top = __fadd_rn(__fmul_rn(wl0, p00[c]), __fmul_rn(wl1, p01[c]));
+        const float bot = __fadd_rn(__fmul_rn(wl0, p10[c]), __fmul_rn(wl1, p11[c]));
+        const float v = __fadd_rn(__fmul_rn(hl0, top), __fmul_rn(hl1, bot));
+        o[(size_t)(2 - c) * kNetSize * kNetSize] = __fdiv_rn(__fsub_rn(v, mean[c]), stdv[c]);  // RGB plane order
+    }
+}
+
+}  // namespace amos
+
+using namespace amos;
+
+struct amos_mask_pre {
+    int device = 0, width = 0, height = 0, maxBatch = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    FixTap *dFixX = nullptr, *dFixY = nullptr;
+    FltTap *dFltX = nullptr, *dFltY = nullptr;
+    float *dLut = nullptr, *dMid = nullptr, *dBack = nullptr;
+};
+
+// cv::resize INTER_LINEAR source index and fraction per destination index (double -> float as OpenCV does);
+// the horizontal pass clamps the fraction at both ends, the vertical pass only clips the indices.
+static void axis_taps(int srcN, int dstN, bool clampFraction, std::vector<int> &s0, std::vector<int> &s1, std::vector<float> &f)
+{
+    const double scale = 1.0 / ((double)dstN / (double)srcN);
+    s0.resize(dstN); s1.resize(dstN); f.resize(dstN);
+    for (int d = 0; d < dstN; d++) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(fx);
+        fx -= (float)s;
+        if (clampFraction) {
+            if (s < 0) { fx = 0; s = 0; }
+            if (s >= srcN - 1) { fx = 0; s = srcN - 1; }
+        }
+        s0[d] = std::min(std::max(s, 0), srcN - 1);
+        s1[d] = std::min(std::max(s + 1, 0), srcN - 1);
+        f[d] = fx;
+    }
+}
+
+static int round_even(float v) { return (int)std::nearbyintf(v); }
+
+extern "C" {
+
+int amos_mask_pre_create(int device, void *stream, int width, int height, int max_batch, amos_mask_pre **out)
+{
+    if (!out || width < 2 || height < 2 || max_batch < 1) { set_error("amos_mask_pre_create: invalid argument"); return AMOS_ERR_INVALID; }
+    AMOS_HIP_CHECK(hipSetDevice(device));
+    amos_mask_pre *p = new amos_mask_pre();
+    p->device = device; p->width = width; p->height = height; p->maxBatch = max_batch;
+    if (stream) p->stream = (hipStream_t)stream;
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete p; return AMOS_ERR_DEVICE; }
+        p->ownStream = true;
+    }
+    std::vector<int> s0, s1;
+    std::vector<float> f;
+    auto fix = [&](int srcN, int dstN, bool clamp, FixTap **dst) -> hipError_t {
+        axis_taps(srcN, dstN, clamp, s0, s1, f);
+        std::vector<FixTap> t(dstN);
+        for (int d = 0; d < dstN; d++) t[d] = FixTap{s0[d], s1[d], round_even((1.f - f[d]) * 2048.f), round_even(f[d] * 2048.f)};
+        hipError_t e = hipMalloc((void **)dst, sizeof(FixTap) * dstN);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, t.data(), sizeof(FixTap) * dstN, hipMemcpyHostToDevice);
+    };
+    auto flt = [&](int srcN, int dstN, bool clamp, FltTap **dst) -> hipError_t {
+        axis_taps(srcN, dstN, clamp, s0, s1, f);
+        std::vector<FltTap> t(dstN);
+        for (int d = 0; d < dstN; d++) t[d] = FltTap{s0[d], s1[d], 1.0f - f[d], f[d]};
+        hipError_t e = hipMalloc((void **)dst, sizeof(FltTap) * dstN);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, t.data(), sizeof(FltTap) * dstN, hipMemcpyHostToDevice);
+    };
+    float lut[256];
+    for (int v = 0; v < 256; v++) lut[v] = (float)((double)v / 255.0) * 255.0f;  // yolact.cc:424-431, yolact_interface.py:864
+    hipError_t e = fix(width, kMidW, true, &p->dFixX);
+    if (e == hipSuccess) e = fix(height, kMidH, false, &p->dFixY);
+    if (e == hipSuccess) e = flt(kMidW, kBackW, true, &p->dFltX);
+    if (e == hipSuccess) e = flt(kMidH, kBackH, false, &p->dFltY);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->dLut, sizeof(lut));
+    if (e == hipSuccess) e = hipMemcpy(p->dLut, lut, sizeof(lut), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->dMid, sizeof(float) * 3 * kMidW * kMidH * (size_t)max_batch);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->dBack, sizeof(float) * 3 * kBackW * kBackH * (size_t)max_batch);
+    if (e != hipSuccess) {
+        set_error("amos_mask_pre_create: %s", hipGetErrorString(e));
+        amos_mask_pre_destroy(p);
+        return AMOS_ERR_DEVICE;
+    }
+    *out = p;
+    return AMOS_OK;
+}
+
+void amos_mask_pre_destroy(amos_mask_pre *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    void *ptrs[] = {p->dFixX, p->dFixY, p->dFltX, p->dFltY, p->dLut, p->dMid, p->dBack};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (p->ownStream && p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+void *amos_mask_pre_stream(amos_mask_pre *p) { return p ? (void *)p->stream : nullptr; }
+
+int amos_mask_preprocess_batch_device(amos_mask_pre *p, const uint8_t *d_bgr, int n_frames, float *d_out)
+{
+    if (!p || !d_bgr || !d_out || n_frames < 1) { set_error("amos_mask_preprocess_batch_device: invalid argument"); return AMOS_ERR_INVALID; }
+    if (n_frames > p->maxBatch) { set_error("amos_mask_preprocess_batch_device: %d frames, handle made for %d", n_frames, p->maxBatch); return AMOS_ERR_CAPACITY; }
+    AMOS_HIP_CHECK(hipSetDevice(p->device));
+    hipLaunchKernelGGL(k_mask_pre_a, dim3((kMidW * kMidH + 255) / 256, n_frames), dim3(256), 0, p->stream, d_bgr, p->width, p->height, p->dFixX,
+                       p->dFixY, p->dLut, p->dMid);
+    hipLaunchKernelGGL(k_mask_pre_b, dim3((kBackW * kBackH + 255) / 256, n_frames), dim3(256), 0, p->stream, p->dMid, p->dFltX, p->dFltY, p->dBack);
+    hipLaunchKernelGGL(k_mask_pre_c, dim3((kNetSize * kNetSize + 255) / 256, n_frames), dim3(256), 0, p->stream, p->dBack, d_out);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+}  // extern "C"

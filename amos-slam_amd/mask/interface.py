@@ -34,10 +34,36 @@ class MaskEngine:
         # NHWC activations/weights: MIOpen's fp32 convolutions run the 550x550 ResNet-50-FPN forward 29 % faster
         # than NCHW on MI355X (22.2 vs 31.2 ms per 16 frames, tools/mask_prof.py); results agree to 3e-7.
         self.conv_dtype = conv_dtype
+        self.use_hip_pre = True   # GPU: pre-processing by the HIP kernels; False = the torch restatement (tests)
         self.channels_last = self.device.type == "cuda"
         if self.channels_last:
             self.net.to(memory_format=torch.channels_last)
             torch.backends.cudnn.benchmark = True  # MIOpen solver search on first use of a shape
+        self._hip_pre = {}  # (height, width) -> MaskPreprocessor, made on first use (GPU only)
+
+    def _preprocess_hip(self, frames):
+        """The whole pre-processing chain in three HIP kernels (libamos_frontend.so, amos_mask_pre_*): returns
+        the [b, 3, 550, 550] network input for [b, H, W, 3] uint8 frames on this engine's GPU."""
+        from .. import MaskPreprocessor
+        b, h, w = frames.shape[:3]
+        pre = self._hip_pre.get((h, w))
+        if pre is None or pre.max_batch < b:
+            pre = MaskPreprocessor(w, h, max(b, 16), device=self.device.index or 0, stream=None)
+            self._hip_pre[(h, w)] = pre
+        out = torch.empty((b, 3, 550, 550), dtype=torch.float32, device=self.device)
+        frames = frames.contiguous()
+        cur = torch.cuda.current_stream(self.device)
+        # the kernels run on the preprocessor's own stream: order them after the frames' producer and
+        # make the consumer (the network, on torch's stream) wait for them
+        ev_in = torch.cuda.Event()
+        ev_in.record(cur)
+        ext = torch.cuda.ExternalStream(pre.stream_ptr, device=self.device)
+        ext.wait_event(ev_in)
+        pre.run(frames.data_ptr(), b, out.data_ptr())
+        ev_out = torch.cuda.Event()
+        ev_out.record(ext)
+        cur.wait_event(ev_out)
+        return out
 
     def _forward(self, x):
         if self.channels_last:
@@ -79,9 +105,14 @@ class MaskEngine:
         B, H, W = frames.shape[:3]
         out = torch.zeros((B, H, W), dtype=torch.uint8, device=self.device)
         for b0 in range(0, B, chunk):
-            chw = cxx_marshalling(frames[b0:b0 + chunk])                      # [b, 3, 640, 480]
-            imgs = resize_f32_cv(chw.permute(0, 2, 3, 1) * 255, 640, 480)     # [b, 480, 640, 3]
-            pred = self._forward(fast_base_transform(imgs))
-            masks, _found = person_mask_batch(detect_batch(pred), imgs.shape[2], imgs.shape[1])
-            out[b0:b0 + imgs.shape[0]] = masks
+            part = frames[b0:b0 + chunk]
+            if self.device.type == "cuda" and self.use_hip_pre:
+                x = self._preprocess_hip(part)                                  # [b, 3, 550, 550]
+            else:
+                chw = cxx_marshalling(part)                                      # [b, 3, 640, 480]
+                imgs = resize_f32_cv(chw.permute(0, 2, 3, 1) * 255, 640, 480)    # [b, 480, 640, 3]
+                x = fast_base_transform(imgs)
+            pred = self._forward(x)
+            masks, _found = person_mask_batch(detect_batch(pred), 640, 480)      # eval_image resizes to 640 x 480 whatever came in
+            out[b0:b0 + part.shape[0]] = masks
         return out

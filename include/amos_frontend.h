@@ -287,6 +287,20 @@ typedef struct amos_window_search {
 } amos_window_search;
 int amos_match_window_best2_batch_device(amos_match *m, const amos_window_search *w, amos_best2 *d_out);
 
+/* ---------------------------------------------------------------- mask pre-processing (8f-4) - */
+
+/* The pre-processing chain of the mask pass on the device, from the raw BGR frame to the network input:
+ * yolact::evalImage's marshalling (yolact.cc:220, 385-451: cv::resize to W480 x H640, u8 / 255.0),
+ * eval_image's "* 255" and cv2.resize back to 640 x 480 (yolact_interface.py:862-866) and FastBaseTransform
+ * (utils/augmentations.py:616-657: bilinear to 550 x 550, (x - MEANS) / STD, BGR -> RGB).
+ * d_bgr: [n_frames][height][width][3] uint8; d_out: [n_frames][3][550][550] float32.  Asynchronous on the
+ * handle's stream (pass PyTorch's current stream so that the network simply follows). */
+typedef struct amos_mask_pre amos_mask_pre;
+int amos_mask_pre_create(int device, void *stream, int width, int height, int max_batch, amos_mask_pre **out);
+void amos_mask_pre_destroy(amos_mask_pre *p);
+void *amos_mask_pre_stream(amos_mask_pre *p); /* the hipStream_t the handle issues on */
+int amos_mask_preprocess_batch_device(amos_mask_pre *p, const uint8_t *d_bgr, int n_frames, float *d_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,6 +171,32 @@ def test_engine_end_to_end_gpu(mask, gpu_lib):
     assert (got & want).sum() / max((got | want).sum(), 1) >= 1 - 1e-3
 
 
+@pytest.mark.gpu
+def test_hip_preprocessing_matches_the_torch_chain(mask, gpu_lib):
+    """8f-4: amos_mask_preprocess_batch_device (three HIP kernels) against the torch restatement of the same chain
+    (cxx_marshalling -> * 255 -> resize_f32_cv -> fast_base_transform).  The two OpenCV resizes and the u8 -> float
+    step are exact by construction; torch's bilinear kernel may fuse multiply-adds, hence the small tolerance
+    (values are normalised pixels in about [-2.2, 2.7])."""
+    rng = np.random.default_rng(4)
+    frames = torch.from_numpy(rng.integers(0, 256, (5, 480, 640, 3), dtype=np.uint8)).cuda()
+    frames[0] = torch.from_numpy(_frame()).cuda()
+    eng = _engine(mask, "cuda:0")
+    got = eng._preprocess_hip(frames)
+    chw = mask.cxx_marshalling(frames)
+    imgs = mask.resize_f32_cv(chw.permute(0, 2, 3, 1) * 255, 640, 480)
+    want = mask.fast_base_transform(imgs)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (5, 3, 550, 550)
+    err = (got - want).abs().max().item()
+    assert err < 1e-4, err  # measured 3.5e-5 on random-noise frames (one ulp of a bilinear weight times 255 / 57)
+    # end to end: the engine's masks do not depend on which implementation prepared the input
+    m_hip = eng.eval_bgr_batch(frames)
+    eng.use_hip_pre = False
+    m_torch = eng.eval_bgr_batch(frames)
+    a, b = m_hip > 0, m_torch > 0
+    assert ((a & b).sum().item() / max((a | b).sum().item(), 1)) >= 1 - 1e-3
+
+
 def _yolact_class_roundtrip(mask, tmp_path, device):
     """The C++ ORB_SLAM2::yolact class (embedded CPython) end to end: ctor(py file, weights, categories),
     evalImage(BGR frame) -> 8-bit mask; weights travel through a .pth exactly like the reference's."""
