@@ -70,7 +70,7 @@ struct Cell {
     short ndw;     // 16-byte pieces per staged tile row = (tw + 7 + 15) / 16
     int slotOff;   // first candidate slot of the cell inside one frame
     unsigned magicDw, magicG;  // (1 << 20) / d + 1 for d = pieces per row, groups: division by multiplication
-    short groups;  // 4-pixel groups per row = (tw + 3) / 4
+    short groups;  // 8-pixel groups per row = (tw + 7) / 8
     short pad[3];
 };
 

@@ -214,7 +214,7 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
                 c.th = (short)th;
                 c.slotOff = slotOff;
                 c.ndw = (short)((tw + 7 + 15) >> 4);  // bytes 0 .. tw + 6 of the staged row, in 16-byte pieces
-                c.groups = (short)((tw + 3) >> 2);
+                c.groups = (short)((tw + 7) >> 3);  // 8-pixel groups per row (phase 1 of k_fast_cells)
                 c.magicDw = (1u << 20) / (unsigned)c.ndw + 1u;
                 c.magicG = (1u << 20) / (unsigned)c.groups + 1u;
                 maxTw = std::max(maxTw, tw);
@@ -269,7 +269,7 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
     g.kpLevelTotal = kpOff;
     g.kpCap = kpOff;
     g.blurItems = blurOff;
-    g.fastTileStrideDw = ((maxTw + 7 + 15) >> 4) * 4;  // whole 16-byte pieces
+    g.fastTileStrideDw = ((maxTw + 7 + 8 + 15) >> 4) * 4;  // whole 16-byte pieces; + 8: the last 8-pixel group reads one dword past tw + 6
     g.fastTileRows = maxTh + 6;
     g.fastMapRows = maxTh + 2;
     g.fastKeptCap = ((maxTw + 1) / 2) * ((maxTh + 1) / 2);

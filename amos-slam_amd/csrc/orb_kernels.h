@@ -448,43 +448,67 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
     for (int pass = 0; pass < 2; pass++) {
         const int t = pass == 0 ? iniTh : minTh;
         if (pass == 1 && minTh >= iniTh) break;  // a second cv::FAST at a higher threshold finds nothing new
-        // ---- phase 1 (necessary test, 4 pixels per lane) feeding phase 2 (exact arc value) in dense chunks
-        const short2v tt = short2v{(short)t, (short)t};
+        // ---- phase 1 (necessary test, 8 pixels per lane) feeding phase 2 (exact arc value) in dense chunks.
+        // Even and odd pixels of a dword are isolated with one v_and each (odd ones stay shifted left by 8:
+        // every operand of a comparison is scaled alike), then everything is unsigned packed 16-bit:
+        //   dark   <=>  max(min(n,s), min(e,w)) < c - t      bright  <=>  min(max(n,s), max(e,w)) > c + t
+        // with saturating c -+ t and "a > b" as sat(a - b) != 0.
+        const unsigned tE = (unsigned)t * 0x00010001u, tO = tE << 8;
         int ncand = 0, done = 0;   // list entries [0, done) have their arc value
         bool overflow = false;     // wave-uniform: the list wrapped, phase 3 must scan the arc map instead
+        // pixel k of a group <-> bit {0, 1, 16, 17, 2, 3, 18, 19}[k]; pixels beyond tw in the row's last group are masked
+        const int nLast = tw - 8 * (groups - 1);  // 1 .. 8, wave-uniform
+        const unsigned lastMask = ((1u << (min(nLast, 2) + min(max(nLast - 4, 0), 2))) - 1u) |
+                                  (((1u << (min(max(nLast - 2, 0), 2) + min(max(nLast - 6, 0), 2))) - 1u) << 16);
         for (int item0 = 0; item0 < nitems; item0 += 64) {
             const int item = item0 + lane;
             unsigned bits = 0;
             int p0 = 0;
             if (item < nitems) {
                 const int y = div_small(item, c.magicG), gx = item - y * groups;
-                const uint32_t *row = tile32 + (y + 3) * rowDw + gx;  // dword holding pixels x0 + 4gx - 4 ..
-                const unsigned L = row[0], C = row[1], R = row[2];
-                const unsigned N = row[1 - 3 * rowDw], S = row[1 + 3 * rowDw];
-                const unsigned W = __builtin_amdgcn_alignbyte(C, L, 1u);  // pixels x-3 .. x
-                const unsigned E = __builtin_amdgcn_alignbyte(R, C, 3u);  // pixels x+3 .. x+6
-                const unsigned m = fast_compass(unpack_lo(C), unpack_lo(N), unpack_lo(S), unpack_lo(E), unpack_lo(W), tt) >> 15;
-                const unsigned mh = fast_compass(unpack_hi(C), unpack_hi(N), unpack_hi(S), unpack_hi(E), unpack_hi(W), tt) >> 15;
-                bits = (m & 1u) | ((m >> 15) & 2u) | ((mh & 1u) << 2) | ((mh >> 13) & 8u);
-                const int valid = tw - 4 * gx;  // pixels of this group inside the cell
-                if (valid < 4) bits &= (1u << valid) - 1u;
-                p0 = (y << 6) | (4 * gx);
+                const uint32_t *row = tile32 + (y + 3) * rowDw + 2 * gx;  // dword holding pixels x0 + 8gx - 4 ..
+                const unsigned L = row[0], C0 = row[1], C1 = row[2], R = row[3];
+                const unsigned N0 = row[1 - 3 * rowDw], N1 = row[2 - 3 * rowDw], S0 = row[1 + 3 * rowDw], S1 = row[2 + 3 * rowDw];
+                const unsigned W0 = __builtin_amdgcn_alignbyte(C0, L, 1u), W1 = __builtin_amdgcn_alignbyte(C1, C0, 1u);  // x-3 ..
+                const unsigned E0 = __builtin_amdgcn_alignbyte(C1, C0, 3u), E1 = __builtin_amdgcn_alignbyte(R, C1, 3u);  // x+3 ..
+                auto flags = [](unsigned cc, unsigned nn, unsigned ss, unsigned ee, unsigned ww, unsigned m, unsigned tt) -> unsigned {
+                    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+                    const ushort2v c2 = __builtin_bit_cast(ushort2v, cc & m), n2 = __builtin_bit_cast(ushort2v, nn & m),
+                                   s2 = __builtin_bit_cast(ushort2v, ss & m), e2 = __builtin_bit_cast(ushort2v, ee & m),
+                                   w2 = __builtin_bit_cast(ushort2v, ww & m), t2 = __builtin_bit_cast(ushort2v, tt);
+                    const ushort2v lo = __builtin_elementwise_max(__builtin_elementwise_min(n2, s2), __builtin_elementwise_min(e2, w2));
+                    const ushort2v hi = __builtin_elementwise_min(__builtin_elementwise_max(n2, s2), __builtin_elementwise_max(e2, w2));
+                    const ushort2v f = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(c2, t2), lo) |
+                                       __builtin_elementwise_sub_sat(hi, __builtin_elementwise_add_sat(c2, t2));
+                    unsigned r;  // 1 in bit 0 / bit 16 where the lane is non-zero (the compiler turns min(f, 1) into compares)
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, f)), "v"(0x00010001u));
+                    return r;
+                };
+                const unsigned bE0 = flags(C0, N0, S0, E0, W0, 0x00ff00ffu, tE), bO0 = flags(C0, N0, S0, E0, W0, 0xff00ff00u, tO);
+                const unsigned bE1 = flags(C1, N1, S1, E1, W1, 0x00ff00ffu, tE), bO1 = flags(C1, N1, S1, E1, W1, 0xff00ff00u, tO);
+                bits = bE0 | (bO0 << 1) | (bE1 << 2) | (bO1 << 3);
+                if (gx == groups - 1) bits &= lastMask;
+                p0 = (y << 6) | (8 * gx);
             }
-            if (ncand + 256 > kFastCandCap) {  // wave-uniform: make room, remember that the list is no longer complete
+            if (ncand + 512 > kFastCandCap) {  // wave-uniform: make room (one iteration adds <= 64 x 8), remember that the list is no longer complete
                 fast_score_chunk(tile, tileStride, amap, cand, done, min(ncand - done, 64), lane, t);  // < 64 left over
                 ncand = done = 0;
                 overflow = true;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-            {   // append the survivors: one wave-wide prefix sum of the per-lane counts, then up to 4 stores
+            {   // append the survivors: one wave-wide prefix sum of the per-lane counts, then up to 8 stores
                 const int c = __popc(bits);
                 const int incl = wave_inclusive_scan(c);
                 int o = ncand + incl - c;
-                if (bits & 1u) cand[o++] = (uint16_t)p0;
-                if (bits & 2u) cand[o++] = (uint16_t)(p0 + 1);
-                if (bits & 4u) cand[o++] = (uint16_t)(p0 + 2);
-                if (bits & 8u) cand[o] = (uint16_t)(p0 + 3);
+                if (bits & 0x00001u) cand[o++] = (uint16_t)p0;
+                if (bits & 0x00002u) cand[o++] = (uint16_t)(p0 + 1);
+                if (bits & 0x10000u) cand[o++] = (uint16_t)(p0 + 2);
+                if (bits & 0x20000u) cand[o++] = (uint16_t)(p0 + 3);
+                if (bits & 0x00004u) cand[o++] = (uint16_t)(p0 + 4);
+                if (bits & 0x00008u) cand[o++] = (uint16_t)(p0 + 5);
+                if (bits & 0x40000u) cand[o++] = (uint16_t)(p0 + 6);
+                if (bits & 0x80000u) cand[o] = (uint16_t)(p0 + 7);
                 ncand += __builtin_amdgcn_readlane(incl, 63);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
