@@ -400,6 +400,57 @@ __device__ __forceinline__ void fast_score_chunk(const uint8_t *tile, int tileSt
     }
 }
 
+// The same for 65 .. 128 survivors, TWO PER LANE (A = cand[first + lane] in the low halves of the packed
+// registers, B = cand[first + 64 + lane] in the high halves), on the raw pixel values -- no differences, no
+// polarity:  A = max( v - min_arcs max_{k in arc} p_k ,  max_arcs min_{k in arc} p_k - v )  clamped at 0,
+// i.e. one unsigned packed max-chain and one min-chain over the 16 circle pixels of both candidates.
+__device__ __forceinline__ void fast_score_chunk2(const uint8_t *tile, int tileStride, uint8_t *amap, const uint16_t *cand,
+                                                  int first, int count, int lane, int t)
+{
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    const bool hasA = lane < count, hasB = lane + 64 < count;
+    const int pA = cand[first + (hasA ? lane : 0)], pB = hasB ? cand[first + 64 + lane] : pA;
+    const int s = tileStride;
+    const uint8_t *cA = tile + (pA >> 6) * s + (pA & 63), *cB = tile + (pB >> 6) * s + (pB & 63);
+    ushort2v x[16];
+#define AMOS_FAST_P(k, off) x[k] = __builtin_bit_cast(ushort2v, (unsigned)cA[off] | ((unsigned)cB[off] << 16));
+    AMOS_FAST_P(0, 3 * s) AMOS_FAST_P(1, 3 * s + 1) AMOS_FAST_P(2, 2 * s + 2) AMOS_FAST_P(3, s + 3)
+    AMOS_FAST_P(4, 3) AMOS_FAST_P(5, -s + 3) AMOS_FAST_P(6, -2 * s + 2) AMOS_FAST_P(7, -3 * s + 1)
+    AMOS_FAST_P(8, -3 * s) AMOS_FAST_P(9, -3 * s - 1) AMOS_FAST_P(10, -2 * s - 2) AMOS_FAST_P(11, -s - 3)
+    AMOS_FAST_P(12, -3) AMOS_FAST_P(13, s - 3) AMOS_FAST_P(14, 2 * s - 2) AMOS_FAST_P(15, 3 * s - 1)
+#undef AMOS_FAST_P
+    ushort2v lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo2[k] = __builtin_elementwise_min(x[k], x[(k + 1) & 15]);
+        hi2[k] = __builtin_elementwise_max(x[k], x[(k + 1) & 15]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo4[k] = __builtin_elementwise_min(lo2[k], lo2[(k + 2) & 15]);
+        hi4[k] = __builtin_elementwise_max(hi2[k], hi2[(k + 2) & 15]);
+    }
+    ushort2v maxMin = ushort2v{0, 0}, minMax = ushort2v{255, 255};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {  // 9 contiguous = two groups of four + the ninth
+        maxMin = __builtin_elementwise_max(maxMin, __builtin_elementwise_min(__builtin_elementwise_min(lo4[k], lo4[(k + 4) & 15]), x[(k + 8) & 15]));
+        minMax = __builtin_elementwise_min(minMax, __builtin_elementwise_max(__builtin_elementwise_max(hi4[k], hi4[(k + 4) & 15]), x[(k + 8) & 15]));
+    }
+    const ushort2v vv = __builtin_bit_cast(ushort2v, (unsigned)cA[0] | ((unsigned)cB[0] << 16));
+    const ushort2v a2 = __builtin_elementwise_max(__builtin_elementwise_sub_sat(vv, minMax), __builtin_elementwise_sub_sat(maxMin, vv));
+    const int aA = a2.x, aB = a2.y;
+    if (hasA) amap[((pA >> 6) + 1) * kFastMapStride + (pA & 63) + 1] = (uint8_t)(aA > t ? aA : 0);
+    if (hasB) amap[((pB >> 6) + 1) * kFastMapStride + (pB & 63) + 1] = (uint8_t)(aB > t ? aB : 0);
+}
+
+// count survivors starting at first: two per lane when that fills more than one wave's worth of lanes
+__device__ __forceinline__ void fast_score_tail(const uint8_t *tile, int tileStride, uint8_t *amap, const uint16_t *cand, int first,
+                                                int count, int lane, int t)
+{
+    if (count > 64) fast_score_chunk2(tile, tileStride, amap, cand, first, count, lane, t);  // wave-uniform
+    else fast_score_chunk(tile, tileStride, amap, cand, first, count, lane, t);
+}
+
 #ifndef AMOS_FAST_CELLS_PER_GROUP
 #define AMOS_FAST_CELLS_PER_GROUP 4
 #endif
@@ -491,7 +542,7 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
                 p0 = (y << 6) | (8 * gx);
             }
             if (ncand + 512 > kFastCandCap) {  // wave-uniform: make room (one iteration adds <= 64 x 8), remember that the list is no longer complete
-                fast_score_chunk(tile, tileStride, amap, cand, done, min(ncand - done, 64), lane, t);  // < 64 left over
+                fast_score_tail(tile, tileStride, amap, cand, done, ncand - done, lane, t);  // < 128 left over
                 ncand = done = 0;
                 overflow = true;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -513,12 +564,12 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            while (ncand - done >= 64) {  // wave-uniform: dense chunks of 64 survivors
-                fast_score_chunk(tile, tileStride, amap, cand, done, 64, lane, t);
-                done += 64;
+            while (ncand - done >= 128) {  // wave-uniform: dense chunks of 128 survivors, two per lane
+                fast_score_chunk2(tile, tileStride, amap, cand, done, 128, lane, t);
+                done += 128;
             }
         }
-        fast_score_chunk(tile, tileStride, amap, cand, done, ncand - done, lane, t);
+        fast_score_tail(tile, tileStride, amap, cand, done, ncand - done, lane, t);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- phase 3: strict 3x3 NMS.  For a corner at threshold t (a > t) every non-corner neighbour is
