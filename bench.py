@@ -235,6 +235,25 @@ def main():
     stage_ms["match"] = float(np.mean([a.elapsed_time(b) for a, b in match_events])) if match_events else 0.0
     if mask_events:
         stage_ms["mask_net"] = float(np.mean([a.elapsed_time(b) for a, b in mask_events]))
+    # The same per-launch times with lane 0 ALONE on the chip (after the timed region; the other lanes idle): what
+    # one launch of each kernel costs when it does not share the CUs with three other lanes' kernels.
+    alone_ms = None
+    if S > 1 and not use_mask:
+        barrier()
+        ext.timing_enable(4)
+        ev_alone = []
+        for _ in range(4):
+            ln = lanes[0]
+            ln.ext.extract_batch_device(ln.frames.data_ptr(), H * W, W, W, H, Bl)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ln.stream)
+            ln.matcher.bruteforce_best2_batch_device(ln.d_desc, ln.cap * 32, ln.d_counts, ln.pairs_q.data_ptr(), ln.pairs_t.data_ptr(),
+                                                     Bl, ln.cap, 256, ln.d_match.data_ptr())
+            e1.record(ln.stream)
+            ev_alone.append((e0, e1))
+        barrier()
+        alone_ms, _ = ext.timing_collect()
+        alone_ms["match"] = float(np.mean([a.elapsed_time(b) for a, b in ev_alone]))
     # result digest: keypoint counts + number of matches within TH_LOW (final gather over RCCL)
     n_kp = [len(ext.batch_fetch(f)[0]) for f in range(min(Bl, 8))]
     mean_kp = float(np.mean(n_kp))
@@ -341,6 +360,12 @@ def main():
             "stage_frac_of_hbm_peak": {k: (round(alg[k] * Bl / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if v > 0 else None)
                                        for k, v in stage_ms.items()},
             "digest_per_rank": digest_all,
+            "stage_ms_per_launch_lane_alone": ({k: round(v, 4) for k, v in alone_ms.items()} if alone_ms else None),
+            "roofline_lane_alone": ({"kernel": dominant, "note": "same launch, measured after the timed region with the other lanes idle",
+                                     "avg_launch_ms": round(alone_ms[dominant] / launches[dominant], 4),
+                                     "achieved": round(dom_bytes / (alone_ms[dominant] / launches[dominant] * 1e-3) / 1e9, 2),
+                                     "frac": round(dom_bytes / (alone_ms[dominant] / launches[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                                    if alone_ms and alone_ms.get(dominant, 0) > 0 else None),
             # Hamming throughput of the N x N match as N_q * N_t * 256 bit comparisons per second
             "hamming_bitops_per_s": round(fps * mean_kp * mean_kp * 256.0, 1),
         }
