@@ -351,13 +351,8 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
                        h->dPyr, h->dGeom, h->dCells, h->dSlotCount, h->dSlots, nFrames);
     if (ev) (void)hipEventRecord(ev[4], h->stream);
     const size_t lds = oct_lds_bytes(h->octNC, h->octSC);
-    // frames of a megapixel and more have thousands of FAST corners per level: register forms up to 16 384 candidates
-    if ((long long)g.W * g.H >= 1000000LL)
-        hipLaunchKernelGGL(k_octree<true>, dim3(nFrames * g.nLevels), dim3(256), lds, h->stream, h->dGeom, h->dCells, h->dSlotCount,
-                           h->dSlots, h->dPts, h->dNodeOf, h->dQuadOf, h->dCandCount, h->dLvKps, h->dLvCount, h->octNC, h->octSC);
-    else
-        hipLaunchKernelGGL(k_octree<false>, dim3(nFrames * g.nLevels), dim3(256), lds, h->stream, h->dGeom, h->dCells, h->dSlotCount,
-                           h->dSlots, h->dPts, h->dNodeOf, h->dQuadOf, h->dCandCount, h->dLvKps, h->dLvCount, h->octNC, h->octSC);
+    hipLaunchKernelGGL(k_octree, dim3(nFrames * g.nLevels), dim3(256), lds, h->stream, h->dGeom, h->dCells, h->dSlotCount,
+                       h->dSlots, h->dPts, h->dNodeOf, h->dQuadOf, h->dCandCount, h->dLvKps, h->dLvCount, h->octNC, h->octSC);
     if (ev) (void)hipEventRecord(ev[5], h->stream);
     hipLaunchKernelGGL(k_orient, dim3(xcd_grid((g.kpLevelTotal + 15) / 16, nFrames)), dim3(256), 0, h->stream, h->dPyr, h->dGeom,
                        h->dLvKps, h->dLvCount, nFrames);
@@ -517,8 +512,7 @@ int amos_orb_create(const amos_orb_params *params, int max_width, int max_height
     const size_t maxLds = oct_lds_bytes(align_up(maxNC, 4), align_up(std::max(maxSC, maxNC), 4));
     if (maxLds > 160 * 1024) { set_error("quad-tree needs %zu B of LDS (n_features too large)", maxLds); amos_orb_destroy(h); return AMOS_ERR_INVALID; }
     if (maxLds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); amos_orb_destroy(h); return AMOS_ERR_DEVICE; }
     }
     hipError_t e = hipStreamSynchronize(h->stream);

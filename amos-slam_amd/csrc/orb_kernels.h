@@ -754,27 +754,25 @@ enum { V_SIZE = 0, V_NEXPAND = 1, V_RSTAR = 2, V_NCAND = 3 };
 // grid = frames * nLevels, block = 256, dynamic LDS = oct_lds_bytes(NC, SC).
 //
 // Candidate state (packed point, node index, quadrant) lives in REGISTERS when the level has at most
-// 256 * kPts candidates (thread t owns candidates t, t + 256, ...): the subdivision passes then
+// 256 * kOctRegPts candidates (thread t owns candidates t, t + 256, ...): the subdivision passes then
 // touch only LDS.  Larger levels run the same code with the state in global scratch.
-// Three register-resident sizes (8, 32, 64 candidates per thread: up to 2 048 / 8 192 / 16 384 per level;
-// 1920x1080 levels hold 1 000 - 13 000) and the global-scratch form (kPts = 0).
-template <int kPts>
+constexpr int kOctRegPts = 8;
+
+template <bool kRegs>
 __device__ __forceinline__ void octree_body(const OctLds &L, const LevelGeom &lg, int level, int n, uint32_t *__restrict__ P,
                                             uint16_t *__restrict__ nodeIdx, uint8_t *__restrict__ quad,
                                             amos_keypoint *__restrict__ out, int *__restrict__ lvCountOut)
 {
     const int tid = threadIdx.x;
     const int N = lg.quota;
-    constexpr bool kRegs = kPts > 0;
-    constexpr int kOctRegPts = kRegs ? kPts : 1;
     uint32_t rp[kOctRegPts];
-    uint32_t rnq[kOctRegPts];  // node index | quadrant << 16
+    int rnode[kOctRegPts], rquad[kOctRegPts];
 #define OCT_POINTS(k, i) _Pragma("unroll") for (int k = 0, i = tid; k < (kRegs ? kOctRegPts : (n + 255) / 256); k++, i += 256) if (i < n)
 #define OCT_P(k, i) (kRegs ? rp[k] : P[i])
-#define OCT_NODE(k, i) (kRegs ? (int)(rnq[k] & 0xffffu) : (int)nodeIdx[i])
-#define OCT_SET_NODE(k, i, v) do { if (kRegs) rnq[k] = (rnq[k] & 0xffff0000u) | (uint32_t)(v); else nodeIdx[i] = (uint16_t)(v); } while (0)
-#define OCT_QUAD(k, i) (kRegs ? (int)(rnq[k] >> 16) : (int)quad[i])
-#define OCT_SET_QUAD(k, i, v) do { if (kRegs) rnq[k] = (rnq[k] & 0xffffu) | ((uint32_t)(v) << 16); else quad[i] = (uint8_t)(v); } while (0)
+#define OCT_NODE(k, i) (kRegs ? rnode[k] : (int)nodeIdx[i])
+#define OCT_SET_NODE(k, i, v) do { if (kRegs) rnode[k] = (v); else nodeIdx[i] = (uint16_t)(v); } while (0)
+#define OCT_QUAD(k, i) (kRegs ? rquad[k] : (int)quad[i])
+#define OCT_SET_QUAD(k, i, v) do { if (kRegs) rquad[k] = (v); else quad[i] = (uint8_t)(v); } while (0)
     if (kRegs) {
         OCT_POINTS(k, i) rp[k] = P[i];
     }
@@ -985,9 +983,6 @@ __device__ __forceinline__ void octree_body(const OctLds &L, const LevelGeom &lg
 #undef OCT_SET_QUAD
 }
 
-// kLarge adds the 32- and 64-candidates-per-thread register forms (256 VGPRs: two work-groups per CU) for frames
-// whose levels hold thousands of candidates; the small kernel keeps the occupancy the 640x480 path wants.
-template <bool kLarge>
 __global__ __launch_bounds__(256) void k_octree(const Geom *__restrict__ g, const Cell *__restrict__ cells,
                                                const int *__restrict__ slotCount,
                                                const uint32_t *__restrict__ slots, uint32_t *__restrict__ pts,
@@ -1022,14 +1017,10 @@ __global__ __launch_bounds__(256) void k_octree(const Geom *__restrict__ g, cons
     uint8_t *quad = quadOf + (size_t)frame * g->ptsTotal + lg.ptsOff;
     amos_keypoint *out = lvKps + (size_t)frame * g->kpLevelTotal + lg.kpOff;
     int *cntOut = lvCount + frame * g->nLevels + level;
-    if (n <= 256 * 8)
-        octree_body<8>(L, lg, level, n, P, nodeIdx, quad, out, cntOut);
-    else if (kLarge && n <= 256 * 32)
-        octree_body<kLarge ? 32 : 0>(L, lg, level, n, P, nodeIdx, quad, out, cntOut);
-    else if (kLarge && n <= 256 * 64)
-        octree_body<kLarge ? 64 : 0>(L, lg, level, n, P, nodeIdx, quad, out, cntOut);
+    if (n <= 256 * kOctRegPts)
+        octree_body<true>(L, lg, level, n, P, nodeIdx, quad, out, cntOut);
     else
-        octree_body<0>(L, lg, level, n, P, nodeIdx, quad, out, cntOut);
+        octree_body<false>(L, lg, level, n, P, nodeIdx, quad, out, cntOut);
 }
 
 // ---------------------------------------------------------------------------------------------
