@@ -36,6 +36,38 @@ def test_null_and_range_arguments(pkg):
     L.amos_match_destroy(None)
 
 
+def test_new_entry_points_reject_bad_arguments(pkg):
+    """The entry points added for the callers either side of the path validate before touching the device."""
+    L = pkg.lib()
+    f4 = (C.c_float * 4)()
+    assert L.amos_frame_image_bounds(C.c_int(0), C.c_int(480), C.c_float(500), C.c_float(500), C.c_float(320), C.c_float(240), None,
+                                     C.c_int(0), f4) == -1
+    assert L.amos_frame_image_bounds(C.c_int(640), C.c_int(480), C.c_float(0), C.c_float(500), C.c_float(320), C.c_float(240), None,
+                                     C.c_int(0), f4) == -1                                  # fx == 0
+    assert L.amos_frame_image_bounds(C.c_int(640), C.c_int(480), C.c_float(500), C.c_float(500), C.c_float(320), C.c_float(240), None,
+                                     C.c_int(5), f4) == -1                                  # n_dist > 0 without coefficients
+    assert L.amos_frame_undistort_batch_device(None, C.c_float(1), C.c_float(1), C.c_float(0), C.c_float(0), None, C.c_int(0), None) == -1
+    assert L.amos_frame_rgbd_glue_batch_device(None, None, C.c_int(0), C.c_float(1), C.c_size_t(0), C.c_size_t(0), C.c_float(0), C.c_float(0),
+                                               C.c_float(640), C.c_float(0), C.c_float(480), None, None, None, None) == -1
+    assert L.amos_frame_grid_build_batch_device(None, None, None, C.c_int(1), C.c_int(1), None, None) == -1
+    assert L.amos_match_window_best2_batch_device(None, None, None) == -1
+    p = C.c_void_p()
+    assert L.amos_mask_pre_create(C.c_int(0), None, C.c_int(1), C.c_int(480), C.c_int(1), C.byref(p)) == -1 and not p.value
+    assert L.amos_mask_pre_create(C.c_int(0), None, C.c_int(640), C.c_int(480), C.c_int(0), C.byref(p)) == -1
+    assert L.amos_mask_preprocess_batch_device(None, None, C.c_int(1), None) == -1
+    L.amos_mask_pre_destroy(None)
+    assert len(L.amos_last_error()) > 0
+
+
+def test_image_bounds_host_routine_matches_the_oracle(pkg, ob):
+    """amos_frame_image_bounds runs on the host (four points): bit-exact against the oracle without a GPU."""
+    dist = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+    cam = (517.306408, 516.469215, 318.643040, 255.313989)
+    assert pkg.image_bounds(640, 480, *cam, dist) == ob.image_bounds(640, 480, *cam, dist)
+    assert pkg.image_bounds(640, 480, *cam, dist[:4]) == ob.image_bounds(640, 480, *cam, dist[:4])
+    assert pkg.image_bounds(752, 480, *cam, np.zeros(4, np.float32)) == (0.0, 752.0, 0.0, 480.0)
+
+
 @pytest.mark.gpu
 def test_state_and_capacity_errors(gpu_lib, synth):
     ext = gpu_lib.OrbExtractor(max_width=640, max_height=480, max_batch=2)
