@@ -223,6 +223,65 @@ def test_set_level_keypoints_roundtrip(gpu_lib, ob, synth):
     _same(dg, do, "descriptors")
 
 
+def test_full_benchmark_size_properties(gpu_lib, ob, synth):
+    """BASELINE configs[1] at the bench's launch size (128 frames of 640x480 per lane), where the oracle would take
+    minutes: size-independent properties on every frame + the oracle on a sample.
+      determinism (two passes give identical bytes), keypoints ordered by level and inside their level's FAST region,
+      per-level counts within the quad-tree's bound, sizes = int(31 * scale[level]), a frame matched against itself
+      returns the identity with distance 0 (and second best > 0 unless the descriptor is duplicated),
+      matching k against k-1 equals matching through the single-pair API."""
+    import torch
+    n = 128
+    frames = synth.frames(2, 0, n)
+    ext = gpu_lib.OrbExtractor(max_batch=n)
+    mt = gpu_lib.OrbMatcher(stream=ext.stream)
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    d_kps, d_desc, d_counts, cap = ext.batch_results_device()
+    pairs_q = torch.arange(n, dtype=torch.int32, device="cuda")
+    pairs_prev = (pairs_q - 1) % n
+    d_self = torch.zeros((n, cap, 4), dtype=torch.int32, device="cuda")
+    d_prev = torch.zeros((n, cap, 4), dtype=torch.int32, device="cuda")
+    digests = []
+    for _ in range(2):
+        ext.extract_batch_device(d.data_ptr(), 480 * 640, 640, 640, 480, n)
+        mt.bruteforce_best2_batch_device(d_desc, cap * 32, d_counts, pairs_q.data_ptr(), pairs_q.data_ptr(), n, cap, 256, d_self.data_ptr())
+        mt.bruteforce_best2_batch_device(d_desc, cap * 32, d_counts, pairs_q.data_ptr(), pairs_prev.data_ptr(), n, cap, 256, d_prev.data_ptr())
+        ext.sync()
+        torch.cuda.synchronize()
+        res = [ext.batch_fetch(f) for f in range(n)]
+        digests.append((b"".join(k.tobytes() + dd.tobytes() for k, dd in res), d_prev.cpu().numpy().tobytes()))
+    assert digests[0] == digests[1], "two passes over the same batch differ"
+    tab = ext.tables()
+    lw, lh = ext.level_sizes(640, 480)
+    self_m, prev_m = d_self.cpu().numpy(), d_prev.cpu().numpy()
+    for f, (k, dd) in enumerate(res):
+        m = len(k)
+        assert 900 <= m <= cap
+        assert np.all(np.diff(k["octave"]) >= 0), "levels out of order"
+        counts = np.bincount(k["octave"], minlength=8)
+        assert np.all(counts <= tab["features_per_level"] + 3 * 4), counts       # each of the last divisions adds <= 3 nodes
+        sc = tab["scale"][k["octave"]]
+        assert np.array_equal(k["size"], np.floor(np.float32(31) * sc).astype(np.float32))   # int scaledPatchSize, ORBextractor.cc:1180
+        xl, yl = k["x"] / np.where(k["octave"] == 0, 1, sc), k["y"] / np.where(k["octave"] == 0, 1, sc)
+        assert np.all(xl >= 16 - 1e-3) and np.all(yl >= 16 - 1e-3)
+        assert np.all(xl <= lw[k["octave"]] - 16 + 1e-3) and np.all(yl <= lh[k["octave"]] - 16 + 1e-3)
+        sm = self_m[f, :m]
+        assert np.array_equal(sm[:, 1], np.zeros(m, np.int32)), "self distance"
+        same = sm[:, 0] == np.arange(m)
+        # best index differs from i only where an EARLIER keypoint has the same descriptor (first wins)
+        for i in np.nonzero(~same)[0]:
+            assert sm[i, 0] < i and np.array_equal(dd[sm[i, 0]], dd[i])
+    for f in (0, 77, 127):                                                         # oracle on a sample
+        ko, do = ob.Oracle().extract(frames[f])
+        _same(res[f][0], ko, f"frame {f} keypoints")
+        _same(res[f][1], do, f"frame {f} descriptors")
+        want = ob.bruteforce_best2(res[f][1], res[(f - 1) % n][1])
+        got = prev_m[f, :len(ko)]
+        for c, name in enumerate(("best_idx", "best_dist", "second_idx", "second_dist")):
+            assert np.array_equal(got[:, c], want[name]), (f, name)
+
+
 def test_batch_equals_single(gpu_lib, ob, synth):
     """The batched device-resident path gives, per frame, what the single-frame path gives."""
     import torch
