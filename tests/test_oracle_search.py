@@ -508,3 +508,121 @@ def test_search_by_sim3_vs_python(frames):
     m2[q21["src"][b21 >= 0]] = b21[b21 >= 0]
     want = np.array([m1[i] if m1[i] >= 0 and m2[m1[i]] == i else -1 for i in range(len(k0))], np.int32)
     assert np.array_equal(m_o, want) and n_o == (want >= 0).sum() and n_o > 20
+
+
+def py_search_points(kps, desc, ur, q, match, obs, sf, th, ratio):
+    """Independent restatement of ORBmatcher::SearchByProjection(F, vpMapPoints, th), ORBmatcher.cc:70-175."""
+    grid = PyGrid(kps)
+    match, obs = match.copy(), obs.copy()
+    n = 0
+    for i, p in enumerate(q):
+        lvl = int(p["level"])
+        r = F32(2.5) if F32(p["view_cos"]) > 0.998 else F32(4.0)
+        if th != 1.0:
+            r = F32(r * F32(th))
+        radius = F32(r * F32(sf[lvl]))
+        cand = grid.area(p["proj_x"], p["proj_y"], radius, lvl - 1, lvl)
+        b1 = b2 = 256
+        l1 = l2 = bi = -1
+        for idx in cand:
+            if match[idx] >= 0 and obs[idx]:
+                continue
+            if ur is not None and ur[idx] > 0:
+                if abs(F32(F32(p["proj_xr"]) - F32(ur[idx]))) > radius:
+                    continue
+            d = _dist(p["desc"], desc[idx])
+            if d < b1:
+                b2, b1, l2, l1, bi = b1, d, l1, int(kps[idx]["octave"]), idx
+            elif d < b2:
+                l2, b2 = int(kps[idx]["octave"]), d
+        if cand and b1 <= 100:
+            if l1 == l2 and F32(b1) > F32(F32(ratio) * F32(b2)):
+                continue
+            match[bi] = i
+            obs[bi] = 1 if p["has_obs"] else 0
+            n += 1
+    return n, match, obs
+
+
+def test_search_by_projection_points_vs_python(frames):
+    """Same-level ratio rule (:163-167), occupied-with-observations skip (:116-118), right-coordinate gate (:121-127)."""
+    k0, d0, k1, d1, sf = frames
+    rng = np.random.default_rng(21)
+    ur = np.where(rng.random(len(k1)) < 0.5, k1["x"] - 20, -1).astype(np.float32)
+    view, keep = hb.frame_view(k1, d1, ur)
+    q = np.zeros(len(k0), hb.MAP_QUERY)
+    q["proj_x"], q["proj_y"] = k0["x"] - 2, k0["y"] - 1
+    q["proj_xr"] = q["proj_x"] - 20 + rng.normal(0, 3, len(k0)).astype(np.float32)
+    q["view_cos"] = rng.choice([0.9, 0.999], len(k0)).astype(np.float32)
+    q["level"] = np.maximum(k0["octave"], 0)
+    q["has_obs"] = rng.random(len(k0)) < 0.5
+    q["desc"] = d0
+    # pre-existing matches: some with observations (never replaced), some without (may be replaced)
+    match0 = np.where(rng.random(len(k1)) < 0.2, 0, -1).astype(np.int32)
+    obs0 = ((match0 >= 0) & (rng.random(len(k1)) < 0.5)).astype(np.uint8)
+    for th, ratio in ((1.0, 0.8), (3.0, 0.8), (5.0, 0.95)):
+        n_o, m_o, o_o = hb.search_points("oracle", view, q, match0, obs0, sf, th, ratio)
+        n_p, m_p, o_p = py_search_points(k1, d1, ur, q, match0, obs0, sf, th, ratio)
+        assert n_o == n_p and np.array_equal(m_o, m_p) and np.array_equal(o_o, o_p)
+    assert n_o > 20
+
+
+def py_search_init(k1, d1, k2, d2, prev, window, ratio):
+    """Independent restatement of ORBmatcher::SearchForInitialization, ORBmatcher.cc:515-643."""
+    grid = PyGrid(k2)
+    m12 = np.full(len(k1), -1, np.int32)
+    m21 = np.full(len(k2), -1, np.int32)
+    mdist = np.full(len(k2), 2 ** 31 - 1, np.int64)
+    prev = prev.copy()
+    n = 0
+    hist = [[] for _ in range(30)]
+    factor = F32(30) / F32(360.0)
+    for i1 in range(len(k1)):
+        if k1[i1]["octave"] > 0:
+            continue
+        cand = grid.area(prev[i1, 0], prev[i1, 1], F32(window), 0, 0)
+        b1 = b2 = 2 ** 31 - 1
+        bi = -1
+        for i2 in cand:
+            d = _dist(d1[i1], d2[i2])
+            if mdist[i2] <= d:
+                continue
+            if d < b1:
+                b2, b1, bi = b1, d, i2
+            elif d < b2:
+                b2 = d
+        if cand and b1 <= 50 and F32(b1) < F32(F32(b2) * F32(ratio)):
+            if m21[bi] >= 0:
+                m12[m21[bi]] = -1
+                n -= 1
+            m12[i1], m21[bi], mdist[bi] = bi, i1, b1
+            n += 1
+            rot = F32(k1[i1]["angle"]) - F32(k2[bi]["angle"])
+            if rot < 0:
+                rot = F32(rot + F32(360.0))
+            b = _round_half_away(F32(rot * factor))
+            hist[0 if b == 30 else b].append(i1)
+    a1, a2, a3 = _three_maxima([len(h) for h in hist])
+    for b in range(30):
+        if b not in (a1, a2, a3):
+            for i1 in hist[b]:
+                if m12[i1] >= 0:
+                    m12[i1] = -1
+                    n -= 1
+    for i1 in range(len(k1)):
+        if m12[i1] >= 0:
+            prev[i1] = (k2[m12[i1]]["x"], k2[m12[i1]]["y"])
+    return n, m12, prev
+
+
+def test_search_for_initialization_vs_python(frames):
+    """Level-0 only, the vMatchedDistance back-check (:554-555), displaced earlier matches (:577-581)."""
+    k0, d0, k1, d1, _ = frames
+    v0, keep0 = hb.frame_view(k0, d0)
+    v1, keep1 = hb.frame_view(k1, d1)
+    prev = np.stack([k0["x"], k0["y"]], 1).astype(np.float32)
+    for window, ratio in ((100, 0.9), (30, 0.7)):
+        n_o, m_o, p_o = hb.search_init("oracle", v0, v1, prev, window, ratio)
+        n_p, m_p, p_p = py_search_init(k0, d0, k1, d1, prev, window, ratio)
+        assert n_o == n_p and np.array_equal(m_o, m_p) and np.array_equal(p_o.reshape(-1, 2), p_p)
+    assert n_o > 10
