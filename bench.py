@@ -124,6 +124,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 path on a box with fewer GPUs than ranks (AMOS_DIST_BACKEND=gloo): ranks share the
+    # visible devices and the three collectives run on CPU tensors.  The driver's runs use RCCL, one GPU per rank.
+    backend = os.environ.get("AMOS_DIST_BACKEND", "nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
@@ -134,8 +137,11 @@ def main():
     synth = importlib.import_module("amos_slam_amd.synth")
     shard = importlib.import_module("amos_slam_amd.shard")
 
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    shard.init("nccl", torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+    shard.init(backend, torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+    coll_dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
 
     cfg = CONFIGS[args.config]
     if args.batch <= 0:
@@ -229,7 +235,7 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, f"cuda:{local_rank}")
+    elapsed = shard.max_over_ranks(elapsed, coll_dev)
 
     stage_ms, n_rec = ext.timing_collect()
     stage_ms["match"] = float(np.mean([a.elapsed_time(b) for a, b in match_events])) if match_events else 0.0
@@ -259,7 +265,7 @@ def main():
     mean_kp = float(np.mean(n_kp))
     good = int(sum(int((ln.d_match[:, :, 1] <= 50).sum().item()) for ln in lanes))
     # the one collective of the path: final gather of the per-rank digests
-    digest_all = shard.gather_digests([float(sum(n_kp)), float(good)], f"cuda:{local_rank}")
+    digest_all = shard.gather_digests([float(sum(n_kp)), float(good)], coll_dev)
 
     # SURVEY 8d match workload (ii): window-gated search (SearchByProjection radius 15 * scale, levels
     # octave-1..octave+1) of frame k's keypoints in frame k-1, everything resident: grid cells, CSR grid,
