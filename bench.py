@@ -109,8 +109,8 @@ def cpu_baseline_all_cores(cfg, workers, n_per_worker):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 512; 32 with the mask; 128 for c5)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--streams", type=int, default=0, help="independent lanes (handle + HIP streams) the batch is split over (default 4; 2 with the mask)")
