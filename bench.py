@@ -17,6 +17,10 @@ import time
 
 import numpy as np
 
+# HIP multiplexes streams onto this many hardware queues in creation order; the lanes below create their
+# streams as main0, side0, main1, side1, ... so that with 4 queues the main streams of lanes (0, 2) and (1, 3)
+# and the side streams of (0, 2) and (1, 3) share a queue each -- measured best.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
