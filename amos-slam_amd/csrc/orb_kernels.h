@@ -305,14 +305,16 @@ __global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr
 // non-max suppression at threshold t iff A > t and every in-cell neighbour has A_n <= t or A_n < A
 // (scores outside the cell's tested region are 0 in OpenCV's row buffers).
 //
-// Per cell (one work-group; tile + 3-px halo staged in LDS so that the cell's first tested pixel
-// sits at byte 4 of its row, i.e. 4-pixel groups are dword aligned):
-//   1. a cheap necessary test on every pixel, four pixels per lane with dword LDS reads and packed
-//      16-bit min/max: any 9-arc of the 16-pixel circle contains two compass points 90 degrees
-//      apart, so a corner at threshold t needs  min(max(dS,dN), max(dE,dW)) > t  (both darker) or
-//      the mirrored expression (both brighter); survivors go onto an LDS list;
-//   2. the survivors (dense lanes again) get the exact arc value with v_pk_min_i16 on (d, -d)
-//      pairs: one chain serves the dark and the bright polarity;
+// Per cell (ONE WAVE; tile + 3-px halo staged in LDS so that the cell's first tested pixel sits at byte 4
+// of its row, i.e. 8-pixel groups are 8-byte aligned):
+//   1. a cheap necessary test on every pixel, eight pixels per lane: any 9-arc of the 16-pixel circle
+//      contains two compass points 90 degrees apart, so a corner at threshold t needs
+//      max(min(n,s), min(e,w)) < c - t  (dark) or  min(max(n,s), max(e,w)) > c + t  (bright).  Even and odd
+//      pixels of a dword are isolated by one v_and each (odd ones stay shifted left by 8) and everything is
+//      unsigned packed 16-bit with saturating c -+ t -- no unpacking; survivors go onto an LDS list;
+//   2. the survivors (dense lanes again) get the exact arc value: up to 64 at a time with v_pk_min_i16 on
+//      (d, -d) pairs (one chain serves both polarities), 65..128 two per lane with one packed max-chain and
+//      one min-chain on the raw circle pixels;
 //   3. 3x3 strict non-max suppression over the survivors only; the kept ones are ranked by pixel
 //      index (row-major = FAST's output order) and written to the cell's slots.
 // The cell is processed at iniThFAST first and, only if that leaves it EMPTY, again at minThFAST
