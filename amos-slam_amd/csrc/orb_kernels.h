@@ -58,7 +58,8 @@ __device__ __forceinline__ uint8_t *level_origin(uint8_t *pyr, const Geom *g, in
 // cv::resize's 11-bit fixed-point bilinear, border pixels by the same formula at the
 // reflect-101 source coordinate (the host-built tap tables are indexed by padded
 // coordinate with the reflection folded in).
-// grid = (ceil(groups/64), ceil((h+38)/4), frames), block = (64, 4).
+// Level 0 is imported by k_pyramid_level0_wide (16 bytes per lane); levels >= 1 by k_pyramid_level with
+// grid = (ceil(groups/64), ceil((h+38)/(4*kPyrRows)), frames), block = (64, 4).
 constexpr int kPyrRows = 8;  // padded rows per thread (x taps are loaded once; consecutive rows share source rows)
 
 // Level 0, 16 bytes per lane.  Interior pieces (16 consecutive bytes of the padded plane whose source is
@@ -1067,9 +1068,10 @@ __device__ __forceinline__ int level_of_slot(const Geom *g, int slot)
 }
 
 // grid = xcd_grid(ceil(kpLevelTotal/16), frames), block = 256 = 16 keypoints: SIXTEEN LANES PER
-// KEYPOINT.  In each of 16 steps a group reads two patch rows as 2 x 8 unaligned dwords (32 pixels,
-// columns -15 .. +16); a per-(step, lane) table in LDS holds, per byte, the weight u + 16 inside the
-// circular patch (0 outside) and a 0/1 mask, so one row costs two v_dot4_u32_u8:
+// KEYPOINT.  The 31 x 31 patch is 62 half rows of 16 bytes (columns -15 .. 0 and +1 .. +16); lane j takes
+// half (j & 1) of rows (j >> 1) + 8 q, q = 0..3, as four unaligned 16-byte loads issued together; a
+// per-(row, half) table in LDS holds, per byte, the weight u + 16 inside the circular patch (0 outside)
+// and a 0/1 mask, so a dword costs two v_dot4_u32_u8:
 //   m10 = sum (u + 16) p - 16 sum p,   m01 = sum v p.
 __device__ __forceinline__ int group16_sum(int v)
 {
