@@ -72,6 +72,46 @@ def test_other_scale_factors(gpu_lib, ob, synth, sf, nl):
         _same(ext.level_image(l, padded=True), orc.level_image(l, padded=True), f"level {l} incl. border")
 
 
+def test_random_geometries(gpu_lib, ob):
+    """Fuzz over frame sizes, level counts, scale factors, feature counts and thresholds: every combination
+    exercises different edge handling (partial 16-byte import pieces, partial 8-pixel FAST groups, level widths that
+    are not multiples of 4, cells clipped at the right / bottom border, quotas larger than the candidate count)."""
+    rng = np.random.default_rng(2024)
+    done = 0
+    for trial in range(60):
+        w, h = int(rng.integers(130, 820)), int(rng.integers(110, 620))
+        nl = int(rng.integers(1, 9))
+        sf = float(np.float32(rng.choice([1.1, 1.2, 1.25, 1.33, 1.5])))
+        nf = int(rng.integers(50, 2500))
+        ini, mn = int(rng.integers(8, 40)), int(rng.integers(2, 8))
+        kind = trial % 3
+        if kind == 0:
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 1:  # smooth blobs + sharp rectangles
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = (127 + 90 * np.sin(xx / 17.0) * np.cos(yy / 23.0)).astype(np.uint8)
+            for _ in range(40):
+                x0, y0 = int(rng.integers(0, w - 20)), int(rng.integers(0, h - 20))
+                img[y0:y0 + int(rng.integers(4, 40)), x0:x0 + int(rng.integers(4, 40))] = int(rng.integers(0, 256))
+        else:            # mostly flat with a few dots (min threshold path)
+            img = np.full((h, w), 120, np.uint8)
+            for _ in range(300):
+                img[int(rng.integers(0, h)), int(rng.integers(0, w))] = int(rng.integers(0, 256))
+        try:
+            ext = gpu_lib.OrbExtractor(n_features=nf, scale_factor=sf, n_levels=nl, ini_th=ini, min_th=mn, max_width=w, max_height=h)
+        except gpu_lib.AmosError:
+            with pytest.raises(RuntimeError):   # the oracle rejects the same geometry (a level without a FAST cell)
+                ob.Oracle(n_features=nf, scale_factor=sf, n_levels=nl, ini_th=ini, min_th=mn).detect(img)
+            continue
+        orc = ob.Oracle(n_features=nf, scale_factor=sf, n_levels=nl, ini_th=ini, min_th=mn)
+        kg, dg = ext.extract(img)
+        ko, do = orc.extract(img, cap=max(4 * nf + 64, 4096))
+        _same(kg, ko, f"trial {trial} ({w}x{h} L{nl} sf{sf} N{nf} th{ini}/{mn}) keypoints")
+        _same(dg, do, f"trial {trial} descriptors")
+        done += 1
+    assert done >= 40
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_extract_many_frames(gpu_lib, ob, synth, seed):
     ext, orc = _pair(gpu_lib, ob, 640, 480, 1000, 8)
