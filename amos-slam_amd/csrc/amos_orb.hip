@@ -51,6 +51,7 @@ struct amos_orb {
     hipStream_t streamB = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr, evBlur0 = nullptr, evBlur1 = nullptr;
     bool blurDone = false;  // the blurred planes of the current frame(s) exist
+    size_t octLdsAttr = 0;  // dynamic LDS limit last set on k_octree
     // a1 tables
     float scale[AMOS_MAX_LEVELS]{}, invScale[AMOS_MAX_LEVELS]{}, sigma2[AMOS_MAX_LEVELS]{}, invSigma2[AMOS_MAX_LEVELS]{};
     int quota[AMOS_MAX_LEVELS]{};
@@ -299,6 +300,14 @@ static int set_geometry(amos_orb *h, int W, int Hh)
     g.kpCap = c.kpCap;
     h->octNC = align_up(nc, 4);
     h->octSC = align_up(std::max(sc, h->octNC), 4);
+    {
+        const size_t lds = oct_lds_bytes(h->octNC, h->octSC);
+        if (lds > 160 * 1024) { set_error("quad-tree needs %zu B of LDS for a %dx%d frame", lds, W, Hh); return AMOS_ERR_INVALID; }
+        if (lds > 48 * 1024 && lds > h->octLdsAttr) {
+            AMOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            h->octLdsAttr = lds;
+        }
+    }
     h->geom = g;
     h->cells.swap(cells);
     h->taps.swap(taps);
@@ -436,9 +445,27 @@ int amos_orb_create(const amos_orb_params *params, int max_width, int max_height
     std::vector<ResizeTap> taps;
     int rc = build_geometry(h, max_width, max_height, h->capGeom, &cells, &taps);
     if (rc != AMOS_OK) { delete h; return rc; }
+    // The allocation must hold EVERY frame up to max_width x max_height, and the cell layout of a smaller frame is
+    // not always smaller (fewer, larger cells; another aspect ratio and so more quad-tree roots): inflate the
+    // layout-dependent capacities of the largest frame to bounds that hold for all of them.
+    {
+        Geom &cg = h->capGeom;
+        long long slots = 0, ncell = 0, kpl = 0;
+        const int nIniMax = std::max(1, (int)std::lround((double)max_width / 48.0));  // width / height of any frame with a FAST cell
+        for (int l = 0; l < cg.nLevels; l++) {
+            const long long w = cg.lv[l].w, hh = cg.lv[l].h;
+            slots += (w * hh * 27 + 99) / 100 + 64;           // sum of ceil(tw/2) * ceil(th/2) over cells of >= 30 px: <= (31/30)^2 / 4 of the area
+            ncell += (w / 30 + 2) * (hh / 30 + 2);
+            kpl += std::max(cg.lv[l].quota, 4 * nIniMax) + 4;
+        }
+        cg.slotTotal = (int)std::max<long long>(cg.slotTotal, slots);
+        cg.ptsTotal = (int)std::max<long long>(cg.ptsTotal, slots);
+        cg.kpLevelTotal = (int)std::max<long long>(cg.kpLevelTotal, kpl);
+        cg.kpCap = cg.kpLevelTotal;
+        h->capCells = (size_t)std::max<long long>((long long)cells.size(), ncell) + 64;
+    }
     const Geom &c = h->capGeom;
-    h->capCells = cells.size() + 64;
-    h->capTaps = taps.size() + 64;
+    h->capTaps = taps.size() + 64 + 8 * (size_t)c.nLevels;
     if (stream) h->stream = (hipStream_t)stream;
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -514,6 +541,7 @@ int amos_orb_create(const amos_orb_params *params, int max_width, int max_height
     if (maxLds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); amos_orb_destroy(h); return AMOS_ERR_DEVICE; }
+        h->octLdsAttr = maxLds;
     }
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { set_error("create sync: %s", hipGetErrorString(e)); amos_orb_destroy(h); return AMOS_ERR_DEVICE; }

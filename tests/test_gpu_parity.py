@@ -98,7 +98,12 @@ def test_random_geometries(gpu_lib, ob):
             for _ in range(300):
                 img[int(rng.integers(0, h)), int(rng.integers(0, w))] = int(rng.integers(0, 256))
         try:
-            ext = gpu_lib.OrbExtractor(n_features=nf, scale_factor=sf, n_levels=nl, ini_th=ini, min_th=mn, max_width=w, max_height=h)
+            # every other handle is allocated for a larger frame than it is given
+            mw, mh = (w, h) if trial % 2 else (w + int(rng.integers(0, 200)), h + int(rng.integers(0, 150)))
+            ext = gpu_lib.OrbExtractor(n_features=nf, scale_factor=sf, n_levels=nl, ini_th=ini, min_th=mn, max_width=mw, max_height=mh)
+            if trial % 2 == 0:
+                ext.level_sizes(w, h)
+                ext.detect(img)   # geometry of the smaller frame
         except gpu_lib.AmosError:
             with pytest.raises(RuntimeError):   # the oracle rejects the same geometry (a level without a FAST cell)
                 ob.Oracle(n_features=nf, scale_factor=sf, n_levels=nl, ini_th=ini, min_th=mn).detect(img)
