@@ -369,6 +369,65 @@ def test_batch_with_unaligned_strides(gpu_lib, ob, synth):
         _same(dg, do, f"frame {f} descriptors")
 
 
+def test_random_batches_masks_and_colour(gpu_lib, ob):
+    """Fuzz of the device-resident batch entry points: random sizes, batch fill, strides and base offsets, gray or
+    colour input, optionally the staged detect -> gate (random masks) -> describe flow."""
+    import torch
+    rng = np.random.default_rng(77)
+    for trial in range(14):
+        w = int(rng.integers(240, 700))
+        h = int(rng.integers(160, min(500, w)))          # landscape: the reference needs round(width / height) >= 1 quad-tree roots
+        nmax = int(rng.integers(1, 5))
+        n = int(rng.integers(1, nmax + 1))
+        nf, nl = int(rng.integers(200, 1500)), int(rng.integers(2, 6))
+        ch = int(rng.choice([1, 1, 3, 4]))
+        rgb = bool(rng.integers(0, 2))
+        pad, off = int(rng.integers(0, 9)) * ch, int(rng.integers(0, 16))
+        row_stride = w * ch + pad
+        frame_stride = row_stride * h + int(rng.integers(0, 64))
+        host = rng.integers(0, 256, off + n * frame_stride + 64, dtype=np.uint8)
+        # blocky content gives corners at several levels
+        for f in range(n):
+            img = np.kron(rng.integers(0, 256, ((h + 15) // 16, (w + 15) // 16, ch), dtype=np.uint8), np.ones((16, 16, 1), np.uint8))[:h, :w]
+            img = np.clip(img.astype(np.int16) + rng.integers(-12, 12, img.shape), 0, 255).astype(np.uint8)
+            view = host[off + f * frame_stride: off + f * frame_stride + row_stride * h].reshape(h, row_stride)
+            view[:, :w * ch] = img.reshape(h, w * ch)
+        d = torch.from_numpy(host).cuda()
+        torch.cuda.synchronize()
+        ext = gpu_lib.OrbExtractor(n_features=nf, n_levels=nl, max_width=w + int(rng.integers(0, 50)), max_height=h + int(rng.integers(0, 20)),
+                                   max_batch=nmax)
+        frames = []
+        for f in range(n):
+            v = host[off + f * frame_stride: off + f * frame_stride + row_stride * h].reshape(h, row_stride)[:, :w * ch].reshape(h, w, ch)
+            frames.append(v[..., 0].copy() if ch == 1 else ob.color_to_gray(v.copy(), rgb))
+        staged = ch == 1 and trial % 2 == 0
+        if ch > 1:
+            ext.extract_batch_device_color(d.data_ptr() + off, frame_stride, row_stride, w, h, n, ch, rgb)
+        elif staged:
+            masks = (rng.random((n, h, w)) < 0.002).astype(np.uint8) * 255
+            d_masks = torch.from_numpy(masks).cuda()
+            torch.cuda.synchronize()
+            ext.detect_batch_device(d.data_ptr() + off, frame_stride, row_stride, w, h, n)
+            ext.gate_batch_device(d_masks.data_ptr(), h * w, w)
+            ext.describe_batch_device()
+        else:
+            ext.extract_batch_device(d.data_ptr() + off, frame_stride, row_stride, w, h, n)
+        ext.sync()
+        torch.cuda.synchronize()
+        for f in range(n):
+            orc = ob.Oracle(n_features=nf, n_levels=nl)
+            if staged:
+                orc.detect(frames[f])
+                orc.gate(masks[f])
+                ko, do = orc.describe()
+            else:
+                ko, do = orc.extract(frames[f])
+            kg, dg = ext.batch_fetch(f)
+            what = f"trial {trial} frame {f} ({w}x{h}x{ch} n={n}/{nmax} strides {row_stride},{frame_stride}+{off} staged={staged})"
+            _same(kg, ko, what + " keypoints")
+            _same(dg, do, what + " descriptors")
+
+
 def test_staged_batch_with_masks(gpu_lib, ob, synth):
     """Full front-end, device resident: detect -> gate (closed mask) -> describe for a batch,
     frame by frame equal to the oracle's a7 -> a8 -> a9."""
@@ -553,6 +612,26 @@ def test_bruteforce_vs_oracle(gpu_lib, ob):
     r = m.bruteforce_best2(q[:3], t[:0])
     assert (r["best_idx"] == -1).all() and (r["best_dist"] == 256).all()
     _same(m.bruteforce_best2(q[:1], t[:1]), ob.bruteforce_best2(q[:1], t[:1]), "1x1")
+
+
+def test_matcher_size_fuzz(gpu_lib, ob):
+    """Brute-force and list reductions over awkward set sizes (wave / tile boundaries, 1, 2, 3 descriptors, train sets
+    shorter than the four per-wave quarters) and gates; descriptors drawn from a small pool so that ties are common."""
+    rng = np.random.default_rng(99)
+    pool = _descs(rng, 37)
+    m = gpu_lib.OrbMatcher()
+    for nq, nt in ((1, 1), (1, 2), (2, 3), (3, 1), (5, 7), (63, 65), (64, 64), (65, 63), (127, 4), (4, 129), (257, 255), (1, 1500), (1300, 2), (513, 1025)):
+        q = pool[rng.integers(0, len(pool), nq)].copy()
+        t = pool[rng.integers(0, len(pool), nt)].copy()
+        flip = rng.random((nt, 32)) < 0.05                      # perturb some train descriptors
+        t ^= (flip * rng.integers(0, 256, (nt, 32))).astype(np.uint8)
+        for init in (256, 40, 1, 2 ** 31 - 1):
+            _same(m.bruteforce_best2(q, t, init), ob.bruteforce_best2(q, t, init), f"bf {nq}x{nt} init={init}")
+        _same(m.distances(q, t), ob.distances(q, t), f"dense {nq}x{nt}")
+        off, idx = _random_lists(rng, nq, nt, min(nt, 40))
+        _same(m.list_distances(q, t, off, idx), ob.list_distances(q, t, off, idx), f"list dist {nq}x{nt}")
+        for init in (256, 30):
+            _same(m.list_best2(q, t, off, idx, init), ob.list_best2(q, t, off, idx, init), f"list best2 {nq}x{nt} init={init}")
 
 
 def test_match_consecutive_frames(gpu_lib, ob, synth):
