@@ -347,3 +347,56 @@ def test_resident_grid_and_window_search(gpu_lib, ob, synth, mode, stereo, shift
             assert np.array_equal(got[:, k], want[name]), (p, name)
         nfound += int((want["best_idx"] >= 0).sum())
     assert nfound > 500
+
+
+def test_resident_search_with_distorted_camera(gpu_lib, ob, synth):
+    """Undistort -> glue (cells from mvKeysUn, bounds from ComputeImageBounds) -> CSR grid -> window search
+    around the undistorted positions; the oracle gets a frame view of the undistorted keypoints and the same bounds."""
+    import torch
+    import host_binding as hb
+    n, th = 3, 12.0
+    fx, fy, cx, cy = 517.306408, 516.469215, 318.643040, 255.313989
+    dist = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+    bounds = gpu_lib.image_bounds(640, 480, fx, fy, cx, cy, dist)
+    assert bounds != (0.0, 640.0, 0.0, 480.0)
+    frames = synth.frames(6, 0, n)
+    ext = gpu_lib.OrbExtractor(max_batch=n)
+    d_frames = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    ext.extract_batch_device(d_frames.data_ptr(), 480 * 640, 640, 640, 480, n)
+    d_kps, d_desc, d_counts, cap = ext.batch_results_device()
+    d_un = torch.zeros((n, cap, 7), dtype=torch.float32, device="cuda")
+    d_cell = torch.zeros((n, cap), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ext.undistort_batch_device(fx, fy, cx, cy, dist, d_un.data_ptr())
+    ext.rgbd_glue_batch_device(None, False, 1.0, 0, 0, 0.0, bounds, None, None, d_cell.data_ptr(), d_kps_un=d_un.data_ptr())
+    ext.sync()
+    mt = gpu_lib.OrbMatcher()
+    d_start = torch.zeros((n, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    d_items = torch.zeros((n, cap), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    mt.grid_build_batch_device(d_cell.data_ptr(), d_counts, n, cap, d_start.data_ptr(), d_items.data_ptr())
+    pq = torch.arange(0, n - 1, dtype=torch.int32, device="cuda")
+    pt = torch.arange(1, n, dtype=torch.int32, device="cuda")
+    d_uv = d_un[:n - 1, :, :2].contiguous()                     # query positions = the undistorted keypoints of the query frame
+    d_out = torch.zeros((n - 1, cap, 4), dtype=torch.int32, device="cuda")
+    sf = ext.tables()["scale"]
+    torch.cuda.synchronize()
+    mt.window_best2_batch_device(d_un.data_ptr(), d_desc, d_counts, d_start.data_ptr(), d_items.data_ptr(), pq.data_ptr(), pt.data_ptr(),
+                                 n - 1, cap, sf, th, d_out.data_ptr(), mode=0, bounds=bounds, d_query_uv=d_uv.data_ptr())
+    mt.sync()
+    torch.cuda.synchronize()
+    un = d_un.cpu().numpy().view(np.uint8).reshape(n, cap, 28)
+    out = d_out.cpu().numpy()
+    found = 0
+    for p in range(n - 1):
+        (kq, dq), (kt, dt) = ext.batch_fetch(p), ext.batch_fetch(p + 1)
+        uq = np.frombuffer(un[p, :len(kq)].tobytes(), ob.KP_DTYPE)
+        ut = np.frombuffer(un[p + 1, :len(kt)].tobytes(), ob.KP_DTYPE)
+        view, keep = hb.frame_view(ut, dt, None, bounds)
+        want = hb.window_best2(view, uq, dq, sf, th, mode=0, query_uv=np.stack([uq["x"], uq["y"]], 1))
+        got = out[p, :len(kq)]
+        for c, name in enumerate(("best_idx", "best_dist", "second_idx", "second_dist")):
+            assert np.array_equal(got[:, c], want[name]), (p, name)
+        found += int((want["best_idx"] >= 0).sum())
+    assert found > 500
