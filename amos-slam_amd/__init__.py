@@ -31,7 +31,8 @@ EXPORTS = [
     "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
-    "amos_match_bruteforce_best2_batch_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device",
+    "amos_match_bruteforce_best2_batch_device", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
+    "amos_slic_run", "amos_slic_batch_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device",
 ]
 
 
@@ -293,6 +294,58 @@ class OrbExtractor:
     @property
     def stream(self):
         return self.L.amos_orb_stream(self.h)
+
+
+SLIC_CENTER_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("L", "<i4"), ("A", "<i4"), ("B", "<i4"), ("D", "<i4"), ("label", "<i4"), ("id", "<i4")])
+
+
+class Slic:
+    """cluster::SLIC of the reference from the Lab image on (src/cluster.cc:300-343): superpixel label map + centres."""
+
+    def __init__(self, max_width=640, max_height=480, max_batch=1, device=0, stream=None):
+        self.L = lib()
+        s = C.c_void_p()
+        _check(self.L.amos_slic_create(C.c_int(device), C.c_void_p(stream), C.c_int(max_width), C.c_int(max_height), C.c_int(max_batch),
+                                       C.byref(s)), "amos_slic_create")
+        self.s = s
+        self.L.amos_slic_stream.restype = C.c_void_p
+
+    def close(self):
+        if getattr(self, "s", None):
+            self.L.amos_slic_destroy(self.s)
+            self.s = None
+
+    def __del__(self):
+        self.close()
+
+    @staticmethod
+    def center_count(width, height, length=5):
+        nx, ny = C.c_int(0), C.c_int(0)
+        n = lib().amos_slic_center_count(C.c_int(width), C.c_int(height), C.c_int(length), C.byref(nx), C.byref(ny))
+        return n, nx.value, ny.value
+
+    def run(self, lab, depth, length=5, m=10, iterations=5):
+        lab = np.ascontiguousarray(lab, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        h, w = depth.shape
+        assert lab.shape == (h, w, 3)
+        n = self.center_count(w, h, length)[0]
+        labels = np.zeros((h, w), np.float64)
+        centers = np.zeros(max(n, 1), SLIC_CENTER_DTYPE)
+        nc = C.c_int(0)
+        _check(self.L.amos_slic_run(self.s, _p(lab), _p(depth), C.c_int(w), C.c_int(h), C.c_int(length), C.c_int(m), C.c_int(iterations),
+                                    _p(labels), _p(centers), C.byref(nc)), "amos_slic_run")
+        return labels, centers[:nc.value]
+
+    def run_batch_device(self, d_lab, d_depth, width, height, n_frames, d_labels, d_centers, length=5, m=10, iterations=5):
+        _check(self.L.amos_slic_batch_device(self.s, C.c_void_p(d_lab), C.c_void_p(d_depth), C.c_int(width), C.c_int(height), C.c_int(n_frames),
+                                             C.c_int(length), C.c_int(m), C.c_int(iterations), C.c_void_p(d_labels), C.c_void_p(d_centers)),
+               "amos_slic_batch_device")
+
+    def sync(self):
+        import torch  # noqa: F401  (the HIP runtime is torch's)
+        st = self.L.amos_slic_stream(self.s)
+        torch.cuda.ExternalStream(st).synchronize()
 
 
 class MaskPreprocessor:

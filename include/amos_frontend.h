@@ -301,6 +301,35 @@ void amos_mask_pre_destroy(amos_mask_pre *p);
 void *amos_mask_pre_stream(amos_mask_pre *p); /* the hipStream_t the handle issues on */
 int amos_mask_preprocess_batch_device(amos_mask_pre *p, const uint8_t *d_bgr, int n_frames, float *d_out);
 
+/* ---------------------------------------------------------------- SLIC superpixels (8f-2) ---- */
+
+/* ORB_SLAM2::center, include/cluster.h:21-30. */
+typedef struct amos_slic_center {
+    int32_t x, y; /* column, row */
+    int32_t L, A, B, D;
+    int32_t label; /* 1 .. n_centers */
+    int32_t id;    /* k-means cluster, filled by the caller (cluster.cc:18-24); 0 here */
+} amos_slic_center;
+
+/* cluster::SLIC (src/cluster.cc:300-343) from the Lab image on -- initilizeCenters, fituneCenter (Sobel gradient),
+ * `iterations` (5 in the reference) rounds of clustering + updateCenter with grid step `len` (5) and weight `m` (10).
+ * The cv::cvtColor(image, imageLAB, COLOR_BGR2Lab) of cluster.cc:310 stays with the caller (its 8-bit path is table
+ * driven inside OpenCV), as does the k-means over the centres that follows (cluster.cc:345-464).
+ *   lab:    height x width x 3 uint8 (imageLAB);   depth: height x width uint16 (imD)
+ *   labels: height x width float64 (labelMask / imLS: the label of the centre a pixel belongs to, 0 = none)
+ *   centers: amos_slic_center_count(width, height, len) records in creation order (row-major grid) */
+typedef struct amos_slic amos_slic;
+int amos_slic_center_count(int width, int height, int len, int *nx, int *ny);
+int amos_slic_create(int device, void *stream, int max_width, int max_height, int max_batch, amos_slic **out);
+void amos_slic_destroy(amos_slic *s);
+void *amos_slic_stream(amos_slic *s);
+int amos_slic_run(amos_slic *s, const uint8_t *lab, const uint16_t *depth, int width, int height, int len, int m, int iterations,
+              double *labels, amos_slic_center *centers, int *n_centers);
+/* The same for n_frames resident frames: d_lab [n][h][w][3], d_depth [n][h][w], d_labels [n][h][w],
+ * d_centers [n][center_count].  Asynchronous on the handle's stream. */
+int amos_slic_batch_device(amos_slic *s, const uint8_t *d_lab, const uint16_t *d_depth, int width, int height, int n_frames,
+                           int len, int m, int iterations, double *d_labels, amos_slic_center *d_centers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1741,3 +1741,118 @@ int orc_search_by_sim3(const amos_frame_view *kf1, const amos_frame_view *kf2, c
     free(m1); free(m2); free(b12); free(b21);
     return nFound;
 }
+
+/* ---------------------------------------------------------------- cluster::SLIC (src/cluster.cc) ----------
+ * From the Lab image on (cluster.cc:310's cvtColor stays with the caller).  Sequential, loop for loop as the reference:
+ * Sobel + addWeighted (:314-316), initilizeCenters (:212-244), fituneCenter (:246-298), `iterations` x { clustering
+ * (:88-158), updateCenter (:160-210) }.  Doubles throughout, no fused multiply-add.  Returns the centre count. */
+static int orc_refl101(int i, int n) { if (i < 0) i = -i; if (i >= n) i = 2 * n - 2 - i; return i; }
+
+int orc_slic(const uint8_t *lab, const uint16_t *depth, int w, int h, int len, int m, int iterations, double *labels,
+             amos_slic_center *centers, int cap)
+{
+    const size_t px = (size_t)w * h;
+    /* cv::Sobel(imageLAB, CV_64F, 0, 1, 3), cv::Sobel(.., 1, 0, 3), addWeighted(0.5, 0.5): 3 channels, REFLECT_101 */
+    double *grad = (double *)malloc(sizeof(double) * px * 3);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < 3; c++) {
+                const int ym = orc_refl101(y - 1, h), yp = orc_refl101(y + 1, h), xm = orc_refl101(x - 1, w), xp = orc_refl101(x + 1, w);
+#define LABP(yy, xx) ((int)lab[((size_t)(yy) * w + (xx)) * 3 + c])
+                const double sx = (double)((LABP(yp, xm) + 2 * LABP(yp, x) + LABP(yp, xp)) - (LABP(ym, xm) + 2 * LABP(ym, x) + LABP(ym, xp)));
+                const double sy = (double)((LABP(ym, xp) + 2 * LABP(y, xp) + LABP(yp, xp)) - (LABP(ym, xm) + 2 * LABP(y, xm) + LABP(yp, xm)));
+#undef LABP
+                grad[((size_t)y * w + x) * 3 + c] = sx * 0.5 + sy * 0.5;
+            }
+    /* initilizeCenters */
+    int n = 0;
+    for (int i = 0; i < h; i += len) {
+        const int cy = i + len / 2;
+        if (cy >= h) continue;
+        for (int j = 0; j < w; j += len) {
+            const int cx = j + len / 2;
+            if (cx >= w) continue;
+            if (n < cap) {
+                amos_slic_center *ce = &centers[n];
+                ce->x = cx; ce->y = cy;
+                ce->L = lab[((size_t)cy * w + cx) * 3]; ce->A = lab[((size_t)cy * w + cx) * 3 + 1]; ce->B = lab[((size_t)cy * w + cx) * 3 + 2];
+                ce->label = n + 1;
+                ce->D = depth[(size_t)cy * w + cx];
+                ce->id = 0;
+            }
+            n++;
+        }
+    }
+    if (n > cap) { free(grad); return n; }
+    /* fituneCenter */
+    for (int ck = 0; ck < n; ck++) {
+        amos_slic_center cent = centers[ck];
+        if (cent.x - 1 < 0 || cent.x + 1 >= w || cent.y - 1 < 0 || cent.y + 1 >= h) continue;
+        double minGradient = 9999999;
+        int tempx = 0, tempy = 0;
+        for (int mm = -1; mm < 2; mm++)
+            for (int nn = -1; nn < 2; nn++) {
+                const double *g = &grad[((size_t)(cent.y + mm) * w + (cent.x + nn)) * 3];
+                const double gradient = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+                if (gradient < minGradient) { minGradient = gradient; tempy = mm; tempx = nn; }
+            }
+        cent.x += tempx;
+        cent.y += tempy;
+        centers[ck].x = cent.x;
+        centers[ck].y = cent.y;
+        centers[ck].L = lab[((size_t)cent.y * w + cent.x) * 3];
+        centers[ck].A = lab[((size_t)cent.y * w + cent.x) * 3 + 1];
+        centers[ck].B = lab[((size_t)cent.y * w + cent.x) * 3 + 2];
+    }
+    free(grad);
+    for (size_t p = 0; p < px; p++) labels[p] = 0;
+    double *dis_mask = (double *)malloc(sizeof(double) * px);
+    for (int time = 0; time < iterations; time++) {
+        for (size_t p = 0; p < px; p++) dis_mask[p] = 999999;
+        for (int ck = 0; ck < n; ck++) { /* clustering */
+            const int cx = centers[ck].x, cy = centers[ck].y, cL = centers[ck].L, cA = centers[ck].A, cB = centers[ck].B;
+            for (int i = cy - len; i < cy + len; i++) {
+                if (i < 0 || i >= h) continue;
+                for (int j = cx - len; j < cx + len; j++) {
+                    if (j < 0 || j >= w) continue;
+                    const int L = lab[((size_t)i * w + j) * 3], A = lab[((size_t)i * w + j) * 3 + 1], B = lab[((size_t)i * w + j) * 3 + 2];
+                    const double disc = sqrt((double)((L - cL) * (L - cL) + (A - cA) * (A - cA) + (B - cB) * (B - cB)));
+                    const double diss = sqrt((double)((j - cx) * (j - cx) + (i - cy) * (i - cy)));
+                    const double dis = sqrt(disc * disc + m * (diss * diss));
+                    if (dis < dis_mask[(size_t)i * w + j]) {
+                        dis_mask[(size_t)i * w + j] = dis;
+                        labels[(size_t)i * w + j] = centers[ck].label;
+                    }
+                }
+            }
+        }
+        for (int ck = 0; ck < n; ck++) { /* updateCenter */
+            double sumx = 0, sumy = 0, sumL = 0, sumA = 0, sumB = 0, sumNum = 0, sumD = 0;
+            const int cx = centers[ck].x, cy = centers[ck].y;
+            for (int i = cy - len; i < cy + len; i++) {
+                if (i < 0 || i >= h) continue;
+                for (int j = cx - len; j < cx + len; j++) {
+                    if (j < 0 || j >= w) continue;
+                    if (labels[(size_t)i * w + j] == centers[ck].label) {
+                        sumL += lab[((size_t)i * w + j) * 3];
+                        sumA += lab[((size_t)i * w + j) * 3 + 1];
+                        sumB += lab[((size_t)i * w + j) * 3 + 2];
+                        sumx += j;
+                        sumy += i;
+                        sumNum += 1;
+                        sumD += (int)depth[(size_t)i * w + j];
+                    }
+                }
+            }
+            if (sumNum == 0) sumNum = 0.000000001;
+            centers[ck].x = (int)(sumx / sumNum);
+            centers[ck].y = (int)(sumy / sumNum);
+            centers[ck].L = (int)(sumL / sumNum);
+            centers[ck].A = (int)(sumA / sumNum);
+            centers[ck].B = (int)(sumB / sumNum);
+            centers[ck].D = (int)(sumD / sumNum);
+        }
+    }
+    free(dis_mask);
+    return n;
+}

@@ -138,6 +138,9 @@ int orc_search_by_sim3(const amos_frame_view *kf1, const amos_frame_view *kf2, c
                        const amos_window_query *q21, int n21, const float *scale_factors1, const float *scale_factors2, float th,
                        int32_t *matches12);
 
+int orc_slic(const uint8_t *lab, const uint16_t *depth, int w, int h, int len, int m, int iterations, double *labels,
+             amos_slic_center *centers, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -302,3 +302,20 @@ def image_bounds(width, height, fx, fy, cx, cy, dist):
     lib().orc_image_bounds(C.c_int(width), C.c_int(height), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), _p(dist),
                            C.c_int(len(dist)), _p(out))
     return tuple(float(v) for v in out)
+
+
+SLIC_CENTER_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("L", "<i4"), ("A", "<i4"), ("B", "<i4"), ("D", "<i4"), ("label", "<i4"), ("id", "<i4")])
+
+
+def slic(lab, depth, length=5, m=10, iterations=5):
+    """orc_slic: cluster::SLIC from the Lab image on.  Returns (label map float64, centres)."""
+    lab = np.ascontiguousarray(lab, np.uint8)
+    depth = np.ascontiguousarray(depth, np.uint16)
+    h, w = depth.shape
+    cap = ((h + length - 1) // length) * ((w + length - 1) // length) + 1
+    labels = np.zeros((h, w), np.float64)
+    centers = np.zeros(cap, SLIC_CENTER_DTYPE)
+    n = lib().orc_slic(_p(lab), _p(depth), C.c_int(w), C.c_int(h), C.c_int(length), C.c_int(m), C.c_int(iterations), _p(labels), _p(centers),
+                       C.c_int(cap))
+    assert 0 < n <= cap
+    return labels, centers[:n]

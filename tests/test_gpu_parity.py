@@ -644,3 +644,52 @@ def test_match_consecutive_frames(gpu_lib, ob, synth):
     _same(got, ob.bruteforce_best2(d1, d0), "consecutive-frame matches")
     good = (got["best_dist"] <= 50) & (got["best_dist"] < 0.6 * got["second_dist"])
     assert good.sum() > 100  # the scene moved by (2, 1) px: most corners re-match
+
+
+def _lab_scene(rng, h, w):
+    base = np.kron(rng.integers(0, 256, ((h + 23) // 24, (w + 23) // 24, 3)), np.ones((24, 24, 1)))[:h, :w]
+    lab = np.clip(base + rng.normal(0, 6, (h, w, 3)), 0, 255).astype(np.uint8)
+    depth = (5000 * (1.5 + 0.5 * np.sin(np.arange(w) / 40.0))[None, :] * np.ones((h, 1))).astype(np.uint16)
+    depth[rng.random((h, w)) < 0.1] = 0
+    return lab, depth
+
+
+@pytest.mark.parametrize("w,h,length", [(640, 480, 5), (322, 241, 5), (203, 157, 4), (64, 48, 7)])
+def test_slic_vs_oracle(gpu_lib, ob, w, h, length):
+    """8f-2 (SLIC half): cluster::SLIC from the Lab image on -- label map (float64) and centres, bit for bit."""
+    rng = np.random.default_rng(w + h)
+    lab, depth = _lab_scene(rng, h, w)
+    sl = gpu_lib.Slic(max_width=w, max_height=h)
+    for iters in (0, 2, 5):
+        lg, cg = sl.run(lab, depth, length, 10, iters)
+        lo, co = ob.slic(lab, depth, length, 10, iters)
+        _same(lg, lo, f"label map after {iters} iterations")
+        _same(cg, co, f"centres after {iters} iterations")
+    assert gpu_lib.Slic.center_count(w, h, length)[0] == len(co)
+    # flat image: every distance ties except for the spatial term; uniform depth
+    flat = np.full((h, w, 3), 128, np.uint8)
+    lg, cg = sl.run(flat, np.full((h, w), 4000, np.uint16), length, 10, 5)
+    lo, co = ob.slic(flat, np.full((h, w), 4000, np.uint16), length, 10, 5)
+    _same(lg, lo, "flat label map")
+    _same(cg, co, "flat centres")
+
+
+def test_slic_batch_device(gpu_lib, ob):
+    import torch
+    n, w, h = 3, 320, 240
+    rng = np.random.default_rng(5)
+    scenes = [_lab_scene(rng, h, w) for _ in range(n)]
+    d_lab = torch.from_numpy(np.stack([s[0] for s in scenes])).cuda()
+    d_depth = torch.from_numpy(np.stack([s[1] for s in scenes]).view(np.int16)).cuda()
+    nc = gpu_lib.Slic.center_count(w, h, 5)[0]
+    d_labels = torch.zeros((n, h, w), dtype=torch.float64, device="cuda")
+    d_cent = torch.zeros((n, nc, 8), dtype=torch.int32, device="cuda")
+    sl = gpu_lib.Slic(max_width=w, max_height=h, max_batch=n)
+    torch.cuda.synchronize()
+    sl.run_batch_device(d_lab.data_ptr(), d_depth.data_ptr(), w, h, n, d_labels.data_ptr(), d_cent.data_ptr())
+    sl.sync()
+    torch.cuda.synchronize()
+    for f in range(n):
+        lo, co = ob.slic(*scenes[f])
+        _same(d_labels[f].cpu().numpy(), lo, f"frame {f} labels")
+        _same(np.frombuffer(d_cent[f].cpu().numpy().tobytes(), ob.SLIC_CENTER_DTYPE), co, f"frame {f} centres")

@@ -558,6 +558,92 @@ def test_undistort_points_inverts_the_distortion_model(ob):
     assert ob.image_bounds(640, 480, fx, fy, cx, cy, np.zeros(5, np.float32)) == (0.0, 640.0, 0.0, 480.0)
 
 
+def _lab_image(rng, h, w):
+    """Blocky colour regions + noise, like a Lab image of an indoor scene; depth in millimetre-like units."""
+    base = np.kron(rng.integers(0, 256, ((h + 23) // 24, (w + 23) // 24, 3)), np.ones((24, 24, 1)))[:h, :w]
+    lab = np.clip(base + rng.normal(0, 6, (h, w, 3)), 0, 255).astype(np.uint8)
+    depth = (5000 * (1.5 + 0.5 * np.sin(np.arange(w) / 40.0))[None, :] * np.ones((h, 1))).astype(np.uint16)
+    depth[rng.random((h, w)) < 0.1] = 0
+    return lab, depth
+
+
+def py_slic(lab, depth, length, m, iterations):
+    """Independent restatement of cluster::SLIC (cluster.cc:88-343 after cvtColor): Sobel by array slicing, the
+    assignment as a per-pixel minimum over (distance, centre index) instead of the sequential overwrite."""
+    h, w = depth.shape
+    L = lab.astype(np.int64)
+    pad = np.pad(L, ((1, 1), (1, 1), (0, 0)), mode="reflect")          # REFLECT_101
+    sob_dy = (pad[2:, :-2] + 2 * pad[2:, 1:-1] + pad[2:, 2:]) - (pad[:-2, :-2] + 2 * pad[:-2, 1:-1] + pad[:-2, 2:])
+    sob_dx = (pad[:-2, 2:] + 2 * pad[1:-1, 2:] + pad[2:, 2:]) - (pad[:-2, :-2] + 2 * pad[1:-1, :-2] + pad[2:, :-2])
+    grad = sob_dy * 0.5 + sob_dx * 0.5
+    g2 = (grad ** 2)[..., 0] + (grad ** 2)[..., 1] + (grad ** 2)[..., 2]
+    cents = []
+    for i in range(0, h, length):
+        cy = i + length // 2
+        if cy >= h:
+            continue
+        for j in range(0, w, length):
+            cx = j + length // 2
+            if cx >= w:
+                continue
+            cents.append([cx, cy, int(L[cy, cx, 0]), int(L[cy, cx, 1]), int(L[cy, cx, 2]), int(depth[cy, cx]), len(cents) + 1])
+    for c in cents:
+        cx, cy = c[0], c[1]
+        if cx - 1 < 0 or cx + 1 >= w or cy - 1 < 0 or cy + 1 >= h:
+            continue
+        win = g2[cy - 1:cy + 2, cx - 1:cx + 2]
+        k = int(np.argmin(win))                                         # first minimum in row-major (m outer, n inner) order
+        c[0], c[1] = cx + k % 3 - 1, cy + k // 3 - 1
+        c[2:5] = [int(v) for v in L[c[1], c[0]]]
+    labels = np.zeros((h, w))
+    for _ in range(iterations):
+        best = np.full((h, w), 999999.0)
+        owner = np.full((h, w), -1)
+        for ck, (cx, cy, cL, cA, cB, cD, lb) in enumerate(cents):
+            y0, y1, x0, x1 = max(cy - length, 0), min(cy + length, h), max(cx - length, 0), min(cx + length, w)
+            if y0 >= y1 or x0 >= x1:
+                continue
+            blk = L[y0:y1, x0:x1]
+            disc = np.sqrt(((blk[..., 0] - cL) ** 2 + (blk[..., 1] - cA) ** 2 + (blk[..., 2] - cB) ** 2).astype(np.float64))
+            yy, xx = np.mgrid[y0:y1, x0:x1]
+            diss = np.sqrt(((xx - cx) ** 2 + (yy - cy) ** 2).astype(np.float64))
+            dis = np.sqrt(disc * disc + m * (diss * diss))
+            take = dis < best[y0:y1, x0:x1]                              # strictly smaller: the earlier centre keeps ties
+            best[y0:y1, x0:x1][take] = dis[take]
+            owner[y0:y1, x0:x1][take] = ck
+        cov = owner >= 0
+        labels[cov] = np.array([c[6] for c in cents])[owner[cov]]
+        for c in cents:
+            cx, cy, lb = c[0], c[1], c[6]
+            y0, y1, x0, x1 = max(cy - length, 0), min(cy + length, h), max(cx - length, 0), min(cx + length, w)
+            sel = labels[y0:y1, x0:x1] == lb if (y0 < y1 and x0 < x1) else np.zeros((0, 0), bool)
+            num = float(sel.sum()) if sel.size else 0.0
+            if num == 0:
+                num = 0.000000001
+            yy, xx = np.mgrid[y0:y1, x0:x1] if (y0 < y1 and x0 < x1) else (np.zeros((0, 0)), np.zeros((0, 0)))
+            blk = L[y0:y1, x0:x1]
+            c[0] = int(float(xx[sel].sum()) / num)
+            c[1] = int(float(yy[sel].sum()) / num)
+            c[2] = int(float(blk[..., 0][sel].sum()) / num)
+            c[3] = int(float(blk[..., 1][sel].sum()) / num)
+            c[4] = int(float(blk[..., 2][sel].sum()) / num)
+            c[5] = int(float(depth[y0:y1, x0:x1].astype(np.int64)[sel].sum()) / num)
+    return labels, np.array(cents, np.int64)
+
+
+@pytest.mark.parametrize("h,w,length", [(60, 83, 5), (47, 64, 4), (33, 40, 7)])
+def test_slic_matches_python_restatement(ob, h, w, length):
+    rng = np.random.default_rng(h * w)
+    lab, depth = _lab_image(rng, h, w)
+    for iters in (0, 1, 5):
+        lo, co = ob.slic(lab, depth, length, 10, iters)
+        lp, cp = py_slic(lab, depth, length, 10, iters)
+        assert np.array_equal(lo, lp), f"label map, {iters} iterations"
+        for k, name in enumerate(("x", "y", "L", "A", "B", "D", "label")):
+            assert np.array_equal(co[name], cp[:, k]), (name, iters)
+    assert len(np.unique(lo)) > len(co) // 2                               # most centres own pixels
+
+
 # ------------------------------------------------------------------------------------ golden fixtures
 
 
