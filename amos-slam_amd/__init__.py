@@ -22,7 +22,7 @@ BEST2_DTYPE = np.dtype([("best_idx", "<i4"), ("best_dist", "<i4"), ("second_idx"
 TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # ORBmatcher.cc:49-51
 
 EXPORTS = [
-    "amos_last_error", "amos_device_count", "amos_orb_create", "amos_orb_destroy", "amos_orb_tables",
+    "amos_last_error", "amos_device_count", "amos_orb_geometry_probe", "amos_orb_create", "amos_orb_destroy", "amos_orb_tables",
     "amos_orb_level_sizes", "amos_orb_detect", "amos_orb_level_count", "amos_orb_level_keypoints",
     "amos_orb_set_level_keypoints", "amos_orb_level_layout", "amos_orb_fetch_levels", "amos_orb_store_levels", "amos_orb_gate", "amos_orb_closed_mask", "amos_orb_describe",
     "amos_orb_extract", "amos_orb_level_image", "amos_orb_blurred_image", "amos_orb_level_candidates",
@@ -82,6 +82,15 @@ def _check(rc, what):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def geometry_probe(max_width, max_height, width, height, n_features=1000, scale_factor=1.2, n_levels=8, ini_th=20, min_th=7):
+    """Host-only: (rc, need[6], cap[6]) of amos_orb_geometry_probe -- no device is touched."""
+    params = OrbParams(n_features, scale_factor, n_levels, ini_th, min_th)
+    need, cap = np.zeros(6, np.int32), np.zeros(6, np.int32)
+    rc = lib().amos_orb_geometry_probe(C.byref(params), C.c_int(max_width), C.c_int(max_height), C.c_int(width), C.c_int(height),
+                                       _p(need), _p(cap))
+    return rc, need, cap
 
 
 def device_count():

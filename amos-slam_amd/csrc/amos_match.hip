@@ -231,9 +231,12 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowArgs a, amos_b
     int x1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(u, a.minX), r), a.wInv));
     int y0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(v, a.minY), r), a.hInv));
     int y1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(v, a.minY), r), a.hInv));
+    // Frame.cc:905-921: the reference returns early when a clamp range is empty; without this a query projected far
+    // outside the bounds would index cellStart with y0 >= ROWS
+    const bool empty = x0 >= AMOS_FRAME_GRID_COLS || x1 < 0 || y0 >= AMOS_FRAME_GRID_ROWS || y1 < 0;
     x0 = max(x0, 0); y0 = max(y0, 0);
-    x1 = min(x1, AMOS_FRAME_GRID_COLS - 1); y1 = min(y1, AMOS_FRAME_GRID_ROWS - 1);
-    // (the reference's early returns for an empty clamp range are the empty loops below)
+    x1 = empty ? -1 : min(x1, AMOS_FRAME_GRID_COLS - 1); y1 = min(y1, AMOS_FRAME_GRID_ROWS - 1);
+    y0 = min(y0, AMOS_FRAME_GRID_ROWS - 1);
     const int *cs = a.cellStart + (size_t)ft * (kGridCells + 1);
     const int *it = a.items + (size_t)ft * a.capacity;
     const amos_keypoint *tk = a.kps + (size_t)ft * a.capacity;

@@ -279,6 +279,46 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
     return AMOS_OK;
 }
 
+// Capacities of a handle for frames up to maxW x maxH (host only: no device call).
+static int compute_capacity(amos_orb *h)
+{
+    const int max_width = h->maxW, max_height = h->maxH;
+    std::vector<Cell> cells;
+    std::vector<ResizeTap> taps;
+    int rc = build_geometry(h, max_width, max_height, h->capGeom, &cells, &taps);
+    if (rc != AMOS_OK) return rc;
+    // The allocation must hold EVERY frame up to max_width x max_height, and the cell layout of a smaller frame is
+    // not always smaller (fewer, larger cells; another aspect ratio and so more quad-tree roots): inflate the
+    // layout-dependent capacities of the largest frame to bounds that hold for all of them.
+    {
+        Geom &cg = h->capGeom;
+        long long slots = 0, ncell = 0, kpl = 0;
+        const int nIniMax = std::max(1, (int)std::lround((double)max_width / 48.0));  // width / height of any frame with a FAST cell
+        for (int l = 0; l < cg.nLevels; l++) {
+            const long long w = cg.lv[l].w, hh = cg.lv[l].h;
+            slots += (w * hh * 27 + 99) / 100 + 64;           // sum of ceil(tw/2) * ceil(th/2) over cells of >= 30 px: <= (31/30)^2 / 4 of the area
+            ncell += (w / 30 + 2) * (hh / 30 + 2);
+            kpl += std::max(cg.lv[l].quota, 4 * nIniMax) + 4;
+        }
+        cg.slotTotal = (int)std::max<long long>(cg.slotTotal, slots);
+        cg.ptsTotal = (int)std::max<long long>(cg.ptsTotal, slots);
+        cg.kpLevelTotal = (int)std::max<long long>(cg.kpLevelTotal, kpl);
+        cg.kpCap = cg.kpLevelTotal;
+        h->capCells = (size_t)std::max<long long>((long long)cells.size(), ncell) + 64;
+        cg.totalCells = (int)h->capCells;  // dSlotCount is indexed frame * totalCells + cell with the CURRENT frame's totalCells <= capCells
+    }
+    h->capTaps = taps.size() + 64 + 8 * (size_t)h->capGeom.nLevels;
+    return AMOS_OK;
+}
+
+// does a W x H frame fit the handle's capacities?  (the ONE comparison set_geometry and the probe use)
+static bool geometry_fits(const amos_orb *h, const Geom &g, size_t nTaps)
+{
+    const Geom &c = h->capGeom;
+    return g.frameBytes <= c.frameBytes && g.totalCells <= c.totalCells && (size_t)g.totalCells <= h->capCells && g.slotTotal <= c.slotTotal &&
+           g.ptsTotal <= c.ptsTotal && g.kpLevelTotal <= c.kpLevelTotal && nTaps <= h->capTaps;
+}
+
 static int set_geometry(amos_orb *h, int W, int Hh)
 {
     if (W == h->curW && Hh == h->curH) return AMOS_OK;
@@ -288,9 +328,11 @@ static int set_geometry(amos_orb *h, int W, int Hh)
     std::vector<ResizeTap> taps;
     int rc = build_geometry(h, W, Hh, g, &cells, &taps);
     if (rc != AMOS_OK) return rc;
+    // the side stream may still be reading dGeom / dPyr (k_blur of a detect-only call): let it finish
+    // before the geometry records below are overwritten
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->streamB));
     const Geom &c = h->capGeom;
-    if (g.frameBytes > c.frameBytes || g.totalCells > (int)h->capCells || g.slotTotal > c.slotTotal ||
-        g.ptsTotal > c.ptsTotal || g.kpLevelTotal > c.kpLevelTotal || taps.size() > h->capTaps) {
+    if (!geometry_fits(h, g, taps.size())) {
         set_error("frame %dx%d needs more scratch than the handle's %dx%d allocation", W, Hh, h->maxW, h->maxH);
         return AMOS_ERR_CAPACITY;
     }
@@ -327,6 +369,9 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
 {
     const Geom &g = h->geom;
     hipEvent_t *ev = (h->maxRecords > 0 && h->nRecords < h->maxRecords) ? &h->events[(size_t)h->nRecords * (kTimingEvents)] : nullptr;
+    // a previous detect-only call may still have its blur in flight on the side stream, reading the planes
+    // that the pyramid kernels below overwrite
+    if (h->blurDone) AMOS_HIP_CHECK(hipStreamWaitEvent(h->stream, h->evJoin, 0));
     if (ev) (void)hipEventRecord(ev[0], h->stream);
     for (int l = 0; l < g.nLevels; l++) {
         const LevelGeom &lg = g.lv[l];
@@ -422,6 +467,36 @@ int amos_device_count(void)
     return n;
 }
 
+int amos_orb_geometry_probe(const amos_orb_params *params, int max_width, int max_height, int width, int height, int32_t need[6], int32_t cap[6])
+{
+    if (!params || max_width < 1 || max_height < 1 || width < 1 || height < 1 || params->n_levels < 1 || params->n_levels > AMOS_MAX_LEVELS ||
+        params->n_features < 1 || !(params->scale_factor > 1.0f) || !(params->scale_factor <= 2.0f)) {
+        set_error("amos_orb_geometry_probe: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    amos_orb h;  // host fields only: nothing is allocated on a device
+    h.p = *params;
+    h.maxW = max_width;
+    h.maxH = max_height;
+    build_tables(&h);
+    int rc = compute_capacity(&h);
+    if (rc != AMOS_OK) return rc;
+    if (width > max_width || height > max_height) { set_error("frame %dx%d exceeds %dx%d", width, height, max_width, max_height); return AMOS_ERR_CAPACITY; }
+    Geom g;
+    std::vector<Cell> cells;
+    std::vector<ResizeTap> taps;
+    rc = build_geometry(&h, width, height, g, &cells, &taps);
+    if (rc != AMOS_OK) return rc;
+    const Geom &c = h.capGeom;
+    const long long n[6] = {(long long)g.totalCells, g.slotTotal, g.ptsTotal, g.kpLevelTotal, (long long)taps.size(), (long long)(g.frameBytes >> 8)};
+    const long long k[6] = {(long long)c.totalCells, c.slotTotal, c.ptsTotal, c.kpLevelTotal, (long long)h.capTaps, (long long)(c.frameBytes >> 8)};
+    for (int i = 0; i < 6; i++) {
+        if (need) need[i] = (int32_t)n[i];
+        if (cap) cap[i] = (int32_t)k[i];
+    }
+    return geometry_fits(&h, g, taps.size()) ? AMOS_OK : AMOS_ERR_CAPACITY;
+}
+
 int amos_orb_create(const amos_orb_params *params, int max_width, int max_height, int max_batch, int device,
                     void *stream, amos_orb **out)
 {
@@ -441,31 +516,9 @@ int amos_orb_create(const amos_orb_params *params, int max_width, int max_height
     build_tables(h);
     static const int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     if (std::memcmp(kUmax, h->umax, sizeof(kUmax)) != 0) { set_error("umax table mismatch"); delete h; return AMOS_ERR_INVALID; }
-    std::vector<Cell> cells;
-    std::vector<ResizeTap> taps;
-    int rc = build_geometry(h, max_width, max_height, h->capGeom, &cells, &taps);
+    int rc = compute_capacity(h);
     if (rc != AMOS_OK) { delete h; return rc; }
-    // The allocation must hold EVERY frame up to max_width x max_height, and the cell layout of a smaller frame is
-    // not always smaller (fewer, larger cells; another aspect ratio and so more quad-tree roots): inflate the
-    // layout-dependent capacities of the largest frame to bounds that hold for all of them.
-    {
-        Geom &cg = h->capGeom;
-        long long slots = 0, ncell = 0, kpl = 0;
-        const int nIniMax = std::max(1, (int)std::lround((double)max_width / 48.0));  // width / height of any frame with a FAST cell
-        for (int l = 0; l < cg.nLevels; l++) {
-            const long long w = cg.lv[l].w, hh = cg.lv[l].h;
-            slots += (w * hh * 27 + 99) / 100 + 64;           // sum of ceil(tw/2) * ceil(th/2) over cells of >= 30 px: <= (31/30)^2 / 4 of the area
-            ncell += (w / 30 + 2) * (hh / 30 + 2);
-            kpl += std::max(cg.lv[l].quota, 4 * nIniMax) + 4;
-        }
-        cg.slotTotal = (int)std::max<long long>(cg.slotTotal, slots);
-        cg.ptsTotal = (int)std::max<long long>(cg.ptsTotal, slots);
-        cg.kpLevelTotal = (int)std::max<long long>(cg.kpLevelTotal, kpl);
-        cg.kpCap = cg.kpLevelTotal;
-        h->capCells = (size_t)std::max<long long>((long long)cells.size(), ncell) + 64;
-    }
     const Geom &c = h->capGeom;
-    h->capTaps = taps.size() + 64 + 8 * (size_t)c.nLevels;
     if (stream) h->stream = (hipStream_t)stream;
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -601,6 +654,7 @@ int amos_orb_detect(amos_orb *h, const uint8_t *gray, size_t stride, int width, 
     rc = launch_detect(h, h->dInput, 0, h->inputPitch, 1);
     if (rc != AMOS_OK) return rc;
     AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->streamB));  // the blur on the side stream reads dInput's pyramid: nothing of this call is in flight on return
     return AMOS_OK;
 }
 

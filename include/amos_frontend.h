@@ -94,6 +94,15 @@ int amos_orb_create(const amos_orb_params *params, int max_width, int max_height
                     int device, void *stream, amos_orb **out);
 void amos_orb_destroy(amos_orb *h);
 
+/* Host-only capacity check (no device is touched): would a handle created for frames up to
+ * max_width x max_height accept a width x height frame?  need / cap (either may be NULL) receive
+ * {FAST cells, candidate slots, compacted candidates, per-level keypoint slots, resize tap records,
+ * pyramid bytes / 256} of the frame and of the allocation.  Returns AMOS_OK, AMOS_ERR_CAPACITY
+ * (a bound is exceeded: amos_orb_create's sizing would be wrong) or AMOS_ERR_INVALID (the frame has a
+ * level without a FAST cell, which the reference cannot process either, ORBextractor.cc:1083-1086). */
+int amos_orb_geometry_probe(const amos_orb_params *params, int max_width, int max_height, int width,
+                            int height, int32_t need[6], int32_t cap[6]);
+
 /* Constructor tables (a1).  Any pointer may be NULL.  Arrays hold n_levels entries, umax 16. */
 int amos_orb_tables(const amos_orb *h, float *scale_factor, float *inv_scale_factor,
                     float *level_sigma2, float *inv_level_sigma2, int32_t *features_per_level,
