@@ -288,6 +288,10 @@ class OrbExtractor:
     def sync(self):
         _check(self.L.amos_orb_sync(self.h), "amos_orb_sync")
 
+    def pyramid_launches(self):
+        """launches of the resize kernel(s) per pass (the "pyramid" stage of timing_collect)"""
+        return self.n_levels - 1
+
     STAGES = ("import", "pyramid", "fast", "octree", "orient", "blur", "describe")
 
     def timing_enable(self, max_records):

@@ -41,6 +41,14 @@ class MaskEngine:
             torch.backends.cudnn.benchmark = True  # MIOpen solver search on first use of a shape
         self._hip_pre = {}  # (height, width) -> MaskPreprocessor, made on first use (GPU only)
 
+    def prepare(self):
+        """Inference form of the network: batch norms folded into the convolutions (same function up to float32
+        rounding of the folded weights; tests/test_mask.py holds it to the golden tensors and IoU >= 1 - 1e-3)."""
+        self.net.fold_batch_norms()
+        if self.channels_last:
+            self.net.to(memory_format=torch.channels_last)
+        return self
+
     def _preprocess_hip(self, frames):
         """The whole pre-processing chain in three HIP kernels (libamos_frontend.so, amos_mask_pre_*): returns
         the [b, 3, 550, 550] network input for [b, H, W, 3] uint8 frames on this engine's GPU."""

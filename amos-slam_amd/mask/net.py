@@ -23,6 +23,22 @@ PRED_SCALES = (24, 48, 96, 192, 384)   # one scale per pyramid level
 ASPECT_RATIOS = (1.0, 0.5, 2.0)        # pred_aspect_ratios; anchors are squares (use_square_anchors)
 
 
+def _fold(conv, bn):
+    """conv followed by an inference-mode batch norm == one conv with scaled weights and a bias:
+    w' = w * g / sqrt(var + eps),  b' = beta - mean * g / sqrt(var + eps)   (folded in float64, stored float32)."""
+    with torch.no_grad():
+        scale = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+        w = (conv.weight.double() * scale.view(-1, 1, 1, 1)).to(conv.weight.dtype)
+        b = bn.bias.double() - bn.running_mean.double() * scale
+        if conv.bias is not None:
+            b = b + conv.bias.double() * scale
+        fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups, bias=True)
+        fused = fused.to(device=conv.weight.device, dtype=conv.weight.dtype)
+        fused.weight.copy_(w)
+        fused.bias.copy_(b.to(conv.weight.dtype))
+    return fused
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -45,6 +61,13 @@ class Bottleneck(nn.Module):
         y = self.bn3(self.conv3(y))
         return F.relu(y + (x if self.downsample is None else self.downsample(x)))
 
+    def fold_batch_norms(self):
+        for k in (1, 2, 3):
+            setattr(self, f"conv{k}", _fold(getattr(self, f"conv{k}"), getattr(self, f"bn{k}")))
+            setattr(self, f"bn{k}", nn.Identity())
+        if self.downsample is not None:
+            self.downsample = nn.Sequential(_fold(self.downsample[0], self.downsample[1]), nn.Identity())
+
 
 class ResNet50Trunk(nn.Module):
     """backbone.py:60-125 with args ([3, 4, 6, 3],); returns the four stage outputs."""
@@ -63,6 +86,13 @@ class ResNet50Trunk(nn.Module):
             seq += [Bottleneck(inplanes, planes) for _ in range(n - 1)]
             self.layers.append(nn.Sequential(*seq))
             self.channels.append(inplanes)
+
+    def fold_batch_norms(self):
+        self.conv1 = _fold(self.conv1, self.bn1)
+        self.bn1 = nn.Identity()
+        for layer in self.layers:
+            for block in layer:
+                block.fold_batch_norms()
 
     def forward(self, x):
         x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
@@ -167,6 +197,15 @@ class YolactR50(nn.Module):
             elif key.startswith("fpn.downsample_layers.") and int(key.split(".")[2]) >= 2:
                 del sd[key]
         return self.load_state_dict(sd, strict=False)
+
+    def fold_batch_norms(self):
+        """Inference form: every batch norm of the trunk becomes part of its convolution (53 fewer elementwise
+        passes over the activations).  After this the module no longer matches the checkpoint's key layout:
+        load the weights FIRST.  Idempotent."""
+        if not getattr(self, "_folded", False):
+            self.backbone.fold_batch_norms()
+            self._folded = True
+        return self
 
     def forward(self, x):
         """x: [B, 3, 550, 550] normalised RGB.  Returns raw network outputs (before Detect):

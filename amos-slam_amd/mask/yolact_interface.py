@@ -26,7 +26,7 @@ def yolact_init(weight_path, num_class):
     """weight_path: a YOLACT-ResNet50 `.pth`, or "" for seeded random weights (performance runs only)."""
     global model_interface
     device = os.environ.get("AMOS_MASK_DEVICE") or None
-    model_interface = _mask_package().MaskEngine(weight_path or None, device=device)
+    model_interface = _mask_package().MaskEngine(weight_path or None, device=device).prepare()  # weights loaded, then batch norms folded
     return
 
 

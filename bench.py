@@ -1,19 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- front-end frames/sec (ORB extract + brute-force Hamming match) on MI355X.
+"""bench.py -- front-end frames/sec (ORB extract + match + mask) on MI355X.
 
-A step = one pass of the hot path over one batch of B synthetic 640x480 frames that are already
-resident in HBM: ORB extraction of every frame (pyramid, FAST, quad-tree, orientation, blur, rBRIEF)
-followed by the N x N best-2 Hamming match of frame k against frame k-1.  One process per GPU; rank r
-works on its own synthetic stream r (frames are independent: no data-path collective, weak scaling);
-RCCL is used only for the barrier / max-over-ranks time and the final gather of result digests.
+Default run = BASELINE.json configs[2], the metric as written: a step is one pass of the whole front-end
+over one batch of synthetic 640x480 frames already resident in HBM --
+    ORB detect (pyramid, FAST, quad-tree, orientation)         [HIP, this repo]
+    YOLACT-R50 person mask, fp32                                [PyTorch-ROCm / MIOpen]
+    mask gate (31x31 closing + keypoint removal)                [HIP]
+    blur + rBRIEF descriptors                                   [HIP]
+    N x N best-2 Hamming match of frame k against frame k-1     [HIP]
+(Tracking.cc:366 -> Frame.cc:491-496,633 -> ORBmatcher).  `value` is that.  The same JSON line carries the
+mask-off sub-leg (`extract_match_leg`, BASELINE configs[1]: extract + match only, the part that is hand-written
+HIP), its HBM `roofline` for the dominant kernel, `roofline_mask` (achieved fp32 TFLOP/s of the network against
+the MFMA fp32 peak) and `cpu_baseline` (the CPU oracle on all granted host cores, plus one thread).
+
+One process per GPU; rank r works on its own synthetic stream r (frames are independent: no data-path
+collective, weak scaling); RCCL is used only for the barrier / max-over-ranks time and the final gather of the
+per-frame result digests.  `python bench.py --gpus N` with N > 1 and no launcher environment starts
+`python -m torch.distributed.run` itself (before anything touches a GPU) and relays rank 0's line.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -25,15 +39,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TF = 157.3   # dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32), same guide; gfx950 has no TF32/xf32
+
+METRIC = "front-end frames/sec (ORB extract+match+mask) at 640x480"
 
 CONFIGS = {
     # BASELINE.json configs[1]: single MI355X, extract + brute-force match, mask disabled
-    "c2": dict(width=640, height=480, n_features=1000, n_levels=8, default_batch=512, default_streams=4, label="configs[1]: 640x480 L8 N1000 extract+match, mask off"),
+    "c2": dict(width=640, height=480, n_features=1000, n_levels=8, default_batch=512, default_streams=4,
+               label="configs[1]: 640x480 L8 N1000 extract+match, mask off"),
     # BASELINE.json configs[2]: full front-end incl. the YOLACT mask (network on PyTorch-ROCm, random weights
     # with a biased class head so that ~100 detections exercise the whole post-processing chain)
-    "c3": dict(width=640, height=480, n_features=1000, n_levels=8, mask=True, default_batch=32,
-               label="configs[2]: 640x480 L8 N1000 YOLACT-R50 mask + extract + gate + match"),
+    "c3": dict(width=640, height=480, n_features=1000, n_levels=8, mask=True, default_batch=32, default_streams=2,
+               label="configs[2]: 640x480 L8 N1000 full front-end: YOLACT-R50 fp32 mask + ORB detect + gate + describe + match"),
     # BASELINE.json configs[4]: synthetic HD stream
     "c5": dict(width=1920, height=1080, n_features=4000, n_levels=12, default_batch=128, default_streams=4,
                label="configs[4]: 1920x1080 L12 N4000 extract+match"),
@@ -54,39 +72,15 @@ def algorithmic_bytes(level_w, level_h, n_kp, width, height):
         "blur": 2 * sum(wh),
         "describe": n_kp * (512 + 32),
         "match": 2 * n_kp * 32 + n_kp * 16,
-        "mask_net": 0,  # MFMA-bound convolutions on PyTorch: timed, not part of the HBM roofline
     }
 
 
-def cpu_baseline(synth, cfg, n_sample):
-    """The oracle (CPU restatement of src/ORBextractor.cc + ORBmatcher.cc, 1 thread) on a bounded
-    sample of the same workload.  Checker only: it is never the thing shipped or measured as GPU."""
-    import oracle_binding as ob
-    orc = ob.Oracle(n_features=cfg["n_features"], n_levels=cfg["n_levels"])
-    frames = [synth.frame(0, k, cfg["height"], cfg["width"]) for k in range(n_sample + 1)]
-    t0 = time.perf_counter()
-    prev = orc.extract(frames[0])[1]
-    for k in range(1, n_sample + 1):
-        _, desc = orc.extract(frames[k])
-        ob.bruteforce_best2(desc, prev)
-        prev = desc
-    dt = time.perf_counter() - t0
-    return {"value": round(n_sample / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n_sample} frames of the same synthetic stream: oracle extract + N x N best-2 match, 1 thread"}
-
-
-def _cpu_worker(job):
-    """One worker process of the all-cores CPU baseline: frames of its own synthetic stream."""
-    root, cfg, stream, n = job
-    sys.path.insert(0, root)
-    sys.path.insert(0, os.path.join(root, "tests"))
-    import importlib
-    import __graft_entry__ as entry
-    entry.load_package()
-    synth = importlib.import_module("amos_slam_amd.synth")
-    import oracle_binding as ob
+# --------------------------------------------------------------------------------------------- CPU baseline
+def _oracle_stream_run(ob, synth, cfg, stream, n, barrier=None):
     orc = ob.Oracle(n_features=cfg["n_features"], n_levels=cfg["n_levels"])
     frames = [synth.frame(stream, k, cfg["height"], cfg["width"]) for k in range(n + 1)]
+    if barrier is not None:
+        barrier.wait()
     t0 = time.perf_counter()
     prev = orc.extract(frames[0])[1]
     for k in range(1, n + 1):
@@ -96,43 +90,138 @@ def _cpu_worker(job):
     return time.perf_counter() - t0
 
 
+def cpu_baseline_one_thread(synth, cfg, n_sample):
+    """The oracle (CPU restatement of src/ORBextractor.cc + ORBmatcher.cc, 1 thread) on a bounded
+    sample of the same workload.  Checker only: it is never the thing shipped or measured as GPU."""
+    import oracle_binding as ob
+    dt = _oracle_stream_run(ob, synth, cfg, 0, n_sample)
+    return {"value": round(n_sample / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n_sample} frames of the same synthetic stream: oracle extract + N x N best-2 match, 1 thread"}
+
+
+def _cpu_worker(root, cfg, stream, n, barrier, q):
+    """One worker process of the all-cores CPU baseline: frames of its own synthetic stream."""
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import importlib
+    import __graft_entry__ as entry
+    entry.load_package()
+    synth = importlib.import_module("amos_slam_amd.synth")
+    import oracle_binding as ob
+    q.put(_oracle_stream_run(ob, synth, cfg, stream, n, barrier))
+
+
 def cpu_baseline_all_cores(cfg, workers, n_per_worker):
-    """The same oracle, one frame stream per process, `workers` processes (the GPU box grants 16 host
-    cores per GPU).  Extra information beside the contract's single-thread cpu_baseline."""
+    """The same oracle on `workers` processes, one frame stream per process, started together (the reference
+    extractor is single-threaded per frame, so all cores = one frame per core)."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
-    with ctx.Pool(workers) as pool:
-        t0 = time.perf_counter()
-        pool.map(_cpu_worker, [(ROOT, {k: cfg[k] for k in ("n_features", "n_levels", "height", "width")}, 100 + w, n_per_worker)
-                               for w in range(workers)])
-        dt = time.perf_counter() - t0  # includes process start-up and frame synthesis: a lower bound on fps
-    return {"value": round(workers * n_per_worker / dt, 2), "unit": "frames/s", "cores": workers, "kind": "port",
-            "sample": f"{workers} processes x {n_per_worker} frames (wall time incl. start-up)"}
+    barrier, q = ctx.Barrier(workers), ctx.Queue()
+    small = {k: cfg[k] for k in ("n_features", "n_levels", "height", "width")}
+    procs = [ctx.Process(target=_cpu_worker, args=(ROOT, small, 100 + w, n_per_worker, barrier, q)) for w in range(workers)]
+    for p in procs:
+        p.start()
+    times = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    wall = max(times)  # all workers leave the barrier together: the slowest one is the wall time
+    return {"value": round(workers * n_per_worker / wall, 2), "unit": "frames/s", "cores": workers, "kind": "port",
+            "sample": f"{workers} processes x {n_per_worker} frames of {workers} synthetic streams, started together; "
+                      f"oracle extract + N x N best-2 match per frame"}
+
+
+# --------------------------------------------------------------------------------------------- launcher
+def self_launch(args):
+    """--gpus N > 1 without a launcher environment: start torch.distributed.run as a CHILD process (this process
+    has not imported torch or touched a GPU) and pass its output and return code through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env)
+    if proc.returncode != 0:
+        print(f"bench.py: torch.distributed.run with {args.gpus} ranks exited with code {proc.returncode}", file=sys.stderr, flush=True)
+    return proc.returncode
+
+
+def dry_run(args):
+    """Launcher / collective rehearsal WITHOUT a GPU (tests/test_shard_gloo.py): every rank joins the gloo group,
+    pretends to step, and the three collectives of the real path run.  Prints a line with value null."""
+    import importlib
+    import __graft_entry__ as entry
+    entry.load_package()
+    shard = importlib.import_module("amos_slam_amd.shard")
+    rank, world = shard.init("gloo")
+    if os.environ.get("AMOS_BENCH_FAIL_RANK") == str(rank):  # test hook: a rank that dies must fail the whole run
+        os._exit(3)
+    shard.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    shard.barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, "cpu")
+    digest = shard.gather_digests([float(shard.stream_for_rank(rank)), float(zlib.crc32(bytes([rank] * 32))), 0.0], "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "dry_run": True, "digest_per_rank": digest}), flush=True)
+    shard.finalize()
+    return 0
+
+
+# --------------------------------------------------------------------------------------------- measurement
+def count_network_flops(torch, engine, batch):
+    """FLOPs (2 x multiply-accumulates) of ONE network forward per frame, counted from the shapes the convolutions
+    actually see (forward hooks), plus the prototype x coefficient product of the mask assembly."""
+    total = [0]
+
+    def hook(mod, inp, out):
+        k = mod.kernel_size[0] * mod.kernel_size[1] * (mod.in_channels // mod.groups)
+        total[0] += 2 * k * out.numel()
+
+    hooks = [m.register_forward_hook(hook) for m in engine.net.modules() if isinstance(m, torch.nn.Conv2d)]
+    with torch.no_grad():
+        engine._forward(torch.zeros((batch, 3, 550, 550), device=engine.device))
+    for h in hooks:
+        h.remove()
+    return total[0] / batch
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 512; 32 with the mask; 128 for c5)")
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
-    ap.add_argument("--streams", type=int, default=0, help="independent lanes (handle + HIP streams) the batch is split over (default 4; 2 with the mask)")
-    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU of the headline config (default 32 with the mask; 512 for c2; 128 for c5)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3", help="c3 = BASELINE configs[2] (default, the metric as written); c2 = configs[1]; c5 = configs[4]")
+    ap.add_argument("--streams", type=int, default=0, help="independent lanes (handle + HIP streams) the batch is split over")
+    ap.add_argument("--leg-steps", type=int, default=100, help="timed steps of the mask-off extract+match sub-leg of a c3 run (0 = skip the leg)")
+    ap.add_argument("--leg-batch", type=int, default=512, help="frames per step of that sub-leg (4 lanes)")
+    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the 1-thread CPU baseline sample (0 = skip the CPU baseline)")
+    ap.add_argument("--cpu-cores", type=int, default=-1, help="processes of the all-cores CPU baseline (default: min(granted cores, 16); 0 = skip)")
     ap.add_argument("--mask-conv-dtype", choices=["fp32", "fp16", "bf16"], default="fp32",
                     help="precision of the mask network's convolutions (c3 only; fp32 is the parity configuration)")
-    ap.add_argument("--check", action="store_true", help="verify one frame of the batch against the oracle")
-    ap.add_argument("--cpu-all-cores", type=int, default=0, help="also time the oracle on this many processes (0 = off)")
+    ap.add_argument("--mask-chunk", type=int, default=0, help="frames per network forward (default: frames per lane)")
+    ap.add_argument("--check", action="store_true", help="verify frames of the batch against the oracle")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / collective rehearsal without a GPU (value null)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        raise SystemExit(dry_run(args))
+
+    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # Rehearsal of the N > 1 path on a box with fewer GPUs than ranks (AMOS_DIST_BACKEND=gloo): ranks share the
     # visible devices and the three collectives run on CPU tensors.  The driver's runs use RCCL, one GPU per rank.
     backend = os.environ.get("AMOS_DIST_BACKEND", "nccl")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
     import torch
     import __graft_entry__ as entry
@@ -144,33 +233,55 @@ def main():
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
     shard.init(backend, torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
-    coll_dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
+    coll_dev = dev if backend == "nccl" else "cpu"
 
     cfg = CONFIGS[args.config]
-    if args.batch <= 0:
-        args.batch = cfg.get("default_batch", 256)
-    if args.streams <= 0:
-        args.streams = cfg.get("default_streams", 2)
-    W, H, B = cfg["width"], cfg["height"], args.batch
+    W, H = cfg["width"], cfg["height"]
     use_mask = bool(cfg.get("mask"))
-    frames_np = synth.frames(shard.stream_for_rank(rank), 0, B, H, W)  # one stream per GPU
-    d_frames = torch.from_numpy(frames_np).cuda(local_rank)
-
-    # The batch is split over S independent lanes (extractor + matcher handle, own HIP streams): kernels of
-    # one lane (e.g. the memory-bound pyramid) overlap kernels of the other (e.g. the VALU-bound FAST).
-    S = max(1, min(args.streams, B))
+    B = args.batch if args.batch > 0 else cfg["default_batch"]
+    S = args.streams if args.streams > 0 else cfg["default_streams"]
+    S = max(1, min(S, B))
     while B % S:
         S -= 1
     Bl = B // S  # frames per lane and step
+    # the mask-off sub-leg of a c3 run uses BASELINE configs[1]'s shape: leg_batch frames over 4 lanes
+    leg = use_mask and args.leg_steps > 0
+    legS = 4 if leg else 0
+    legB = (args.leg_batch // 4) * 4 if leg else 0
+    legBl = legB // 4 if leg else 0
+    n_lanes = max(S, legS)
+    lane_cap_frames = max(Bl, legBl)
 
+    # frames of this rank's stream, resident in HBM before any timed region
+    n_frames_dev = max(B, legB)
+    frames_np = synth.frames(shard.stream_for_rank(rank), 0, n_frames_dev, H, W)  # one stream per GPU
+    d_frames = torch.from_numpy(frames_np).to(dev)
+
+    # Lanes: extractor + matcher handle with their own HIP streams; kernels of one lane (e.g. the memory-bound
+    # pyramid) overlap kernels of another (e.g. the VALU-bound FAST).  Created FIRST: their streams' mapping onto
+    # the hardware queues depends on creation order.
     class Lane:
         pass
 
-    engine = None
+    lanes = []
+    for li in range(n_lanes):
+        ln = Lane()
+        ln.ext = pkg.OrbExtractor(n_features=cfg["n_features"], n_levels=cfg["n_levels"], max_width=W, max_height=H,
+                                  max_batch=lane_cap_frames, device=local_rank)
+        ln.matcher = pkg.OrbMatcher(device=local_rank, stream=ln.ext.stream)  # same stream: match follows extract
+        _, ln.d_desc, ln.d_counts, ln.cap = ln.ext.batch_results_device()
+        ln.stream = torch.cuda.ExternalStream(ln.ext.stream, device=local_rank)
+        ln.d_match = torch.full((lane_cap_frames, ln.cap, 4), 1 << 30, dtype=torch.int32, device=dev)
+        lanes.append(ln)
+    cap = lanes[0].cap
+
+    engine, net_flops = None, None
+    chunk = args.mask_chunk if args.mask_chunk > 0 else Bl
     if use_mask:
         mask_mod = importlib.import_module("amos_slam_amd.mask")
-        engine = mask_mod.MaskEngine(device=f"cuda:{local_rank}", seed=0,
+        engine = mask_mod.MaskEngine(device=dev, seed=0,
                                      conv_dtype={"fp32": None, "fp16": torch.float16, "bf16": torch.bfloat16}[args.mask_conv_dtype])
         with torch.no_grad():
             head = engine.net.prediction_layers[0].conf_layer.bias
@@ -178,111 +289,139 @@ def main():
             b[:, 1] += 5.0
             b[1, 3] += 5.5
             head.copy_(b.view(-1).to(head.device))
-    lanes = []
-    for li in range(S):
-        ln = Lane()
-        ln.ext = pkg.OrbExtractor(n_features=cfg["n_features"], n_levels=cfg["n_levels"], max_width=W, max_height=H,
-                                  max_batch=Bl, device=local_rank)
-        ln.matcher = pkg.OrbMatcher(device=local_rank, stream=ln.ext.stream)  # same stream: match follows extract
-        _, ln.d_desc, ln.d_counts, ln.cap = ln.ext.batch_results_device()
-        ln.frames = d_frames[li * Bl:(li + 1) * Bl]
-        ln.pairs_q = torch.arange(Bl, dtype=torch.int32, device=f"cuda:{local_rank}")
-        ln.pairs_t = (ln.pairs_q - 1) % Bl  # frame k against frame k-1 (the lane's first frame against its last)
-        ln.d_match = torch.full((Bl, ln.cap, 4), 1 << 30, dtype=torch.int32, device=f"cuda:{local_rank}")
-        ln.stream = torch.cuda.ExternalStream(ln.ext.stream, device=local_rank)
-        ln.bgr = ln.frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous() if use_mask else None  # gray as BGR, in HBM
-        lanes.append(ln)
-    ext, cap = lanes[0].ext, lanes[0].cap
-    torch.cuda.synchronize()
-    match_events, mask_events = [], []
+        engine.prepare()  # fold the batch norms into the convolutions (inference form)
+        net_flops = count_network_flops(torch, engine, min(chunk, 4))
 
-    def step(timed):
-        for li, ln in enumerate(lanes):
-            rec = timed and li == 0  # per-kernel events on lane 0 only
-            if use_mask:
-                ln.ext.detect_batch_device(ln.frames.data_ptr(), H * W, W, W, H, Bl)
-                with torch.cuda.stream(ln.stream):  # the network runs on the lane's stream: ordering is implicit
-                    if rec:
-                        m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        m0.record(ln.stream)
-                    ln.masks = engine.eval_bgr_batch(ln.bgr)  # kept alive until the stream has consumed it
-                    if rec:
-                        m1.record(ln.stream)
-                        mask_events.append((m0, m1))
-                    ln.ext.gate_batch_device(ln.masks.data_ptr(), H * W, W)
-                    ln.ext.describe_batch_device()
-            else:
-                ln.ext.extract_batch_device(ln.frames.data_ptr(), H * W, W, W, H, Bl)
-            if rec:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(ln.stream)
-            ln.matcher.bruteforce_best2_batch_device(ln.d_desc, ln.cap * 32, ln.d_counts, ln.pairs_q.data_ptr(), ln.pairs_t.data_ptr(),
-                                                     Bl, ln.cap, 256, ln.d_match.data_ptr())
-            if rec:
-                e1.record(ln.stream)
-                match_events.append((e0, e1))
+    def assign(nl, bl):
+        """frames [li * bl, (li + 1) * bl) of the resident stream -> lane li"""
+        for li in range(nl):
+            ln = lanes[li]
+            ln.frames = d_frames[li * bl:(li + 1) * bl]
+            ln.pairs_q = torch.arange(bl, dtype=torch.int32, device=dev)
+            ln.pairs_t = (ln.pairs_q - 1) % bl  # frame k against frame k-1 (the lane's first frame against its last)
+            ln.bgr = None
+        return lanes[:nl]
 
-    def barrier():
-        for ln in lanes:
-            ln.ext.sync()
-        torch.cuda.synchronize()
-        shard.barrier()
-        torch.cuda.synchronize()
+    def run_leg(active, bl, masked, steps, warmup, alone=False):
+        """warmup untimed steps, then exactly `steps` timed steps between barriers; returns (seconds, stage_ms)."""
+        match_events, mask_events = [], []
+        if masked:
+            for ln in active:
+                if ln.bgr is None:
+                    ln.bgr = ln.frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()  # gray as BGR, in HBM
 
-    for _ in range(args.warmup):
-        step(False)
-    ext.timing_enable(args.steps)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, coll_dev)
+        def step(timed):
+            for li, ln in enumerate(active):
+                rec = timed and li == 0  # per-kernel events on lane 0 only
+                if masked:
+                    ln.ext.detect_batch_device(ln.frames.data_ptr(), H * W, W, W, H, bl)
+                    with torch.cuda.stream(ln.stream):  # the network runs on the lane's stream: ordering is implicit
+                        if rec:
+                            m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            m0.record(ln.stream)
+                        ln.masks = engine.eval_bgr_batch(ln.bgr, chunk=chunk)  # kept alive until the stream has consumed it
+                        if rec:
+                            m1.record(ln.stream)
+                            mask_events.append((m0, m1))
+                        ln.ext.gate_batch_device(ln.masks.data_ptr(), H * W, W)
+                        ln.ext.describe_batch_device()
+                else:
+                    ln.ext.extract_batch_device(ln.frames.data_ptr(), H * W, W, W, H, bl)
+                if rec:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(ln.stream)
+                ln.matcher.bruteforce_best2_batch_device(ln.d_desc, ln.cap * 32, ln.d_counts, ln.pairs_q.data_ptr(), ln.pairs_t.data_ptr(),
+                                                         bl, ln.cap, 256, ln.d_match.data_ptr())
+                if rec:
+                    e1.record(ln.stream)
+                    match_events.append((e0, e1))
 
-    stage_ms, n_rec = ext.timing_collect()
-    stage_ms["match"] = float(np.mean([a.elapsed_time(b) for a, b in match_events])) if match_events else 0.0
-    if mask_events:
-        stage_ms["mask_net"] = float(np.mean([a.elapsed_time(b) for a, b in mask_events]))
-    # The same per-launch times with lane 0 ALONE on the chip (after the timed region; the other lanes idle): what
-    # one launch of each kernel costs when it does not share the CUs with three other lanes' kernels.
-    alone_ms = None
-    if S > 1 and not use_mask:
+        def barrier():
+            for ln in lanes:
+                ln.ext.sync()
+            torch.cuda.synchronize()
+            if not alone:
+                shard.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(warmup):
+            step(False)
+        active[0].ext.timing_enable(steps)
         barrier()
-        ext.timing_enable(4)
-        ev_alone = []
-        for _ in range(4):
-            ln = lanes[0]
-            ln.ext.extract_batch_device(ln.frames.data_ptr(), H * W, W, W, H, Bl)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(ln.stream)
-            ln.matcher.bruteforce_best2_batch_device(ln.d_desc, ln.cap * 32, ln.d_counts, ln.pairs_q.data_ptr(), ln.pairs_t.data_ptr(),
-                                                     Bl, ln.cap, 256, ln.d_match.data_ptr())
-            e1.record(ln.stream)
-            ev_alone.append((e0, e1))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
         barrier()
-        alone_ms, _ = ext.timing_collect()
-        alone_ms["match"] = float(np.mean([a.elapsed_time(b) for a, b in ev_alone]))
-    # result digest: keypoint counts + number of matches within TH_LOW (final gather over RCCL)
-    n_kp = [len(ext.batch_fetch(f)[0]) for f in range(min(Bl, 8))]
+        elapsed = time.perf_counter() - t0
+        if not alone:
+            elapsed = shard.max_over_ranks(elapsed, coll_dev)
+        stage_ms, _ = active[0].ext.timing_collect()
+        active[0].ext.timing_enable(0)
+        stage_ms["match"] = float(np.mean([a.elapsed_time(b) for a, b in match_events])) if match_events else 0.0
+        if mask_events:
+            stage_ms["mask_pass"] = float(np.mean([a.elapsed_time(b) for a, b in mask_events]))
+        return elapsed, stage_ms
+
+    def frame_digest(ln, bl, n=8):
+        """per-frame (keypoints, CRC32 of the descriptor bytes, matches within TH_LOW) of the lane's first frames"""
+        rows = []
+        dm = ln.d_match[:bl].cpu().numpy()
+        for f in range(min(bl, n)):
+            kps, desc = ln.ext.batch_fetch(f)
+            rows += [float(len(kps)), float(zlib.crc32(desc.tobytes())), float(int((dm[f, :len(kps), 1] <= 50).sum()))]
+        return rows
+
+    # ---------------------------------------------------------------- headline leg
+    active = assign(S, Bl)
+    elapsed, stage_ms = run_leg(active, Bl, use_mask, args.steps, args.warmup)
+    fps = world * B * args.steps / elapsed
+    digest = frame_digest(lanes[0], Bl)
+    n_kp = digest[0::3]
     mean_kp = float(np.mean(n_kp))
-    good = int(sum(int((ln.d_match[:, :, 1] <= 50).sum().item()) for ln in lanes))
-    # the one collective of the path: final gather of the per-rank digests
-    digest_all = shard.gather_digests([float(sum(n_kp)), float(good)], coll_dev)
+    digest_all = shard.gather_digests(digest, coll_dev)  # the one collective of the path
+
+    checked = None
+    if args.check and rank == 0:
+        import oracle_binding as ob
+        orc = ob.Oracle(n_features=cfg["n_features"], n_levels=cfg["n_levels"])
+        checked = 0
+        for li, f in ((0, 0), (S - 1, Bl - 1)):
+            kg, dg = lanes[li].ext.batch_fetch(f)
+            frame = frames_np[li * Bl + f]
+            if use_mask:
+                orc.detect(frame)
+                orc.gate(lanes[li].masks[f].cpu().numpy())
+                ko, do = orc.describe()
+            else:
+                ko, do = orc.extract(frame)
+            assert kg.tobytes() == ko.tobytes() and dg.tobytes() == do.tobytes(), f"lane {li} frame {f} differs from the oracle"
+            checked += 1
+
+    # ---------------------------------------------------------------- mask-off extract+match leg (c3 runs) or the same leg's extras
+    em = None  # dict describing the extract+match measurement the roofline refers to
+    if use_mask and leg:
+        em_active = assign(legS, legBl)
+        em_elapsed, em_stage = run_leg(em_active, legBl, False, args.leg_steps, 3)
+        em = dict(S=legS, Bl=legBl, B=legB, steps=args.leg_steps, elapsed=em_elapsed, stage_ms=em_stage,
+                  fps=world * legB * args.leg_steps / em_elapsed, mean_kp=float(np.mean(frame_digest(lanes[0], legBl)[0::3])))
+    elif not use_mask:
+        em = dict(S=S, Bl=Bl, B=B, steps=args.steps, elapsed=elapsed, stage_ms=stage_ms, fps=fps, mean_kp=mean_kp)
+    alone_ms = None
+    if em and em["S"] > 1:
+        # the same per-launch times with lane 0 ALONE on the chip (the other lanes idle)
+        _, alone_ms = run_leg(lanes[:1], em["Bl"], False, 4, 0, alone=True)
 
     # SURVEY 8d match workload (ii): window-gated search (SearchByProjection radius 15 * scale, levels
     # octave-1..octave+1) of frame k's keypoints in frame k-1, everything resident: grid cells, CSR grid,
-    # window best-2.  Measured after the timed region on lane 0; not part of `value`.
+    # window best-2.  Measured after the timed regions on lane 0; not part of `value`.
     gated = None
-    if not use_mask:
-        ln = lanes[0]
-        dev = f"cuda:{local_rank}"
+    if em:
+        ln, bl = lanes[0], em["Bl"]
         d_kps = ln.ext.batch_results_device()[0]
-        d_cell = torch.zeros((Bl, ln.cap), dtype=torch.int32, device=dev)
-        d_start = torch.zeros((Bl, 64 * 48 + 1), dtype=torch.int32, device=dev)
-        d_items = torch.zeros((Bl, ln.cap), dtype=torch.int32, device=dev)
-        d_win = torch.zeros((Bl, ln.cap, 4), dtype=torch.int32, device=dev)
+        d_cell = torch.zeros((bl, ln.cap), dtype=torch.int32, device=dev)
+        d_start = torch.zeros((bl, 64 * 48 + 1), dtype=torch.int32, device=dev)
+        d_items = torch.zeros((bl, ln.cap), dtype=torch.int32, device=dev)
+        d_win = torch.zeros((bl, ln.cap, 4), dtype=torch.int32, device=dev)
         bounds = (0.0, float(W), 0.0, float(H))
         sf = ln.ext.tables()["scale"]
         torch.cuda.synchronize()
@@ -293,10 +432,10 @@ def main():
                 ev[0].record(ln.stream)
                 ln.ext.rgbd_glue_batch_device(None, False, 1.0, 0, 0, 0.0, bounds, None, None, d_cell.data_ptr())
                 ev[1].record(ln.stream)
-                ln.matcher.grid_build_batch_device(d_cell.data_ptr(), ln.d_counts, Bl, ln.cap, d_start.data_ptr(), d_items.data_ptr())
+                ln.matcher.grid_build_batch_device(d_cell.data_ptr(), ln.d_counts, bl, ln.cap, d_start.data_ptr(), d_items.data_ptr())
                 ev[2].record(ln.stream)
                 ln.matcher.window_best2_batch_device(d_kps, ln.d_desc, ln.d_counts, d_start.data_ptr(), d_items.data_ptr(),
-                                                     ln.pairs_q.data_ptr(), ln.pairs_t.data_ptr(), Bl, ln.cap, sf, 15.0, d_win.data_ptr(),
+                                                     ln.pairs_q.data_ptr(), ln.pairs_t.data_ptr(), bl, ln.cap, sf, 15.0, d_win.data_ptr(),
                                                      mode=0, bounds=bounds)
                 ev[3].record(ln.stream)
             if it > 0:
@@ -304,45 +443,15 @@ def main():
         ln.ext.sync()
         torch.cuda.synchronize()
         g_ms = [float(np.mean([e[k].elapsed_time(e[k + 1]) for e in evs])) for k in range(3)]
-        nq = mean_kp * Bl
         gated = {"workload": "frame k keypoints searched in frame k-1: window 15*scale, levels octave-1..octave+1, best-2",
-                 "frames_per_launch": Bl, "grid_cells_ms": round(g_ms[0], 4), "grid_build_ms": round(g_ms[1], 4),
-                 "window_best2_ms": round(g_ms[2], 4), "queries_per_s": round(nq / (sum(g_ms) * 1e-3), 1),
+                 "frames_per_launch": bl, "grid_cells_ms": round(g_ms[0], 4), "grid_build_ms": round(g_ms[1], 4),
+                 "window_best2_ms": round(g_ms[2], 4), "queries_per_s": round(em["mean_kp"] * bl / (sum(g_ms) * 1e-3), 1),
                  "matched_within_TH_HIGH": int((d_win[:, :, 1] <= 100).sum().item())}
 
-    if args.check and rank == 0:
-        import oracle_binding as ob
-        orc = ob.Oracle(n_features=cfg["n_features"], n_levels=cfg["n_levels"])
-        for li, f in ((0, 0), (S - 1, Bl - 1)):
-            kg, dg = lanes[li].ext.batch_fetch(f)
-            ko, do = orc.extract(frames_np[li * Bl + f])
-            assert kg.tobytes() == ko.tobytes() and dg.tobytes() == do.tobytes(), f"frame {f} differs from the oracle"
-
     if rank == 0:
-        lw, lh = ext.level_sizes(W, H)
-        alg = algorithmic_bytes(lw, lh, mean_kp, W, H)
-        total_alg = sum(alg.values())
-        # the dominant KERNEL: largest total time per pass; "pyramid" is n_levels - 1 launches of one kernel,
-        # so its per-launch figures are the averages over those launches (what rocprofv3 --stats reports)
-        launches = {k: 1 for k in stage_ms}
-        launches["pyramid"] = cfg["n_levels"] - 1
-        dominant = max((k for k in stage_ms if k != "mask_net"), key=lambda k: stage_ms[k])
-        dom_bytes = alg[dominant] * Bl / launches[dominant]  # algorithmic bytes of one (average) launch
-        dom_ms = stage_ms[dominant] / launches[dominant]
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                ent = tj.get(args.config, {}).get(dominant)
-                if ent and ent.get("batch") == Bl:
-                    traffic = ent["hbm_bytes_per_launch"] / launches[dominant]
-            except Exception:
-                traffic = None
-        fps = world * B * args.steps / elapsed
+        lw, lh = lanes[0].ext.level_sizes(W, H)
         out = {
-            "metric": "front-end frames/sec (ORB extract+match%s) at %dx%d" % ("+mask" if use_mask else ", mask off", W, H),
+            "metric": METRIC if use_mask else "front-end frames/sec (ORB extract+match, mask off) at %dx%d" % (W, H),
             "value": round(fps, 1),
             "unit": "frames/s",
             "n_gpus": world,
@@ -352,41 +461,97 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8" if not use_mask else "u8 (ORB, matcher) + %s (mask network)" % args.mask_conv_dtype,
+            "dtype": "u8" if not use_mask else "u8 (ORB, gate, matcher) + %s (mask network)" % args.mask_conv_dtype,
             "data": "synthetic",
             "config": {"workload": cfg["label"], "frames_per_step_per_gpu": B, "lanes_per_gpu": S, "frames_per_launch": Bl, "width": W, "height": H,
                        "n_features": cfg["n_features"], "n_levels": cfg["n_levels"], "ini_th_fast": 20, "min_th_fast": 7,
                        "mean_keypoints_per_frame": round(mean_kp, 1), "match": "frame k vs k-1, N x N best-2",
+                       "frames": "resident in HBM before the timed region (offline replay: %.0f MB/s of frames, no host link in the figure)" % (fps / world * W * H / 1e6),
                        "synthetic_stream_seed": "stream = rank, frame k seeded 1000*rank+k (amos-slam_amd/synth.py)",
                        "parallelism": f"frames sharded {world} ways, one process per GPU, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
-                         "launches_per_pass": launches[dominant]},
-            "pipeline_roofline": {"algorithmic_bytes_per_frame": int(total_alg),
-                                  "achieved_GBs": round(total_alg * fps / world / 1e9, 2),
-                                  "frac": round(total_alg * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
-            "stage_frac_of_hbm_peak": {k: (round(alg[k] * Bl / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if v > 0 else None)
-                                       for k, v in stage_ms.items()},
-            "digest_per_rank": digest_all,
-            "stage_ms_per_launch_lane_alone": ({k: round(v, 4) for k, v in alone_ms.items()} if alone_ms else None),
-            "roofline_lane_alone": ({"kernel": dominant, "note": "same launch, measured after the timed region with the other lanes idle",
-                                     "avg_launch_ms": round(alone_ms[dominant] / launches[dominant], 4),
-                                     "achieved": round(dom_bytes / (alone_ms[dominant] / launches[dominant] * 1e-3) / 1e9, 2),
-                                     "frac": round(dom_bytes / (alone_ms[dominant] / launches[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-                                    if alone_ms and alone_ms.get(dominant, 0) > 0 else None),
-            # Hamming throughput of the N x N match as N_q * N_t * 256 bit comparisons per second
-            "hamming_bitops_per_s": round(fps * mean_kp * mean_kp * 256.0, 1),
+            "digest_per_rank": {"layout": "per frame of the rank's first lane: keypoints, CRC32 of descriptor bytes, matches <= TH_LOW", "rows": digest_all},
         }
+        if checked is not None:
+            out["oracle_checked_frames"] = checked
+        if use_mask:
+            out["config"]["mask"] = {"network": "YOLACT-R50-FPN 550x550, %s, batch-norm folded, NHWC, random weights (no checkpoint offline)" % args.mask_conv_dtype,
+                                     "frames_per_forward": chunk}
+            n_fwd = (Bl + chunk - 1) // chunk
+            net_ms = stage_ms.get("mask_pass", 0.0)
+            tf = net_flops * Bl / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
+            out["roofline_mask"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                    "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_frame": int(net_flops),
+                                    "ms_per_pass": round(net_ms, 3), "frames_per_pass": Bl, "forwards_per_pass": n_fwd,
+                                    "note": "whole mask pass of one lane (pre-processing, network, detection, mask assembly) timed with events on the "
+                                            "lane's stream inside the timed region, other lanes running; convolution FLOPs only in the numerator"}
+        if em:
+            st = em["stage_ms"]
+            alg = algorithmic_bytes(lw, lh, em["mean_kp"], W, H)
+            total_alg = sum(alg.values())
+            # the dominant KERNEL: largest total time per pass; "pyramid" is the resize launches of one pass,
+            # so its per-launch figures are the averages over those launches (what rocprofv3 --stats reports)
+            launches = {k: 1 for k in st}
+            launches["pyramid"] = lanes[0].ext.pyramid_launches()
+            dominant = max((k for k in st if k in alg), key=lambda k: st[k])
+            dom_bytes = alg[dominant] * em["Bl"] / launches[dominant]  # algorithmic bytes of one (average) launch
+            dom_ms = st[dominant] / launches[dominant]
+            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    ent = tj.get("c2" if W == 640 else args.config, {}).get(dominant)
+                    if ent and ent.get("batch") == em["Bl"]:
+                        traffic = ent["hbm_bytes_per_launch"] / launches[dominant]
+                        traffic_src = tj.get("source", "profiles/traffic.json") + " (PMC pass of an earlier run of this command, not this run)"
+                except Exception:
+                    traffic = None
+            em_fps = em["fps"]
+            out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                               "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
+                               "launches_per_pass": launches[dominant],
+                               "measured_in": "extract_match_leg timed region (HIP events on lane 0's streams)" if use_mask else "the timed region (HIP events on lane 0's streams)"}
+            pipeline = {"algorithmic_bytes_per_frame": int(total_alg), "achieved_GBs": round(total_alg * em_fps / world / 1e9, 2),
+                        "frac": round(total_alg * em_fps / world / 1e9 / HBM_PEAK_GBS, 5)}
+            stage_frac = {k: (round(alg[k] * em["Bl"] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if v > 0 and k in alg else None) for k, v in st.items()}
+            alone = None
+            if alone_ms and alone_ms.get(dominant, 0) > 0:
+                a_ms = alone_ms[dominant] / launches[dominant]
+                alone = {"kernel": dominant, "note": "same launch, measured after the timed region with the other lanes idle",
+                         "avg_launch_ms": round(a_ms, 4), "achieved": round(dom_bytes / (a_ms * 1e-3) / 1e9, 2),
+                         "frac": round(dom_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            leg_obj = {"metric": "front-end frames/sec (ORB extract+match, mask off) at %dx%d" % (W, H), "value": round(em_fps, 1), "unit": "frames/s",
+                       "workload": CONFIGS["c2"]["label"] if W == 640 else cfg["label"], "steps": em["steps"],
+                       "ms_per_step": round(em["elapsed"] / em["steps"] * 1e3, 4), "frames_per_step_per_gpu": em["B"], "lanes_per_gpu": em["S"],
+                       "frames_per_launch": em["Bl"], "mean_keypoints_per_frame": round(em["mean_kp"], 1), "pipeline_roofline": pipeline,
+                       "stage_ms_per_launch": {k: round(v, 4) for k, v in st.items()}, "stage_frac_of_hbm_peak": stage_frac,
+                       "stage_ms_per_launch_lane_alone": ({k: round(v, 4) for k, v in alone_ms.items()} if alone_ms else None),
+                       "roofline_lane_alone": alone,
+                       # Hamming throughput of the N x N match as N_q * N_t * 256 bit comparisons per second
+                       "hamming_bitops_per_s": round(em_fps * em["mean_kp"] * em["mean_kp"] * 256.0, 1)}
+            if use_mask:
+                out["extract_match_leg"] = leg_obj
+            else:
+                out.update({k: v for k, v in leg_obj.items() if k not in ("metric", "value", "unit", "steps", "ms_per_step", "workload")})
+            out["pipeline_roofline"] = pipeline
         if gated:
             out["gated_match"] = gated
-        n_cpu = args.cpu_frames if args.cpu_frames >= 0 else (100 if args.config == "c2" else 12)
+        n_cpu = args.cpu_frames if args.cpu_frames >= 0 else (100 if W == 640 else 12)
         if world == 1 and n_cpu > 0:
-            out["cpu_baseline"] = cpu_baseline(synth, cfg, n_cpu)
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-            if args.cpu_all_cores > 0:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, args.cpu_all_cores, 24 if args.config != "c5" else 3)
+            granted = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = args.cpu_cores if args.cpu_cores >= 0 else min(granted, 16)
+            one = cpu_baseline_one_thread(synth, cfg, n_cpu)
+            if cores > 1:
+                out["cpu_baseline"] = cpu_baseline_all_cores(cfg, cores, 24 if W == 640 else 3)
+                out["cpu_baseline"]["single_thread"] = one
+            else:
+                out["cpu_baseline"] = one
+            out["cpu_baseline"]["host_cores_visible"] = os.cpu_count()
+            out["cpu_baseline"]["host_cores_granted"] = granted
+            out["cpu_baseline"]["workload"] = "ORB extract + N x N best-2 match (the reference's CPU path, src/ORBextractor.cc + ORBmatcher.cc; its mask network runs on a GPU in the reference too)"
         print(json.dumps(out), flush=True)
 
     shard.finalize()
@@ -398,6 +563,11 @@ if __name__ == "__main__":
     except BaseException as exc:  # a failed rank must not sit in the process group's teardown
         if isinstance(exc, SystemExit) and exc.code in (0, None):
             raise
+        if isinstance(exc, SystemExit) and isinstance(exc.code, int):
+            raise
+        if isinstance(exc, SystemExit):
+            print(exc.code, file=sys.stderr, flush=True)
+            os._exit(2)
         import traceback
         traceback.print_exc()
         sys.stderr.flush()

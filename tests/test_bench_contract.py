@@ -9,25 +9,58 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.gpu
-def test_bench_prints_one_contract_line(gpu_lib):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--batch", "64",
-                          "--cpu-frames", "3", "--check"], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
+def _run(args):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def _common(d, steps, warmup):
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                  ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
                  ("cpu_baseline", dict)):
         assert isinstance(d[k], t), (k, d[k])
-    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "u8" and d["data"] == "synthetic" and d["unit"] == "frames/s"
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "frames/s"
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - 64 * 4 / (d["ms_per_step"] * 4 * 1e-3)) / d["value"] < 0.01      # value = frames / time
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and ("traffic" in r)
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 0.02
     c = d["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
+    assert c["kind"] in ("port", "reference") and c["cores"] == 2 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
+    assert c["single_thread"]["cores"] == 1 and c["single_thread"]["value"] > 0
     assert d["pipeline_roofline"]["frac"] > 0 and d["gated_match"]["queries_per_s"] > 0
+    rows = d["digest_per_rank"]["rows"]
+    assert len(rows) == 1 and len(rows[0]) % 3 == 0 and rows[0][0] > 100  # (keypoints, descriptor CRC32, matches) per frame
+    assert d["oracle_checked_frames"] == 2
+
+
+@pytest.mark.gpu
+def test_default_run_is_the_baseline_metric_with_the_mask(gpu_lib):
+    """`python bench.py --gpus 1` times BASELINE.json configs[2] (mask on) and carries the mask-off leg beside it."""
+    d = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8", "--leg-steps", "3", "--leg-batch", "64", "--cpu-frames", "3",
+              "--cpu-cores", "2", "--check"])
+    _common(d, 2, 1)
+    assert "+mask" in d["metric"] and "configs[2]" in d["config"]["workload"]
+    assert "fp32" in d["dtype"]
+    assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 0.01      # value = frames / time
+    leg = d["extract_match_leg"]
+    assert "mask off" in leg["metric"] and leg["value"] > d["value"] and leg["frames_per_step_per_gpu"] == 64 and leg["steps"] == 3
+    assert abs(leg["value"] - 64 * 3 / (leg["ms_per_step"] * 3 * 1e-3)) / leg["value"] < 0.01
+    m = d["roofline_mask"]
+    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and m["peak"] == 157.3 and 0 < m["frac"] < 1
+    assert 5e10 < m["flops_per_frame"] < 2e11  # YOLACT-R50 at 550 x 550
+    assert d["stage_ms_per_launch"]["mask_pass"] > 0
+
+
+@pytest.mark.gpu
+def test_mask_off_config(gpu_lib):
+    d = _run(["--gpus", "1", "--config", "c2", "--steps", "4", "--warmup", "1", "--batch", "64", "--cpu-frames", "3", "--cpu-cores", "2", "--check"])
+    _common(d, 4, 1)
+    assert "mask off" in d["metric"] and d["dtype"] == "u8" and "configs[1]" in d["config"]["workload"]
+    assert abs(d["value"] - 64 * 4 / (d["ms_per_step"] * 4 * 1e-3)) / d["value"] < 0.01
+    assert "extract_match_leg" not in d and d["stage_ms_per_launch"]["fast"] > 0

@@ -40,8 +40,10 @@ def _sub(t):
     return t.detach().float().cpu().reshape(-1)[::SUB].numpy()
 
 
-def _run(mask, device, rtol, atol):
+def _run(mask, device, rtol, atol, fold=False):
     eng = _engine(mask, device)
+    if fold:
+        eng.prepare()
     frame = torch.from_numpy(_frame()).to(device)
     chw = mask.cxx_marshalling(frame)
     img = mask.resize_f32_cv(chw.permute(1, 2, 0) * 255, 640, 480)
@@ -118,6 +120,39 @@ def test_network_vs_reference_cpu(mask):
     assert _run(mask, "cpu", 2e-4, 2e-5) >= 1 - 1e-3
 
 
+def test_network_with_folded_batch_norms_vs_reference_cpu(mask):
+    """MaskEngine.prepare(): the inference form bench.py and the C++ class run."""
+    assert _run(mask, "cpu", 2e-4, 2e-5, fold=True) >= 1 - 1e-3
+
+
+def test_folding_batch_norms_with_nontrivial_statistics(mask):
+    """Freshly initialised batch norms are almost the identity; give them statistics a trained checkpoint has and
+    compare the folded network with the unfolded one on the same input."""
+    eng = _engine(mask, "cpu")
+    torch.manual_seed(3)
+    n_bn = 0
+    for m in eng.net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+            n_bn += 1
+    assert n_bn == 53
+    x = torch.randn(1, 3, 550, 550)
+    with torch.no_grad():
+        a = eng.net(x)
+        eng.prepare()
+        assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in eng.net.modules())
+        b = eng.net(x)
+        eng.prepare()  # idempotent
+        c = eng.net(x)
+    for k in ("loc", "conf", "mask", "proto"):
+        scale = float(a[k].abs().max())
+        assert float((a[k] - b[k]).abs().max()) <= 2e-5 * max(scale, 1e-3), k
+        assert torch.equal(b[k], c[k])
+
+
 def test_batch_path_equals_single(mask):
     eng = _engine(mask, "cpu")
     f0 = _frame()
@@ -159,6 +194,11 @@ def test_no_detection_returns_none(mask):
 @pytest.mark.gpu
 def test_network_vs_reference_gpu(mask, gpu_lib):
     assert _run(mask, "cuda:0", 5e-3, 5e-3) >= 1 - 1e-3
+
+
+@pytest.mark.gpu
+def test_network_with_folded_batch_norms_vs_reference_gpu(mask, gpu_lib):
+    assert _run(mask, "cuda:0", 5e-3, 5e-3, fold=True) >= 1 - 1e-3
 
 
 @pytest.mark.gpu

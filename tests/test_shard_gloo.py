@@ -57,6 +57,41 @@ def test_two_rank_shard_and_gather(ob, synth):
     assert expect[0][1] != expect[1][1] or expect[0][0] != expect[1][0]
 
 
+def _bench(args, extra_env=None, timeout=300):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, lines
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment spawns torch.distributed.run itself (before torch or a
+    GPU is touched) and relays rank 0's single JSON line; --dry-run swaps the GPU work for a sleep so that the
+    launcher, the barrier, the max-over-ranks time and the digest gather run here on two gloo ranks."""
+    out, lines = _bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["dry_run"] is True and d["value"] is None
+    assert len(d["digest_per_rank"]) == 2 and d["digest_per_rank"][0] != d["digest_per_rank"][1]
+    assert [row[0] for row in d["digest_per_rank"]] == [0.0, 1.0]  # stream r on rank r, gathered in rank order
+    assert d["ms_per_step"] >= 2.0  # the slowest rank (2 ms per step) sets the time
+
+
+def test_bench_reports_a_failed_rank():
+    out, lines = _bench(["--gpus", "2", "--dry-run", "--steps", "2"], {"AMOS_BENCH_FAIL_RANK": "1"})
+    assert out.returncode != 0 and not lines
+    assert "exited with code" in out.stderr
+
+
+def test_bench_rejects_a_mismatched_launcher_environment():
+    out, lines = _bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert out.returncode != 0 and not lines
+
+
 def test_single_process_helpers(pkg):
     import importlib
     shard = importlib.import_module("amos_slam_amd.shard")
