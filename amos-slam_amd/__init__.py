@@ -31,7 +31,7 @@ EXPORTS = [
     "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
-    "amos_match_bruteforce_best2_batch_device", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
+    "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
     "amos_slic_run", "amos_slic_batch_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device",
 ]
 
@@ -458,6 +458,11 @@ class OrbMatcher:
         _check(self.L.amos_match_bruteforce_best2(self.m, _p(q), C.c_int(len(q)), _p(t), C.c_int(len(t)),
                                                   C.c_int(init_dist), _p(out)), "amos_match_bruteforce_best2")
         return out
+
+    def set_bruteforce_kernel(self, mode):
+        """0 = by size, 1 = xor + popcount kernel, 2 = i8 MFMA kernel (identical results)."""
+        _check(self.L.amos_match_set_bruteforce_kernel(self.m, C.c_int({"auto": 0, "popcount": 1, "mfma": 2}.get(mode, mode))),
+               "amos_match_set_bruteforce_kernel")
 
     def bruteforce_best2_batch_device(self, d_desc, frame_stride_bytes, d_counts, d_pairs_q, d_pairs_t, n_pairs,
                                       capacity, init_dist, d_out):

@@ -8,6 +8,7 @@
 #include "amos_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace amos {
@@ -359,6 +360,223 @@ __global__ __launch_bounds__(256) void k_bf_best2(const uint8_t *__restrict__ de
     }
 }
 
+// ---- the same reduction on the matrix cores (exact integer arithmetic).
+// For bit vectors  ham(q, t) = |q| + sum_k t_k * (1 - 2 q_k):  with the train bits as 0/1 bytes and the query bits
+// as -+1 bytes (set bit = -1) the sum is an i8 GEMM over K = 256 (v_mfma_i32_32x32x32_i8, i32 accumulate) and |q|
+// is a per-query constant, so the ORDER of the candidates of one query is the order of acc = sum and the key
+//     ((512 + acc) << 16) | train index
+// min-reduces exactly like (dist << 16 | index) of the popcount kernel (first candidate wins ties).  Against
+// k_bf_best2's 18.5 vector instructions per 64 pairs (16 of them xor + popcount) this needs about 4: 2 per
+// operand dword to spread bits into bytes ((x >> r) & 0x01010101, amortised over the four query tiles of a wave),
+// 1 per pair for the key (v_lshl_add_u32 on the accumulator) and 1.5 per pair for the running best two.
+//
+// Layout: block = 128 queries x 4 waves; a wave holds the B operand (queries, +-1) of four 32-query tiles in
+// registers for its whole life (128 VGPRs) and walks the train tiles wave, wave + 4, ...; per tile 32 MFMAs
+// (4 query tiles x K = 256 in 8 steps).  The k index is permuted the same way on both operands (lane half h owns
+// descriptor dwords 4h .. 4h + 3; register r of a step holds bits r, r + 8, r + 16, r + 24 of a dword), which a
+// dot product does not see.  C/D: lane = query column, the 16 accumulators = train rows
+// (i & 3) + 8 (i >> 2) + 4 h  (ascending in i: ascending train index).
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// kWaves = waves per block = ways the train tiles of one 128-query block are split (tile = wave, wave + kWaves, ...).
+// One wave per block amortises the query-side setup over every train tile (batched launches: enough blocks to fill
+// the chip anyway); four waves shorten the critical path of a single pair.
+//
+// The wave's loop is software-pipelined in half tiles so that the matrix cores and the vector units work at the same
+// time (two co-resident waves running the same phases in step do not overlap): while the 16 MFMAs of query tiles
+// 2, 3 run, the best-two update of tiles 0, 1 and the bit spreading of the NEXT train tile issue between them, then
+// the 16 MFMAs of tiles 0, 1 of the next train tile run over the update of tiles 2, 3.
+template <bool kGate, int kWaves>
+__global__ __launch_bounds__(64 * kWaves) void k_bf_best2_mfma(const uint8_t *__restrict__ descBaseQ, const uint8_t *__restrict__ descBaseT,
+                                                             size_t frameStrideBytes, const int *__restrict__ counts,
+                                                             const int *__restrict__ pairsQ, const int *__restrict__ pairsT,
+                                                             int nqFixed, int ntFixed, int capacity, int initDist,
+                                                             amos_best2 *__restrict__ out)
+{
+    __shared__ unsigned mB[2 * kWaves][128], mS[2 * kWaves][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int pair = blockIdx.y;
+    const int fq = pairsQ ? pairsQ[pair] : 0, ft = pairsT ? pairsT[pair] : 0;
+    const int nq = counts ? min(counts[fq], capacity) : nqFixed;
+    const int nt = counts ? min(counts[ft], capacity) : ntFixed;
+    const int q0 = blockIdx.x * 128;
+    if (q0 >= nq) return;  // whole block idle (uniform)
+    const uint8_t *qb = descBaseQ + (size_t)fq * frameStrideBytes;
+    const uint8_t *tb = descBaseT + (size_t)ft * frameStrideBytes;
+    constexpr unsigned M = 0x01010101u;
+    // B operand: -+1 bytes of the lane's four queries (zero for queries beyond nq)
+    v4i Bq[4][4][2];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int q = q0 + 32 * c + r;
+        uint4 y4 = uint4{0, 0, 0, 0};
+        if (q < nq) y4 = *reinterpret_cast<const uint4 *>(qb + (size_t)q * 32 + 16 * h);
+        const unsigned y[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++) {
+                const unsigned m = (y[d] >> rr) & M;                 // 1 where the bit is set
+                const unsigned v = ((m << 8) - m) | (m ^ M);         // bit set: 0xff = -1, clear: 0x01 = +1 (the accumulator is -dot)
+                Bq[c][d][rr >> 2][rr & 3] = q < nq ? (int)v : 0;
+            }
+    }
+    unsigned best[4], second[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) best[c] = second[c] = 0xffffffffu;
+    // (512 << 16) + train index of accumulator i in the wave's current tile, WITHOUT the lane half's 4 h: every key of
+    // a lane carries the same 4 h, so it is added once at the end -- which makes these offsets wave-uniform (SGPRs,
+    // bumped by scalar adds) and the key one v_lshl_add_u32 with a scalar operand.
+    int idxoff[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        idxoff[i] = (512 << 16) + wave * 32 + (i & 3) + 8 * (i >> 2);
+        asm volatile("" : "+s"(idxoff[i]));
+    }
+    auto push2 = [](unsigned &b, unsigned &s, unsigned k1, unsigned k2) {
+        unsigned mid;
+        asm("v_med3_u32 %0, %1, %2, %3" : "=v"(mid) : "v"(b), "v"(k1), "v"(k2));
+        b = min(b, min(k1, k2));  // v_min3_u32
+        s = min(s, mid);
+    };
+    auto spread1 = [&](const unsigned x, v4i (&Ad)[2]) {  // 0/1 bytes of one descriptor dword: register r' holds bits r', r' + 8, ...
+        Ad[0] = v4i{(int)(x & M), (int)((x >> 1) & M), (int)((x >> 2) & M), (int)((x >> 3) & M)};
+        Ad[1] = v4i{(int)((x >> 4) & M), (int)((x >> 5) & M), (int)((x >> 6) & M), (int)((x >> 7) & M)};
+    };
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto mfma_step = [&](const v4i (&Ad)[2], const int c0, const int d, v16i &accA, v16i &accB) {  // query tiles c0, c0 + 1, k-steps 2 d, 2 d + 1
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            accA = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ad[k], Bq[c0][d][k], accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ad[k], Bq[c0 + 1][d][k], accB, 0, 0, 0);
+        }
+    };
+    auto update = [&](const v16i &acc, unsigned &b, unsigned &s) {  // 16 keys of one query into its running best two
+#pragma unroll
+        for (int i = 0; i < 16; i += 2)
+            push2(b, s, ((unsigned)acc[i] << 16) + (unsigned)idxoff[i], ((unsigned)acc[i + 1] << 16) + (unsigned)idxoff[i + 1]);  // v_lshl_add_u32
+    };
+    auto load_tile = [&](int tile) { return *reinterpret_cast<const uint4 *>(tb + (size_t)(tile * 32 + r) * 32 + 16 * h); };
+
+    const int nFull = nt >> 5;                       // tiles whose 32 rows are all train descriptors
+    const int nMine = nFull > wave ? (nFull - wave + kWaves - 1) / kWaves : 0;
+    if (nMine > 0) {
+        // The loop is software-pipelined in half tiles: phase P multiplies query tiles 2, 3 of the current train tile
+        // while the best-two update of tiles 0, 1 issues between the MFMAs; phase Q spreads the NEXT train tile dword by
+        // dword into the same operand registers (the current tile's are dead by then), multiplies its query tiles 0, 1
+        // and updates tiles 2, 3 of the current one.  One operand buffer: under 256 registers, two waves per SIMD.
+        v4i A[4][2];
+        v16i acc0 = zero16, acc1 = zero16, acc2, acc3;
+        {
+            const uint4 a4 = load_tile(wave);
+            const unsigned a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                spread1(a[d], A[d]);
+                mfma_step(A[d], 0, d, acc0, acc1);
+            }
+        }
+        for (int it = 0; it < nMine; it++) {
+            // the next tile (the last trip re-reads its own: those MFMAs are never consumed), used in phase Q
+            const uint4 n4 = load_tile(wave + min(it + 1, nMine - 1) * kWaves);
+            const unsigned nx[4] = {n4.x, n4.y, n4.z, n4.w};
+            acc2 = zero16;
+            acc3 = zero16;
+#pragma unroll
+            for (int d = 0; d < 4; d++) mfma_step(A[d], 2, d, acc2, acc3);
+            update(acc0, best[0], second[0]);
+            update(acc1, best[1], second[1]);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {  // phase P: 1 MFMA : 5 vector instructions
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+            acc0 = zero16;
+            acc1 = zero16;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                spread1(nx[d], A[d]);
+                mfma_step(A[d], 0, d, acc0, acc1);
+            }
+            update(acc2, best[2], second[2]);
+            update(acc3, best[3], second[3]);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                idxoff[i] += 32 * kWaves;
+                asm volatile("" : "+s"(idxoff[i]));  // sixteen live SGPRs, not expressions of the trip count folded into every key
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {  // phase Q: 1 MFMA : 9 vector instructions
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+        }
+    }
+    if ((nt & 31) && (nFull % kWaves) == wave) {  // the partial last tile: rows beyond nt never win
+        const int t = nFull * 32 + r;
+        uint4 a4 = uint4{0, 0, 0, 0};
+        if (t < nt) a4 = *reinterpret_cast<const uint4 *>(tb + (size_t)t * 32 + 16 * h);
+        const unsigned a[4] = {a4.x, a4.y, a4.z, a4.w};
+        v4i A[4][2];
+        v16i acc[4] = {zero16, zero16, zero16, zero16};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            spread1(a[d], A[d]);
+            mfma_step(A[d], 0, d, acc[0], acc[1]);
+            mfma_step(A[d], 2, d, acc[2], acc[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const int row0 = nFull * 32 + (i & 3) + 8 * (i >> 2), row1 = row0 + 1;  // accumulators i, i + 1 (without 4 h)
+                unsigned k1 = ((unsigned)acc[c][i] << 16) + (unsigned)((512 << 16) + row0);
+                unsigned k2 = ((unsigned)acc[c][i + 1] << 16) + (unsigned)((512 << 16) + row1);
+                if (row0 + 4 * h >= nt) k1 = 0xffffffffu;
+                if (row1 + 4 * h >= nt) k2 = 0xffffffffu;
+                push2(best[c], second[c], k1, k2);
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {  // the lane half's share of the train index
+        if (best[c] != 0xffffffffu) best[c] += 4 * h;
+        if (second[c] != 0xffffffffu) second[c] += 4 * h;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        mB[wave * 2 + h][32 * c + r] = best[c];
+        mS[wave * 2 + h][32 * c + r] = second[c];
+    }
+    __syncthreads();
+    for (int qq = tid; qq < 128; qq += 64 * kWaves) {
+        const int qi = q0 + qq;
+        if (qi >= nq) break;
+        unsigned b = mB[0][qq], s2 = mS[0][qq];
+#pragma unroll
+        for (int w = 1; w < 2 * kWaves; w++) top2_merge(b, s2, mB[w][qq], mS[w][qq]);
+        const Desc qd = load_desc(qb + (size_t)qi * 32);
+        int pq = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) pq += __popc(qd.w[k]);
+        // key >> 16 = 512 + acc and ham = |q| + acc
+        int bd = (int)(b >> 16) - 512 + pq, sd = (int)(s2 >> 16) - 512 + pq;
+        bool hb = b != 0xffffffffu, hs = s2 != 0xffffffffu;
+        if (kGate) {
+            hb = hb && bd < initDist;
+            hs = hs && sd < initDist;
+        }
+        amos_best2 res;
+        res.best_idx = hb ? (int)(b & 0xffff) : -1;
+        res.best_dist = hb ? bd : initDist;
+        res.second_idx = hs ? (int)(s2 & 0xffff) : -1;
+        res.second_dist = hs ? sd : initDist;
+        out[(size_t)pair * capacity + qi] = res;
+    }
+}
+
 }  // namespace amos
 
 using namespace amos;
@@ -374,7 +592,32 @@ struct amos_match {
     size_t capOff = 0, capIdx = 0;
     void *dOut = nullptr;
     size_t capOut = 0;
+    int bfKernel = 0;  // brute-force best-2: 0 = choose by size, 1 = xor + popcount kernel, 2 = i8 MFMA kernel
 };
+
+// the MFMA kernel works on 128-query x 32-train tiles: below a few tiles' worth of work the popcount kernel wins
+static bool use_mfma(const amos_match *m, int nq, int nt)
+{
+    if (m->bfKernel == 1) return false;
+    if (m->bfKernel == 2) return true;
+    return nq >= 96 && nt >= 64;
+}
+
+template <bool kGate>
+static void launch_bf(amos_match *m, bool mfma, dim3 gridPop, dim3 gridMfma, const uint8_t *dq, const uint8_t *dt, size_t stride, const int *counts,
+                      const int *pq, const int *pt, int nq, int nt, int capacity, int initDist, amos_best2 *out)
+{
+    static const int forced = getenv("AMOS_MM_WAVES") ? atoi(getenv("AMOS_MM_WAVES")) : 0;  // experiment switch
+    const int waves = forced ? forced : ((size_t)gridMfma.x * gridMfma.y >= 512 ? 1 : 4);
+    if (mfma && waves == 1)  // enough 128-query blocks to fill the chip with one wave each
+        hipLaunchKernelGGL((k_bf_best2_mfma<kGate, 1>), gridMfma, dim3(64), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
+    else if (mfma && waves == 2)
+        hipLaunchKernelGGL((k_bf_best2_mfma<kGate, 2>), gridMfma, dim3(128), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
+    else if (mfma)
+        hipLaunchKernelGGL((k_bf_best2_mfma<kGate, 4>), gridMfma, dim3(256), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
+    else
+        hipLaunchKernelGGL(k_bf_best2<kGate>, gridPop, dim3(256), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
+}
 
 template <typename T>
 static int grow(T **p, size_t *cap, size_t need)
@@ -464,6 +707,13 @@ int amos_match_sync(amos_match *m)
 
 void *amos_match_stream(amos_match *m) { return m ? (void *)m->stream : nullptr; }
 
+int amos_match_set_bruteforce_kernel(amos_match *m, int mode)
+{
+    if (!m || mode < 0 || mode > 2) { set_error("amos_match_set_bruteforce_kernel: mode 0 (by size), 1 (popcount) or 2 (MFMA)"); return AMOS_ERR_INVALID; }
+    m->bfKernel = mode;
+    return AMOS_OK;
+}
+
 int amos_match_distances(amos_match *m, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *out)
 {
     if (!m || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || (!out && nq > 0 && nt > 0)) { set_error("amos_match_distances: invalid argument"); return AMOS_ERR_INVALID; }
@@ -535,12 +785,14 @@ int amos_match_bruteforce_best2(amos_match *m, const uint8_t *q, int nq, const u
     if (rc != AMOS_OK) return rc;
     rc = grow_out(m, (size_t)nq * sizeof(amos_best2));
     if (rc != AMOS_OK) return rc;
-    if (init_dist > 256)
-        hipLaunchKernelGGL(k_bf_best2<false>, dim3((nq + 63) / 64, 1), dim3(256), 0, m->stream, m->dQ, m->dT, (size_t)0, (const int *)nullptr,
-                           (const int *)nullptr, (const int *)nullptr, nq, nt, nq, init_dist, (amos_best2 *)m->dOut);
-    else
-        hipLaunchKernelGGL(k_bf_best2<true>, dim3((nq + 63) / 64, 1), dim3(256), 0, m->stream, m->dQ, m->dT, (size_t)0, (const int *)nullptr,
-                           (const int *)nullptr, (const int *)nullptr, nq, nt, nq, init_dist, (amos_best2 *)m->dOut);
+    {
+        const bool mfma = use_mfma(m, nq, nt);
+        const dim3 gp((nq + 63) / 64, 1), gm((nq + 127) / 128, 1);
+        if (init_dist > 256)
+            launch_bf<false>(m, mfma, gp, gm, m->dQ, m->dT, 0, nullptr, nullptr, nullptr, nq, nt, nq, init_dist, (amos_best2 *)m->dOut);
+        else
+            launch_bf<true>(m, mfma, gp, gm, m->dQ, m->dT, 0, nullptr, nullptr, nullptr, nq, nt, nq, init_dist, (amos_best2 *)m->dOut);
+    }
     AMOS_HIP_CHECK(hipGetLastError());
     AMOS_HIP_CHECK(hipMemcpyAsync(out, m->dOut, (size_t)nq * sizeof(amos_best2), hipMemcpyDeviceToHost, m->stream));
     AMOS_HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -556,12 +808,14 @@ int amos_match_bruteforce_best2_batch_device(amos_match *m, const uint8_t *d_des
         return AMOS_ERR_INVALID;
     }
     AMOS_HIP_CHECK(hipSetDevice(m->device));
-    if (init_dist > 256)
-        hipLaunchKernelGGL(k_bf_best2<false>, dim3((capacity + 63) / 64, n_pairs), dim3(256), 0, m->stream, d_desc, d_desc, frame_stride_bytes,
-                           d_counts, d_pairs_q, d_pairs_t, 0, 0, capacity, init_dist, d_out);
-    else
-        hipLaunchKernelGGL(k_bf_best2<true>, dim3((capacity + 63) / 64, n_pairs), dim3(256), 0, m->stream, d_desc, d_desc, frame_stride_bytes,
-                           d_counts, d_pairs_q, d_pairs_t, 0, 0, capacity, init_dist, d_out);
+    {
+        const bool mfma = use_mfma(m, capacity, capacity);  // the counts live on the device: decide by the capacity
+        const dim3 gp((capacity + 63) / 64, n_pairs), gm((capacity + 127) / 128, n_pairs);
+        if (init_dist > 256)
+            launch_bf<false>(m, mfma, gp, gm, d_desc, d_desc, frame_stride_bytes, d_counts, d_pairs_q, d_pairs_t, 0, 0, capacity, init_dist, d_out);
+        else
+            launch_bf<true>(m, mfma, gp, gm, d_desc, d_desc, frame_stride_bytes, d_counts, d_pairs_q, d_pairs_t, 0, 0, capacity, init_dist, d_out);
+    }
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }

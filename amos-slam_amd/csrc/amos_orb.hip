@@ -270,7 +270,8 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
     g.kpLevelTotal = kpOff;
     g.kpCap = kpOff;
     g.blurItems = blurOff;
-    g.fastTileStrideDw = ((maxTw + 7 + 8 + 15) >> 4) * 4;  // whole 16-byte pieces; + 8: the last 8-pixel group reads one dword past tw + 6
+    // whole 16-byte pieces; + 8: the last 8-pixel group reads one dword past tw + 6.  One of the two strides k_fast_cells is compiled for.
+    g.fastTileStrideDw = ((maxTw + 7 + 8 + 15) >> 4) * 4 <= 16 ? 16 : 20;
     g.fastTileRows = maxTh + 6;
     g.fastMapRows = maxTh + 2;
     g.fastKeptCap = ((maxTw + 1) / 2) * ((maxTh + 1) / 2);
@@ -400,9 +401,14 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
     AMOS_HIP_CHECK(hipEventRecord(h->evJoin, h->streamB));
     h->blurDone = true;
     if (ev) (void)hipEventRecord(ev[3], h->stream);
-    hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid((g.totalCells + kFastCellsPerGroup - 1) / kFastCellsPerGroup, nFrames)), dim3(64 * kFastCellsPerGroup),
-                       kFastCellsPerGroup * (size_t)g.fastWaveBytes, h->stream,
-                       h->dPyr, h->dGeom, h->dCells, h->dSlotCount, h->dSlots, nFrames);
+    {
+        const dim3 fgrid(xcd_grid((g.totalCells + kFastCellsPerGroup - 1) / kFastCellsPerGroup, nFrames)), fblock(64 * kFastCellsPerGroup);
+        const size_t flds = kFastCellsPerGroup * (size_t)g.fastWaveBytes;
+        if (g.fastTileStrideDw == 16)
+            hipLaunchKernelGGL(k_fast_cells<16>, fgrid, fblock, flds, h->stream, h->dPyr, h->dGeom, h->dCells, h->dSlotCount, h->dSlots, nFrames);
+        else
+            hipLaunchKernelGGL(k_fast_cells<20>, fgrid, fblock, flds, h->stream, h->dPyr, h->dGeom, h->dCells, h->dSlotCount, h->dSlots, nFrames);
+    }
     if (ev) (void)hipEventRecord(ev[4], h->stream);
     const size_t lds = oct_lds_bytes(h->octNC, h->octSC);
     hipLaunchKernelGGL(k_octree, dim3(nFrames * g.nLevels), dim3(256), lds, h->stream, h->dGeom, h->dCells, h->dSlotCount,

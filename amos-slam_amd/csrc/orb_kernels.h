@@ -7,6 +7,8 @@
 // Compiled with -ffp-contract=off; the only fused operations are the explicit __fmaf_rn calls in
 // k_describe, which restate the FMA the reference binary executes.
 #pragma once
+#include <type_traits>
+
 #include "amos_common.h"
 #include "../../include/amos_orb_pattern.h"
 #include "../../include/amos_host_types.h"
@@ -459,6 +461,35 @@ __device__ __forceinline__ void fast_score_tail(const uint8_t *tile, int tileStr
 #endif
 constexpr int kFastCellsPerGroup = AMOS_FAST_CELLS_PER_GROUP;  // waves (= cells) per work-group
 
+// Compass flags of the two pixels a dword-set holds in the HIGH bytes of its 16-bit halves (the low bytes may
+// hold anything -- "noise"): with lo = max(min(n,s), min(e,w)), hi = min(max(n,s), max(e,w)) as 16-bit values,
+//   cd = centre << 8 (low byte 0x00):  sat(cd - lo) = 256 (c - lo_hi) - lo_noise  > 256 t  <=>  c - lo_hi > t
+//   cb = centre << 8 | 0xff:           sat(hi - cb) = 256 (hi_hi - c) - (255 - hi_noise) > 256 t  <=>  hi_hi - c > t
+// (min / max of 16-bit values order by the high byte first, so lo / hi carry the right high bytes), i.e. the
+// comparisons are EXACT although the neighbours are never masked.  q = max of the two is the pixel's compass
+// score (scaled by 256): the test at ANY threshold is q > 256 t, which is what lets one sweep answer
+// "is there a candidate at iniThFAST" and "could there be one at minThFAST" together.
+// Returns 1 in bit 0 / bit 16 where q > t2 (t2 = threshold << 8 in both halves).
+template <bool kTrack>
+__device__ __forceinline__ unsigned fast_flags(unsigned cd, unsigned cb, unsigned n, unsigned s, unsigned e, unsigned w, unsigned t2, unsigned &qmax)
+{
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    const ushort2v n2 = __builtin_bit_cast(ushort2v, n), s2 = __builtin_bit_cast(ushort2v, s), e2 = __builtin_bit_cast(ushort2v, e),
+                   w2 = __builtin_bit_cast(ushort2v, w);
+    const ushort2v lo = __builtin_elementwise_max(__builtin_elementwise_min(n2, s2), __builtin_elementwise_min(e2, w2));
+    const ushort2v hi = __builtin_elementwise_min(__builtin_elementwise_max(n2, s2), __builtin_elementwise_max(e2, w2));
+    const ushort2v q = __builtin_elementwise_max(__builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2v, cd), lo),
+                                                 __builtin_elementwise_sub_sat(hi, __builtin_bit_cast(ushort2v, cb)));
+    if (kTrack) qmax = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(ushort2v, qmax), q));
+    const ushort2v f = __builtin_elementwise_sub_sat(q, __builtin_bit_cast(ushort2v, t2));
+    unsigned r;  // 1 in bit 0 / bit 16 where the half is non-zero (the compiler turns min(f, 1) into compares)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, f)), "v"(0x00010001u));
+    return r;
+}
+
+// kRowDw: dwords per LDS tile row, a compile-time constant (16 for cells up to 41 px wide, 20 up to 59) so that
+// every circle / neighbour offset of phases 1 and 2 is an immediate of the LDS instruction.
+template <int kRowDw>
 __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
                                                    const Cell *__restrict__ cells, int *__restrict__ slotCount,
                                                    uint32_t *__restrict__ slots, int nFrames)
@@ -473,7 +504,7 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
     if (cellIdx >= g->totalCells) return;  // wave-uniform; no work-group barrier below
     const Cell c = cells[cellIdx];
     const LevelGeom &lg = g->lv[c.level];
-    const int rowDw = g->fastTileStrideDw, tileStride = rowDw * 4;
+    constexpr int rowDw = kRowDw, tileStride = kRowDw * 4;
     unsigned char *base = fast_smem + (size_t)wave * g->fastWaveBytes;
     uint32_t *tile32 = reinterpret_cast<uint32_t *>(base);
     uint8_t *amap = base + (((size_t)g->fastTileRows * tileStride + 15) & ~(size_t)15);
@@ -498,22 +529,28 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
     const int iniTh = min(max(g->iniTh, 0), 255), minTh = min(max(g->minTh, 0), 255);
     const int groups = c.groups, nitems = th * groups;
     const unsigned long long ltmask = (1ull << lane) - 1ull;
+    uint32_t *out = slots + (size_t)frame * g->slotTotal + c.slotOff;
+    const int xBase = c.x0 - kMinBorder, yBase = c.y0 - kMinBorder;
+    // pixel k of a group <-> bit {0, 1, 16, 17, 2, 3, 18, 19}[k]; pixels beyond tw in the row's last group are masked
+    const int nLast = tw - 8 * (groups - 1);  // 1 .. 8, wave-uniform
+    const unsigned lastMask = ((1u << (min(nLast, 2) + min(max(nLast - 4, 0), 2))) - 1u) |
+                              (((1u << (min(max(nLast - 2, 0), 2) + min(max(nLast - 6, 0), 2))) - 1u) << 16);
     int nkept = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        const int t = pass == 0 ? iniTh : minTh;
-        if (pass == 1 && minTh >= iniTh) break;  // a second cv::FAST at a higher threshold finds nothing new
+    bool anyLower = true;  // wave-uniform: some pixel's compass score exceeds minThFAST (known after the first sweep)
+
+    // One cv::FAST(cell, t, nonmax) -- ORBextractor.cc:1126 / :1135.  kFirst: the sweep at iniThFAST, which also
+    // records whether ANY pixel could pass the compass test at minThFAST: a cell that comes back empty and has
+    // no such pixel needs no second sweep (the test is monotone in t) -- flat regions finish after one pass.
+    auto sweep = [&](const int t, auto first) {
+        constexpr bool kFirst = decltype(first)::value;
         // ---- phase 1 (necessary test, 8 pixels per lane) feeding phase 2 (exact arc value) in dense chunks.
-        // Even and odd pixels of a dword are isolated with one v_and each (odd ones stay shifted left by 8:
-        // every operand of a comparison is scaled alike), then everything is unsigned packed 16-bit:
-        //   dark   <=>  max(min(n,s), min(e,w)) < c - t      bright  <=>  min(max(n,s), max(e,w)) > c + t
-        // with saturating c -+ t and "a > b" as sat(a - b) != 0.
-        const unsigned tE = (unsigned)t * 0x00010001u, tO = tE << 8;
+        // Odd pixels of a dword sit in the high bytes of its 16-bit halves as loaded; even pixels are brought
+        // there by taking the dword one byte to the left (for the west / east neighbours that is just another
+        // alignment of the same row data), and fast_flags compares 16-bit halves whose low bytes are noise.
+        const unsigned t2 = ((unsigned)t * 0x00010001u) << 8;
+        unsigned qmax = 0;
         int ncand = 0, done = 0;   // list entries [0, done) have their arc value
         bool overflow = false;     // wave-uniform: the list wrapped, phase 3 must scan the arc map instead
-        // pixel k of a group <-> bit {0, 1, 16, 17, 2, 3, 18, 19}[k]; pixels beyond tw in the row's last group are masked
-        const int nLast = tw - 8 * (groups - 1);  // 1 .. 8, wave-uniform
-        const unsigned lastMask = ((1u << (min(nLast, 2) + min(max(nLast - 4, 0), 2))) - 1u) |
-                                  (((1u << (min(max(nLast - 2, 0), 2) + min(max(nLast - 6, 0), 2))) - 1u) << 16);
         for (int item0 = 0; item0 < nitems; item0 += 64) {
             const int item = item0 + lane;
             unsigned bits = 0;
@@ -523,23 +560,17 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
                 const uint32_t *row = tile32 + (y + 3) * rowDw + 2 * gx;  // dword holding pixels x0 + 8gx - 4 ..
                 const unsigned L = row[0], C0 = row[1], C1 = row[2], R = row[3];
                 const unsigned N0 = row[1 - 3 * rowDw], N1 = row[2 - 3 * rowDw], S0 = row[1 + 3 * rowDw], S1 = row[2 + 3 * rowDw];
-                const unsigned W0 = __builtin_amdgcn_alignbyte(C0, L, 1u), W1 = __builtin_amdgcn_alignbyte(C1, C0, 1u);  // x-3 ..
-                const unsigned E0 = __builtin_amdgcn_alignbyte(C1, C0, 3u), E1 = __builtin_amdgcn_alignbyte(R, C1, 3u);  // x+3 ..
-                auto flags = [](unsigned cc, unsigned nn, unsigned ss, unsigned ee, unsigned ww, unsigned m, unsigned tt) -> unsigned {
-                    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-                    const ushort2v c2 = __builtin_bit_cast(ushort2v, cc & m), n2 = __builtin_bit_cast(ushort2v, nn & m),
-                                   s2 = __builtin_bit_cast(ushort2v, ss & m), e2 = __builtin_bit_cast(ushort2v, ee & m),
-                                   w2 = __builtin_bit_cast(ushort2v, ww & m), t2 = __builtin_bit_cast(ushort2v, tt);
-                    const ushort2v lo = __builtin_elementwise_max(__builtin_elementwise_min(n2, s2), __builtin_elementwise_min(e2, w2));
-                    const ushort2v hi = __builtin_elementwise_min(__builtin_elementwise_max(n2, s2), __builtin_elementwise_max(e2, w2));
-                    const ushort2v f = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(c2, t2), lo) |
-                                       __builtin_elementwise_sub_sat(hi, __builtin_elementwise_add_sat(c2, t2));
-                    unsigned r;  // 1 in bit 0 / bit 16 where the lane is non-zero (the compiler turns min(f, 1) into compares)
-                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, f)), "v"(0x00010001u));
-                    return r;
-                };
-                const unsigned bE0 = flags(C0, N0, S0, E0, W0, 0x00ff00ffu, tE), bO0 = flags(C0, N0, S0, E0, W0, 0xff00ff00u, tO);
-                const unsigned bE1 = flags(C1, N1, S1, E1, W1, 0x00ff00ffu, tE), bO1 = flags(C1, N1, S1, E1, W1, 0xff00ff00u, tO);
+                // odd pixels (x + 1, x + 3 of each dword): west = x - 3 .., east = x + 3 ..
+                const unsigned oW0 = __builtin_amdgcn_alignbyte(C0, L, 1u), oW1 = __builtin_amdgcn_alignbyte(C1, C0, 1u);
+                const unsigned oE0 = __builtin_amdgcn_alignbyte(C1, C0, 3u), oE1 = __builtin_amdgcn_alignbyte(R, C1, 3u);
+                // even pixels, everything one byte to the left: west = the previous dword as it is, east = alignment 2
+                const unsigned eE0 = __builtin_amdgcn_alignbyte(C1, C0, 2u), eE1 = __builtin_amdgcn_alignbyte(R, C1, 2u);
+                const unsigned bO0 = fast_flags<kFirst>(C0 & 0xff00ff00u, C0 | 0x00ff00ffu, N0, S0, oE0, oW0, t2, qmax);
+                const unsigned bO1 = fast_flags<kFirst>(C1 & 0xff00ff00u, C1 | 0x00ff00ffu, N1, S1, oE1, oW1, t2, qmax);
+                const unsigned bE0 = fast_flags<kFirst>(__builtin_amdgcn_perm(0u, C0, 0x020c000cu), __builtin_amdgcn_perm(0u, C0, 0x020d000du),
+                                                        N0 << 8, S0 << 8, eE0, L, t2, qmax);
+                const unsigned bE1 = fast_flags<kFirst>(__builtin_amdgcn_perm(0u, C1, 0x020c000cu), __builtin_amdgcn_perm(0u, C1, 0x020d000du),
+                                                        N1 << 8, S1 << 8, eE1, C0, t2, qmax);
                 bits = bE0 | (bO0 << 1) | (bE1 << 2) | (bO1 << 3);
                 if (gx == groups - 1) bits &= lastMask;
                 p0 = (y << 6) | (8 * gx);
@@ -552,9 +583,9 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
                 __builtin_amdgcn_wave_barrier();
             }
             {   // append the survivors: one wave-wide prefix sum of the per-lane counts, then up to 8 stores
-                const int c = __popc(bits);
-                const int incl = wave_inclusive_scan(c);
-                int o = ncand + incl - c;
+                const int cnt = __popc(bits);
+                const int incl = wave_inclusive_scan(cnt);
+                int o = ncand + incl - cnt;
                 if (bits & 0x00001u) cand[o++] = (uint16_t)p0;
                 if (bits & 0x00002u) cand[o++] = (uint16_t)(p0 + 1);
                 if (bits & 0x10000u) cand[o++] = (uint16_t)(p0 + 2);
@@ -572,6 +603,10 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
                 done += 128;
             }
         }
+        if (kFirst) {  // compass scores are scaled by 256; pixels outside the cell may be counted (costs a sweep, never a corner)
+            const unsigned m2 = ((unsigned)minTh * 0x00010001u) << 8;
+            anyLower = __ballot(((qmax & 0xffffu) > (m2 & 0xffffu)) || ((qmax >> 16) > (m2 >> 16))) != 0ull;
+        }
         fast_score_tail(tile, tileStride, amap, cand, done, ncand - done, lane, t);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -579,6 +614,8 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
         // smaller than a anyway: keep <=> a > all 8 neighbours.  Over the survivor list, or (list overflowed)
         // over the non-zero entries of the arc map.
         if (!overflow) {
+            // The list is in item order = row-major pixel order and the ordered ballots below keep that order, which
+            // is FAST's output order: the kept corners go straight to their final slots.
             for (int i0 = 0; i0 < ncand; i0 += 64) {
                 const int i = i0 + lane;
                 bool keep = false;
@@ -588,14 +625,14 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
                     const uint8_t *m = amap + ((p >> 6) + 1) * kFastMapStride + (p & 63) + 1;
                     a = m[0];
                     if (a) {
-                        const int s = kFastMapStride;
+                        constexpr int s = kFastMapStride;
                         const int nmax = max(max(max((int)m[-s - 1], (int)m[-s]), max((int)m[-s + 1], (int)m[-1])),
                                              max(max((int)m[1], (int)m[s - 1]), max((int)m[s], (int)m[s + 1])));
                         keep = nmax < a;
                     }
                 }
                 const unsigned long long bal = __ballot(keep);
-                if (keep) kept[nkept + __popcll(bal & ltmask)] = ((uint32_t)p << 8) | (uint32_t)a;
+                if (keep) out[nkept + __popcll(bal & ltmask)] = (uint32_t)(xBase + (p & 63)) | ((uint32_t)(yBase + (p >> 6)) << 12) | ((uint32_t)(a - 1) << 24);
                 nkept += __popcll(bal);
             }
         } else {
@@ -610,7 +647,7 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
                     bool keep = false;
                     if (a) {
                         const uint8_t *m = amap + (y + 1) * kFastMapStride + 4 * dw + k;
-                        const int s = kFastMapStride;
+                        constexpr int s = kFastMapStride;
                         const int nmax = max(max(max((int)m[-s - 1], (int)m[-s]), max((int)m[-s + 1], (int)m[-1])),
                                              max(max((int)m[1], (int)m[s - 1]), max((int)m[s], (int)m[s + 1])));
                         keep = nmax < a;
@@ -620,21 +657,22 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
                     nkept += __popcll(bal);
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // the map scan visits (64-entry block, byte k, lane): rank by pixel index = row-major order
+            for (int i = lane; i < nkept; i += 64) {
+                const uint32_t me = kept[i];
+                int rank = 0;
+                for (int j = 0; j < nkept; j++) rank += kept[j] < me;
+                const int p = (int)(me >> 8), a = (int)(me & 0xff);
+                out[rank] = (uint32_t)(xBase + (p & 63)) | ((uint32_t)(yBase + (p >> 6)) << 12) | ((uint32_t)(a - 1) << 24);
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (nkept > 0) break;  // wave-uniform: the cell is not empty at this threshold
-    }
-    // ---- ordered output: rank by pixel index = row-major order
-    uint32_t *out = slots + (size_t)frame * g->slotTotal + c.slotOff;
-    for (int i = lane; i < nkept; i += 64) {
-        const uint32_t me = kept[i];
-        int rank = 0;
-        for (int j = 0; j < nkept; j++) rank += kept[j] < me;
-        const int p = (int)(me >> 8), a = (int)(me & 0xff);
-        const int xr = c.x0 + (p & 63) - kMinBorder, yr = c.y0 + (p >> 6) - kMinBorder;
-        out[rank] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)(a - 1) << 24);
-    }
+    };
+    sweep(iniTh, std::true_type{});
+    // a second cv::FAST at a higher (or equal) threshold finds nothing new; neither does one on a cell without
+    // a single pixel whose compass score exceeds minThFAST
+    if (nkept == 0 && minTh < iniTh && anyLower) sweep(minTh, std::false_type{});
     if (lane == 0) slotCount[(size_t)frame * g->totalCells + cellIdx] = nkept;
 }
 

@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--mask-conv-dtype", choices=["fp32", "fp16", "bf16"], default="fp32",
                     help="precision of the mask network's convolutions (c3 only; fp32 is the parity configuration)")
     ap.add_argument("--mask-chunk", type=int, default=0, help="frames per network forward (default: frames per lane)")
+    ap.add_argument("--match-kernel", choices=["auto", "popcount", "mfma"], default="auto", help="brute-force matcher kernel (identical results; A/B switch)")
     ap.add_argument("--check", action="store_true", help="verify frames of the batch against the oracle")
     ap.add_argument("--dry-run", action="store_true", help="launcher / collective rehearsal without a GPU (value null)")
     args = ap.parse_args()
@@ -271,6 +272,7 @@ def main():
         ln.ext = pkg.OrbExtractor(n_features=cfg["n_features"], n_levels=cfg["n_levels"], max_width=W, max_height=H,
                                   max_batch=lane_cap_frames, device=local_rank)
         ln.matcher = pkg.OrbMatcher(device=local_rank, stream=ln.ext.stream)  # same stream: match follows extract
+        ln.matcher.set_bruteforce_kernel(args.match_kernel)
         _, ln.d_desc, ln.d_counts, ln.cap = ln.ext.batch_results_device()
         ln.stream = torch.cuda.ExternalStream(ln.ext.stream, device=local_rank)
         ln.d_match = torch.full((lane_cap_frames, ln.cap, 4), 1 << 30, dtype=torch.int32, device=dev)

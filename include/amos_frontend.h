@@ -248,6 +248,10 @@ int amos_match_list_best2(amos_match *m, const uint8_t *q, int nq, const uint8_t
 /* The same with every train descriptor as candidate, in index order (N_q x N_t brute force). */
 int amos_match_bruteforce_best2(amos_match *m, const uint8_t *q, int nq, const uint8_t *t, int nt,
                                 int init_dist, amos_best2 *out);
+/* Which kernel the two brute-force entry points run: 0 = chosen by size (default), 1 = xor + popcount on the vector
+ * units, 2 = exact-integer i8 MFMA (ham = |q| + sum_k t_k (1 - 2 q_k), v_mfma_i32_32x32x32_i8).  Identical results;
+ * a measurement / test switch. */
+int amos_match_set_bruteforce_kernel(amos_match *m, int mode);
 /* Device-pointer form for the batched pipeline: for each of n_pairs (query frame, train frame)
  * pairs: descriptors at d_desc + frame * frame_stride_bytes, counts in d_counts[frame]; out is
  * [n_pairs][capacity] amos_best2 on the device.  Asynchronous on the matcher's stream. */

@@ -599,12 +599,21 @@ def test_list_primitives_vs_oracle(gpu_lib, ob):
         _same(m.list_best2(q, t, off, idx, init), ob.list_best2(q, t, off, idx, init), f"list best2 init={init}")
 
 
-def test_bruteforce_vs_oracle(gpu_lib, ob):
+BF_KERNELS = ["auto", "popcount", "mfma"]  # amos_match_set_bruteforce_kernel: identical results whichever runs
+
+
+@pytest.mark.parametrize("kernel", BF_KERNELS)
+def test_bruteforce_vs_oracle(gpu_lib, ob, kernel):
     rng = np.random.default_rng(3)
     q, t = _descs(rng, 1001), _descs(rng, 999)
     t[500:520] = q[7]  # many equal best distances
     q[9] = q[7]
+    t[3] = 0           # extreme popcounts: all-zero / all-one descriptors on both sides
+    t[4] = 255
+    q[11] = 0
+    q[12] = 255
     m = gpu_lib.OrbMatcher()
+    m.set_bruteforce_kernel(kernel)
     for init in (256, 2 ** 31 - 1, 110):
         _same(m.bruteforce_best2(q, t, init), ob.bruteforce_best2(q, t, init), f"bf best2 init={init}")
     # empty / ragged
@@ -614,13 +623,17 @@ def test_bruteforce_vs_oracle(gpu_lib, ob):
     _same(m.bruteforce_best2(q[:1], t[:1]), ob.bruteforce_best2(q[:1], t[:1]), "1x1")
 
 
-def test_matcher_size_fuzz(gpu_lib, ob):
+@pytest.mark.parametrize("kernel", BF_KERNELS)
+def test_matcher_size_fuzz(gpu_lib, ob, kernel):
     """Brute-force and list reductions over awkward set sizes (wave / tile boundaries, 1, 2, 3 descriptors, train sets
-    shorter than the four per-wave quarters) and gates; descriptors drawn from a small pool so that ties are common."""
+    shorter than the four per-wave quarters or one 32-row MFMA tile) and gates; descriptors drawn from a small pool so
+    that ties are common."""
     rng = np.random.default_rng(99)
     pool = _descs(rng, 37)
     m = gpu_lib.OrbMatcher()
-    for nq, nt in ((1, 1), (1, 2), (2, 3), (3, 1), (5, 7), (63, 65), (64, 64), (65, 63), (127, 4), (4, 129), (257, 255), (1, 1500), (1300, 2), (513, 1025)):
+    m.set_bruteforce_kernel(kernel)
+    for nq, nt in ((1, 1), (1, 2), (2, 3), (3, 1), (5, 7), (63, 65), (64, 64), (65, 63), (127, 4), (4, 129), (257, 255), (1, 1500), (1300, 2), (513, 1025),
+                   (128, 32), (129, 33), (31, 31), (96, 64), (97, 127), (1000, 1000)):
         q = pool[rng.integers(0, len(pool), nq)].copy()
         t = pool[rng.integers(0, len(pool), nt)].copy()
         flip = rng.random((nt, 32)) < 0.05                      # perturb some train descriptors
@@ -632,6 +645,38 @@ def test_matcher_size_fuzz(gpu_lib, ob):
         _same(m.list_distances(q, t, off, idx), ob.list_distances(q, t, off, idx), f"list dist {nq}x{nt}")
         for init in (256, 30):
             _same(m.list_best2(q, t, off, idx, init), ob.list_best2(q, t, off, idx, init), f"list best2 {nq}x{nt} init={init}")
+
+
+@pytest.mark.parametrize("kernel", ["popcount", "mfma"])
+def test_bruteforce_batch_device_kernels(gpu_lib, ob, kernel):
+    """amos_match_bruteforce_best2_batch_device with ragged per-frame counts, both kernels, against the oracle."""
+    import torch
+    rng = np.random.default_rng(17)
+    cap, counts = 1100, [1000, 1, 0, 333, 1100, 97, 128, 31]
+    pool = _descs(rng, 200)
+    desc = np.zeros((len(counts), cap, 32), np.uint8)
+    for f, n in enumerate(counts):
+        desc[f, :n] = pool[rng.integers(0, len(pool), n)]
+        flip = rng.random((n, 32)) < 0.1
+        desc[f, :n] ^= (flip * rng.integers(0, 256, (n, 32))).astype(np.uint8)
+    desc[7, 31:] = 0xAB  # garbage beyond the count must not be matched
+    pq = np.array([0, 1, 2, 3, 4, 5, 6, 7, 0, 4, 3], np.int32)
+    pt = np.array([4, 0, 0, 2, 0, 6, 5, 7, 0, 4, 1], np.int32)
+    d_desc, d_counts = torch.from_numpy(desc).cuda(), torch.tensor(counts, dtype=torch.int32).cuda()
+    d_pq, d_pt = torch.from_numpy(pq).cuda(), torch.from_numpy(pt).cuda()
+    m = gpu_lib.OrbMatcher()
+    m.set_bruteforce_kernel(kernel)
+    for init in (256, 60, 2 ** 31 - 1):
+        d_out = torch.full((len(pq), cap, 4), -7, dtype=torch.int32).cuda()
+        torch.cuda.synchronize()
+        m.bruteforce_best2_batch_device(d_desc.data_ptr(), cap * 32, d_counts.data_ptr(), d_pq.data_ptr(), d_pt.data_ptr(), len(pq), cap, init, d_out.data_ptr())
+        m.sync()
+        got = d_out.cpu().numpy()
+        for p in range(len(pq)):
+            nq, nt = counts[pq[p]], counts[pt[p]]
+            want = ob.bruteforce_best2(desc[pq[p], :nq], desc[pt[p], :nt], init)
+            _same(got[p, :nq].view(gpu_lib.BEST2_DTYPE).reshape(-1), want, f"{kernel} pair {p} ({nq} x {nt}) init={init}")
+            assert (got[p, nq:] == -7).all(), "rows beyond the query count are not written"
 
 
 def test_match_consecutive_frames(gpu_lib, ob, synth):
