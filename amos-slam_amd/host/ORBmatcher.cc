@@ -13,9 +13,9 @@ using namespace std;
 namespace ORB_SLAM2
 {
 
-const int ORBmatcher::TH_HIGH = 100;
-const int ORBmatcher::TH_LOW = 50;
-const int ORBmatcher::HISTO_LENGTH = 30;
+const int AMOS_VIEW_MATCHER::TH_HIGH = 100;
+const int AMOS_VIEW_MATCHER::TH_LOW = 50;
+const int AMOS_VIEW_MATCHER::HISTO_LENGTH = 30;
 
 static void Check(int rc, const char *what)
 {
@@ -76,34 +76,39 @@ vector<size_t> FeatureGrid::GetFeaturesInArea(const float &x, const float &y, co
 }
 
 // ---------------------------------------------------------------------------------------------
-ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri), mpMatch(nullptr)
+AMOS_VIEW_MATCHER::AMOS_VIEW_MATCHER(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri), mpMatch(nullptr)
 {
     Check(amos_match_create(0, nullptr, &mpMatch), "amos_match_create");
 }
 
-ORBmatcher::~ORBmatcher()
+AMOS_VIEW_MATCHER::~AMOS_VIEW_MATCHER()
 {
     if (mpMatch) amos_match_destroy(mpMatch);
 }
 
-int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
+// ORBmatcher.cc:1913-1933: one pair.  Callers use it inside host loops (MapPoint::ComputeDistinctiveDescriptors,
+// Frame / KeyFrame bookkeeping), so a single pair is eight host popcounts, not a kernel launch; sets of descriptors
+// go through DescriptorDistances / the Search* functions (GPU).
+int AMOS_VIEW_MATCHER::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
 {
-    static std::mutex mtx;
-    static amos_match *shared = nullptr;
-    std::lock_guard<std::mutex> lock(mtx);
-    if (!shared) Check(amos_match_create(0, nullptr, &shared), "amos_match_create");
-    uint16_t d = 0;
-    Check(amos_match_distances(shared, a.ptr(), 1, b.ptr(), 1, &d), "amos_match_distances");
-    return d;
+    const unsigned char *pa = a.ptr(), *pb = b.ptr();
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t x, y;
+        memcpy(&x, pa + 4 * i, 4);
+        memcpy(&y, pb + 4 * i, 4);
+        dist += __builtin_popcount(x ^ y);
+    }
+    return dist;
 }
 
-void ORBmatcher::DescriptorDistances(const uint8_t *q, int nq, const uint8_t *t, int nt, std::vector<uint16_t> &out)
+void AMOS_VIEW_MATCHER::DescriptorDistances(const uint8_t *q, int nq, const uint8_t *t, int nt, std::vector<uint16_t> &out)
 {
     out.resize((size_t)nq * nt);
     Check(amos_match_distances(mpMatch, q, nq, t, nt, out.data()), "amos_match_distances");
 }
 
-void ORBmatcher::ListDistances(const amos_frame_view &train, const uint8_t *queries, int nq, const std::vector<int> &off,
+void AMOS_VIEW_MATCHER::ListDistances(const amos_frame_view &train, const uint8_t *queries, int nq, const std::vector<int> &off,
                                const std::vector<int> &idx, std::vector<uint16_t> &dist)
 {
     dist.resize(idx.size());
@@ -112,7 +117,7 @@ void ORBmatcher::ListDistances(const amos_frame_view &train, const uint8_t *quer
           "amos_match_list_distances");
 }
 
-void ORBmatcher::ListDistances(const uint8_t *train, int nt, const uint8_t *queries, int nq, const std::vector<int> &off,
+void AMOS_VIEW_MATCHER::ListDistances(const uint8_t *train, int nt, const uint8_t *queries, int nq, const std::vector<int> &off,
                                const std::vector<int> &idx, std::vector<uint16_t> &dist)
 {
     dist.resize(idx.size());
@@ -120,7 +125,7 @@ void ORBmatcher::ListDistances(const uint8_t *train, int nt, const uint8_t *quer
     Check(amos_match_list_distances(mpMatch, queries, nq, train, nt, off.data(), idx.data(), dist.data()), "amos_match_list_distances");
 }
 
-float ORBmatcher::RadiusByViewingCos(const float &viewCos)
+float AMOS_VIEW_MATCHER::RadiusByViewingCos(const float &viewCos)
 {
     if (viewCos > 0.998)
         return 2.5;
@@ -129,7 +134,7 @@ float ORBmatcher::RadiusByViewingCos(const float &viewCos)
 }
 
 // ORBmatcher.cc:1569-1728
-int ORBmatcher::SearchByProjection(const FeatureGrid &CurrentFrame, const vector<amos_proj_query> &vLastPoints, vector<int> &vnCurMatch,
+int AMOS_VIEW_MATCHER::SearchByProjection(const FeatureGrid &CurrentFrame, const vector<amos_proj_query> &vLastPoints, vector<int> &vnCurMatch,
                                    const vector<float> &mvScaleFactors, float mbf, const float th, const bool bForward, const bool bBackward)
 {
     const amos_frame_view &F = CurrentFrame.Frame();
@@ -209,7 +214,7 @@ int ORBmatcher::SearchByProjection(const FeatureGrid &CurrentFrame, const vector
 }
 
 // ORBmatcher.cc:70-175
-int ORBmatcher::SearchByProjection(const FeatureGrid &Fg, const vector<amos_map_query> &vpMapPoints, vector<int> &vnCurMatch,
+int AMOS_VIEW_MATCHER::SearchByProjection(const FeatureGrid &Fg, const vector<amos_map_query> &vpMapPoints, vector<int> &vnCurMatch,
                                    vector<bool> &vbCurHasObs, const vector<float> &mvScaleFactors, const float th)
 {
     const amos_frame_view &F = Fg.Frame();
@@ -270,7 +275,7 @@ int ORBmatcher::SearchByProjection(const FeatureGrid &Fg, const vector<amos_map_
 
 // ORBmatcher.cc:1731-1863 (relocalisation): window nPredictedLevel-1 .. +1, ANY occupied feature is skipped,
 // best only, accepted at bestDist <= ORBdist, rotation histogram pruning unconditional.
-int ORBmatcher::SearchByProjection(const FeatureGrid &CurrentFrame, const vector<amos_kf_query> &vKFPoints, vector<int> &vnCurMatch,
+int AMOS_VIEW_MATCHER::SearchByProjection(const FeatureGrid &CurrentFrame, const vector<amos_kf_query> &vKFPoints, vector<int> &vnCurMatch,
                                    const vector<float> &mvScaleFactors, const float th, const int ORBdist)
 {
     const amos_frame_view &F = CurrentFrame.Frame();
@@ -335,7 +340,7 @@ int ORBmatcher::SearchByProjection(const FeatureGrid &CurrentFrame, const vector
 // ORBmatcher.cc:230-382.  Candidates of a keyframe feature = the frame's features in the same vocabulary node,
 // in the FeatureVector's order; the two-iterator merge over the ascending node ids is the reference's
 // (lower_bound on a std::map = first node id >= the other side's).
-int ORBmatcher::SearchByBoW(const amos_bow_view &KF, const amos_bow_view &F, vector<int> &vnMatchesF)
+int AMOS_VIEW_MATCHER::SearchByBoW(const amos_bow_view &KF, const amos_bow_view &F, vector<int> &vnMatchesF)
 {
     vnMatchesF.assign(F.n, -1);
     // 1. candidate lists, in the order the reference visits the keyframe features
@@ -445,7 +450,7 @@ static void BowCandidates(const amos_bow_view &A, const amos_bow_view &B, Take1 
 }
 
 // ORBmatcher.cc:656-808
-int ORBmatcher::SearchByBoW(const amos_bow_view &KF1, const amos_bow_view &KF2, vector<int> &vnMatches12, const bool bBothKeyFrames)
+int AMOS_VIEW_MATCHER::SearchByBoW(const amos_bow_view &KF1, const amos_bow_view &KF2, vector<int> &vnMatches12, const bool bBothKeyFrames)
 {
     if (!bBothKeyFrames) return SearchByBoW(KF1, KF2, vnMatches12);
     vnMatches12.assign(KF1.n, -1);
@@ -508,7 +513,7 @@ int ORBmatcher::SearchByBoW(const amos_bow_view &KF1, const amos_bow_view &KF2, 
 }
 
 // ORBmatcher.cc:188-215 (no fused multiply-add: every product and sum rounds to float as written)
-bool ORBmatcher::CheckDistEpipolarLine(const amos_keypoint &kp1, const amos_keypoint &kp2, const float F12[9], float sigma2_kp2)
+bool AMOS_VIEW_MATCHER::CheckDistEpipolarLine(const amos_keypoint &kp1, const amos_keypoint &kp2, const float F12[9], float sigma2_kp2)
 {
     const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
     const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
@@ -521,7 +526,7 @@ bool ORBmatcher::CheckDistEpipolarLine(const amos_keypoint &kp1, const amos_keyp
 }
 
 // ORBmatcher.cc:810-1018
-int ORBmatcher::SearchForTriangulation(const amos_bow_view &KF1, const amos_bow_view &KF2, const float F12[9], float ex, float ey,
+int AMOS_VIEW_MATCHER::SearchForTriangulation(const amos_bow_view &KF1, const amos_bow_view &KF2, const float F12[9], float ex, float ey,
                                        const vector<float> &mvScaleFactors2, const vector<float> &mvLevelSigma2_2,
                                        vector<pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo)
 {
@@ -607,7 +612,7 @@ int ORBmatcher::SearchForTriangulation(const amos_bow_view &KF1, const amos_bow_
 // The candidate loop shared by Fuse (:1086-1127, :1252-1272), SearchByProjection(pKF, Scw, ...) (:466-494) and
 // SearchBySim3 (:1396-1420, :1476-1500): KeyFrame::GetFeaturesInArea(u, v, radius) has no level filter; the level
 // gate  kpLevel < nPredictedLevel-1 || kpLevel > nPredictedLevel  and Fuse's reprojection gate follow per candidate.
-void ORBmatcher::WindowCandidates(const FeatureGrid &KF, const vector<amos_window_query> &q, const vector<float> &mvScaleFactors, const float th,
+void AMOS_VIEW_MATCHER::WindowCandidates(const FeatureGrid &KF, const vector<amos_window_query> &q, const vector<float> &mvScaleFactors, const float th,
                                   const vector<float> *mvInvLevelSigma2, vector<int> &off, vector<int> &idx, vector<uint16_t> &dist)
 {
     const amos_frame_view &F = KF.Frame();
@@ -660,7 +665,7 @@ static int BestOfList(const vector<int> &off, const vector<int> &idx, const vect
 }
 
 // ORBmatcher.cc:1020-1177
-int ORBmatcher::Fuse(const FeatureGrid &KF, const vector<amos_window_query> &vpMapPoints, const vector<float> &mvScaleFactors,
+int AMOS_VIEW_MATCHER::Fuse(const FeatureGrid &KF, const vector<amos_window_query> &vpMapPoints, const vector<float> &mvScaleFactors,
                      const vector<float> &mvInvLevelSigma2, const float th, vector<int> &vnBestIdx)
 {
     vector<int> off, idx;
@@ -680,7 +685,7 @@ int ORBmatcher::Fuse(const FeatureGrid &KF, const vector<amos_window_query> &vpM
 }
 
 // ORBmatcher.cc:1179-1312
-int ORBmatcher::Fuse(const FeatureGrid &KF, const vector<amos_window_query> &vpPoints, const vector<float> &mvScaleFactors, const float th,
+int AMOS_VIEW_MATCHER::Fuse(const FeatureGrid &KF, const vector<amos_window_query> &vpPoints, const vector<float> &mvScaleFactors, const float th,
                      vector<int> &vnBestIdx)
 {
     vector<int> off, idx;
@@ -700,7 +705,7 @@ int ORBmatcher::Fuse(const FeatureGrid &KF, const vector<amos_window_query> &vpP
 }
 
 // ORBmatcher.cc:388-512
-int ORBmatcher::SearchByProjection(const FeatureGrid &KF, const vector<amos_window_query> &vpPoints, vector<int> &vnMatched,
+int AMOS_VIEW_MATCHER::SearchByProjection(const FeatureGrid &KF, const vector<amos_window_query> &vpPoints, vector<int> &vnMatched,
                                    const vector<float> &mvScaleFactors, const int th)
 {
     vector<int> off, idx;
@@ -726,7 +731,7 @@ int ORBmatcher::SearchByProjection(const FeatureGrid &KF, const vector<amos_wind
 }
 
 // ORBmatcher.cc:1314-1565
-int ORBmatcher::SearchBySim3(const FeatureGrid &KF1, const FeatureGrid &KF2, const vector<amos_window_query> &v1in2,
+int AMOS_VIEW_MATCHER::SearchBySim3(const FeatureGrid &KF1, const FeatureGrid &KF2, const vector<amos_window_query> &v1in2,
                              const vector<amos_window_query> &v2in1, const vector<float> &mvScaleFactors1, const vector<float> &mvScaleFactors2,
                              vector<int> &vnMatches12, const float th)
 {
@@ -762,7 +767,7 @@ int ORBmatcher::SearchBySim3(const FeatureGrid &KF1, const FeatureGrid &KF2, con
 }
 
 // ORBmatcher.cc:515-643
-int ORBmatcher::SearchForInitialization(const amos_frame_view &F1, const FeatureGrid &F2g, vector<cv::Point2f> &vbPrevMatched,
+int AMOS_VIEW_MATCHER::SearchForInitialization(const amos_frame_view &F1, const FeatureGrid &F2g, vector<cv::Point2f> &vbPrevMatched,
                                         vector<int> &vnMatches12, int windowSize)
 {
     const amos_frame_view &F2 = F2g.Frame();
@@ -844,7 +849,7 @@ int ORBmatcher::SearchForInitialization(const amos_frame_view &F1, const Feature
 }
 
 // ORBmatcher.cc:1866-1908
-void ORBmatcher::ComputeThreeMaxima(vector<int> *histo, const int L, int &ind1, int &ind2, int &ind3)
+void AMOS_VIEW_MATCHER::ComputeThreeMaxima(vector<int> *histo, const int L, int &ind1, int &ind2, int &ind3)
 {
     int max1 = 0, max2 = 0, max3 = 0;
     for (int i = 0; i < L; i++) {

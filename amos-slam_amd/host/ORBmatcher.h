@@ -38,13 +38,21 @@ private:
     std::vector<size_t> mGrid[AMOS_FRAME_GRID_COLS][AMOS_FRAME_GRID_ROWS];
 };
 
-class ORBmatcher
+// Inside the reference tree (AMOS_REFERENCE_TREE) the name ORBmatcher belongs to the class of ORBmatcher_adaptors.h,
+// which carries the reference's signatures and derives from this one.
+#ifdef AMOS_REFERENCE_TREE
+#define AMOS_VIEW_MATCHER ORBmatcherViews
+#else
+#define AMOS_VIEW_MATCHER ORBmatcher
+#endif
+
+class AMOS_VIEW_MATCHER
 {
 public:
-    ORBmatcher(float nnratio = 0.6, bool checkOri = true);
-    ~ORBmatcher();
-    ORBmatcher(const ORBmatcher &) = delete;
-    ORBmatcher &operator=(const ORBmatcher &) = delete;
+    AMOS_VIEW_MATCHER(float nnratio = 0.6, bool checkOri = true);
+    ~AMOS_VIEW_MATCHER();
+    AMOS_VIEW_MATCHER(const AMOS_VIEW_MATCHER &) = delete;
+    AMOS_VIEW_MATCHER &operator=(const AMOS_VIEW_MATCHER &) = delete;
 
     // ORBmatcher.cc:1913: one pair.  (Batches go through DescriptorDistances; a single pair still
     // runs on the device so that there is one implementation of the distance.)

@@ -1,6 +1,8 @@
 // host_capi.cc -- C entry points that drive the C++ drop-in classes (ORB_SLAM2::ORBextractor,
 // ORB_SLAM2::ORBmatcher) so that the Python parity tests can exercise the reference-shaped API
 // itself, not only the C ABI underneath it.  Test harness, not part of the drop-in surface.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <exception>
 #include <string>
@@ -9,9 +11,16 @@
 #include "../../include/amos_host_types.h"
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
+#include "ORBmatcher_adaptors.h"
+#include "../../tests/host/ref_standins.h"
 #include "yolact.h"
 
 using namespace ORB_SLAM2;
+
+// Every member of the reference-signature matcher is compiled against the stand-in classes (the reference tree
+// instantiates the same template with its own Frame / KeyFrame / MapPoint).
+template class ORB_SLAM2::ORBmatcherFor<amos_standins::Frame, amos_standins::KeyFrame, amos_standins::MapPoint>;
+typedef ORB_SLAM2::ORBmatcherFor<amos_standins::Frame, amos_standins::KeyFrame, amos_standins::MapPoint> RefMatcher;
 
 static thread_local std::string g_host_error;
 
@@ -265,6 +274,116 @@ int amos_host_search_for_initialization(const amos_frame_view *f1, const amos_fr
 }
 
 // ORB_SLAM2::yolact: construct once per (py file, weights), evaluate one BGR frame
+// ---- the reference-signature adaptors (ORBmatcher_adaptors.h) on stand-in Frame / MapPoint objects built from arrays
+
+struct amos_test_camera {
+    float fx, fy, cx, cy, mb, mbf;
+    float min_x, max_x, min_y, max_y;
+    float Tcw[16];
+    int32_t n_levels;
+    float scale_factors[AMOS_MAX_LEVELS];
+};
+
+static void fill_frame(amos_standins::Frame &F, const amos_test_camera *cam, int n, const amos_keypoint *keys, const amos_keypoint *keys_un,
+                       const uint8_t *desc, const float *u_right)
+{
+    F.N = n;
+    F.mvKeys.resize(n);
+    F.mvKeysUn.resize(n);
+    if (n) {
+        std::memcpy(F.mvKeys.data(), keys, sizeof(amos_keypoint) * n);
+        std::memcpy(F.mvKeysUn.data(), keys_un, sizeof(amos_keypoint) * n);
+    }
+    F.mDescriptors = cv::Mat(std::max(n, 1), 32, CV_8U);
+    if (n) std::memcpy(F.mDescriptors.data, desc, (size_t)32 * n);
+    if (u_right) F.mvuRight.assign(u_right, u_right + n);
+    F.mvpMapPoints.assign(n, nullptr);
+    F.mvbOutlier.assign(n, false);
+    F.fx = cam->fx; F.fy = cam->fy; F.cx = cam->cx; F.cy = cam->cy; F.mb = cam->mb; F.mbf = cam->mbf;
+    F.mnMinX = cam->min_x; F.mnMaxX = cam->max_x; F.mnMinY = cam->min_y; F.mnMaxY = cam->max_y;
+    F.mTcw = cv::Mat(4, 4, CV_32F);
+    std::memcpy(F.mTcw.data, cam->Tcw, sizeof(float) * 16);
+    F.mnScaleLevels = cam->n_levels;
+    F.mvScaleFactors.assign(cam->scale_factors, cam->scale_factors + cam->n_levels);
+    F.mfLogScaleFactor = cam->n_levels > 1 ? std::log(cam->scale_factors[1]) : 1.f;
+}
+
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) with the reference's signature.
+// Last frame: per feature has_point / outlier / world position / descriptor / observation count of its map point.
+// cur_occupant_obs[i2]: -1 = CurrentFrame.mvpMapPoints[i2] NULL on entry, else the Observations() of an occupant.
+// Out: cur_match[i2] = index of the last-frame feature whose map point ends up in CurrentFrame.mvpMapPoints[i2],
+// -1 for NULL, -2 for an untouched occupant.
+int amos_host_ref_search_last_frame(const amos_test_camera *cur_cam, int n_cur, const amos_keypoint *cur_keys_un, const uint8_t *cur_desc,
+                                    const float *cur_u_right, const int32_t *cur_occupant_obs, const amos_test_camera *last_cam, int n_last,
+                                    const amos_keypoint *last_keys, const amos_keypoint *last_keys_un, const uint8_t *last_has_point,
+                                    const uint8_t *last_outlier, const float *last_world /* n x 3 */, const uint8_t *last_mp_desc /* n x 32 */,
+                                    const int32_t *last_mp_obs, float th, int mono, float nnratio, int check_orientation, int32_t *cur_match)
+{
+    AMOS_HOST_TRY
+    using namespace amos_standins;
+    Frame Cur, Last;
+    fill_frame(Cur, cur_cam, n_cur, cur_keys_un, cur_keys_un, cur_desc, cur_u_right);
+    std::vector<uint8_t> none((size_t)32 * std::max(n_last, 1), 0);
+    fill_frame(Last, last_cam, n_last, last_keys, last_keys_un, none.data(), nullptr);
+    std::vector<MapPoint> pts(n_last), occupants(n_cur);
+    for (int i = 0; i < n_last; i++) {
+        if (!last_has_point[i]) continue;
+        MapPoint &p = pts[i];
+        for (int k = 0; k < 3; k++) p.mWorldPos.at<float>(k, 0) = last_world[3 * i + k];
+        std::memcpy(p.mDescriptor.data, last_mp_desc + 32 * (size_t)i, 32);
+        p.mnObs = last_mp_obs[i];
+        Last.mvpMapPoints[i] = &p;
+        Last.mvbOutlier[i] = last_outlier[i] != 0;
+    }
+    for (int i2 = 0; i2 < n_cur; i2++)
+        if (cur_occupant_obs && cur_occupant_obs[i2] >= 0) {
+            occupants[i2].mnObs = cur_occupant_obs[i2];
+            Cur.mvpMapPoints[i2] = &occupants[i2];
+        }
+    RefMatcher matcher(nnratio, check_orientation != 0);
+    const int n = matcher.SearchByProjection(Cur, Last, th, mono != 0);
+    for (int i2 = 0; i2 < n_cur; i2++) {
+        MapPoint *p = Cur.mvpMapPoints[i2];
+        if (!p) cur_match[i2] = -1;
+        else if (p >= pts.data() && p < pts.data() + n_last) cur_match[i2] = (int32_t)(p - pts.data());
+        else cur_match[i2] = -2;
+    }
+    return n;
+    AMOS_HOST_CATCH
+}
+
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) with the reference's signature:
+// the map points carry the mTrack* members Tracking::SearchLocalPoints fills.  cur_match[i] = index into the point list or -1.
+int amos_host_ref_search_local_points(const amos_test_camera *cam, int n, const amos_keypoint *keys_un, const uint8_t *desc, const float *u_right,
+                                      const amos_map_query *points, const uint8_t *in_view, const uint8_t *bad, int n_points, float th, float nnratio,
+                                      int32_t *cur_match)
+{
+    AMOS_HOST_TRY
+    using namespace amos_standins;
+    Frame F;
+    fill_frame(F, cam, n, keys_un, keys_un, desc, u_right);
+    std::vector<MapPoint> pts(n_points);
+    std::vector<MapPoint *> vp(n_points);
+    for (int i = 0; i < n_points; i++) {
+        MapPoint &p = pts[i];
+        p.mbTrackInView = in_view[i] != 0;
+        p.mbBad = bad[i] != 0;
+        p.mTrackProjX = points[i].proj_x;
+        p.mTrackProjY = points[i].proj_y;
+        p.mTrackProjXR = points[i].proj_xr;
+        p.mTrackViewCos = points[i].view_cos;
+        p.mnTrackScaleLevel = points[i].level;
+        p.mnObs = points[i].has_obs;
+        std::memcpy(p.mDescriptor.data, points[i].desc, 32);
+        vp[i] = &p;
+    }
+    RefMatcher matcher(nnratio, true);
+    const int nm = matcher.SearchByProjection(F, vp, th);
+    for (int i = 0; i < n; i++) cur_match[i] = F.mvpMapPoints[i] ? (int32_t)(F.mvpMapPoints[i] - pts.data()) : -1;
+    return nm;
+    AMOS_HOST_CATCH
+}
+
 int amos_host_yolact_eval(const char *py_file, const char *weights, const uint8_t *bgr, int w, int h, uint8_t *mask_out, int *mask_w,
                           int *mask_h)
 {

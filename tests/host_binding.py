@@ -279,3 +279,50 @@ def host_yolact_eval(py_file, weights, bgr):
                                       C.byref(mh)))
     assert (mh.value, mw.value) == (h, w)
     return out
+
+
+# ---- the reference-signature adaptors (amos-slam_amd/host/ORBmatcher_adaptors.h) on stand-in Frame / MapPoint objects
+
+class TestCamera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("mb", C.c_float), ("mbf", C.c_float),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float), ("Tcw", C.c_float * 16),
+                ("n_levels", C.c_int32), ("scale_factors", C.c_float * 16)]
+
+
+def test_camera(Tcw, scale_factors, fx=535.4, fy=539.2, cx=320.1, cy=247.6, mb=0.08, mbf=40.0, bounds=(0.0, 640.0, 0.0, 480.0)):
+    cam = TestCamera(fx, fy, cx, cy, mb, mbf, *bounds)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    for i in range(16):
+        cam.Tcw[i] = float(T[i])
+    cam.n_levels = len(scale_factors)
+    for i, s in enumerate(scale_factors):
+        cam.scale_factors[i] = float(s)
+    return cam
+
+
+def ref_search_last_frame(cur_cam, cur_keys_un, cur_desc, cur_u_right, cur_occupant_obs, last_cam, last_keys, last_keys_un, has_point, outlier,
+                          world, mp_desc, mp_obs, th, mono, nnratio=0.9, check_ori=True):
+    """ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono), reference signature."""
+    ck, cd = np.ascontiguousarray(cur_keys_un, KP), np.ascontiguousarray(cur_desc, np.uint8)
+    cur = None if cur_u_right is None else np.ascontiguousarray(cur_u_right, np.float32)
+    occ = None if cur_occupant_obs is None else np.ascontiguousarray(cur_occupant_obs, np.int32)
+    lk, lku = np.ascontiguousarray(last_keys, KP), np.ascontiguousarray(last_keys_un, KP)
+    hp, ol = np.ascontiguousarray(has_point, np.uint8), np.ascontiguousarray(outlier, np.uint8)
+    w, md, mo = np.ascontiguousarray(world, np.float32), np.ascontiguousarray(mp_desc, np.uint8), np.ascontiguousarray(mp_obs, np.int32)
+    match = np.zeros(max(len(ck), 1), np.int32)
+    r = _chk(host().amos_host_ref_search_last_frame(C.byref(cur_cam), C.c_int(len(ck)), _p(ck), _p(cd), _p(cur), _p(occ), C.byref(last_cam),
+                                                   C.c_int(len(lk)), _p(lk), _p(lku), _p(hp), _p(ol), _p(w), _p(md), _p(mo), C.c_float(th),
+                                                   C.c_int(int(mono)), C.c_float(nnratio), C.c_int(int(check_ori)), _p(match)))
+    return r, match[:len(ck)]
+
+
+def ref_search_local_points(cam, keys_un, desc, u_right, points, in_view, bad, th, nnratio=0.8):
+    """ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th), reference signature."""
+    k, d = np.ascontiguousarray(keys_un, KP), np.ascontiguousarray(desc, np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    pts = np.ascontiguousarray(points, MAP_QUERY)
+    iv, bd = np.ascontiguousarray(in_view, np.uint8), np.ascontiguousarray(bad, np.uint8)
+    match = np.zeros(max(len(k), 1), np.int32)
+    r = _chk(host().amos_host_ref_search_local_points(C.byref(cam), C.c_int(len(k)), _p(k), _p(d), _p(ur), _p(pts), _p(iv), _p(bd), C.c_int(len(pts)),
+                                                      C.c_float(th), C.c_float(nnratio), _p(match)))
+    return r, match[:len(k)]

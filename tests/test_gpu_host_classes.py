@@ -400,3 +400,123 @@ def test_resident_search_with_distorted_camera(gpu_lib, ob, synth):
             assert np.array_equal(got[:, c], want[name]), (p, name)
         found += int((want["best_idx"] >= 0).sum())
     assert found > 500
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference-signature adaptors (amos-slam_amd/host/ORBmatcher_adaptors.h), end to end on stand-in
+# Frame / MapPoint objects (tests/host/ref_standins.h) against the oracle.
+
+def _project_like_the_adaptor(T, world, fx, fy, cx, cy):
+    """`Rcw*x3Dw+tcw` as OpenCV evaluates it for CV_32F (one gemm: double accumulation, one rounding), then the
+    reference's float arithmetic (ORBmatcher.cc:1613-1622): xc, yc, invzc = 1.0/zc (double division stored to float),
+    u = fx*xc*invzc+cx with every product and sum rounded to float (the host library is built with -ffp-contract=off)."""
+    T = np.asarray(T, np.float32).reshape(4, 4)
+    R, t = T[:3, :3].astype(np.float64), T[:3, 3].astype(np.float64)
+    w = np.asarray(world, np.float32).astype(np.float64)
+    cam = (w @ R.T + t).astype(np.float32)
+    xc, yc, zc = cam[:, 0], cam[:, 1], cam[:, 2]
+    with np.errstate(divide="ignore"):
+        invz = (1.0 / zc.astype(np.float64)).astype(np.float32)
+    u = (np.float32(fx) * xc) * invz + np.float32(cx)
+    v = (np.float32(fy) * yc) * invz + np.float32(cy)
+    return u.astype(np.float32), v.astype(np.float32), invz
+
+
+def _pose(rx, ry, rz, t):
+    cx_, sx = np.cos(rx), np.sin(rx)
+    cy_, sy = np.cos(ry), np.sin(ry)
+    cz, sz = np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx_, -sx], [0, sx, cx_]])
+    Ry = np.array([[cy_, 0, sy], [0, 1, 0], [-sy, 0, cy_]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = t
+    return T.astype(np.float32)
+
+
+@pytest.mark.parametrize("motion", ["sideways", "forward", "backward", "mono"])
+def test_reference_signature_search_by_projection_last_frame(hb, ob, synth, motion):
+    """int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+    (src/ORBmatcher.cc:1569) exactly as Tracking::TrackWithMotionModel calls it: the adaptor projects LastFrame's map
+    points with CurrentFrame.mTcw, derives bForward / bBackward from the two poses, runs the search and writes
+    CurrentFrame.mvpMapPoints.  Expected result: the oracle's orc_search_by_projection_frame on queries computed here."""
+    k0, d0, k1, d1, sf = _two_frames(ob, synth, stream=23)
+    rng = np.random.default_rng(11)
+    fx, fy, cx, cy, mb, mbf = 535.4, 539.2, 320.1, 247.6, 0.08, 40.0
+    n0, n1 = len(k0), len(k1)
+    # last frame at the origin; its map points = back-projected keypoints at random depths
+    T_last = _pose(0.002, -0.003, 0.001, [0.01, -0.02, 0.005])
+    depth = rng.uniform(0.8, 6.0, n0)
+    ray = np.stack([(k0["x"] - cx) / fx, (k0["y"] - cy) / fy, np.ones(n0)], 1) * depth[:, None]
+    Tl = T_last.astype(np.float64)
+    world = ((ray - Tl[:3, 3]) @ Tl[:3, :3]).astype(np.float32)  # Rlw^T (x_l - tlw)
+    dz = {"sideways": 0.0, "forward": -0.5, "backward": 0.5, "mono": -0.5}[motion]  # camera moves along +z <=> tcw.z decreases
+    T_cur = (_pose(0.001, 0.002, -0.001, [0.004, 0.002, dz]).astype(np.float64) @ Tl).astype(np.float32)
+    has_point = rng.random(n0) < 0.8
+    outlier = rng.random(n0) < 0.1
+    obs = np.where(rng.random(n0) < 0.6, rng.integers(1, 5, n0), 0).astype(np.int32)
+    world[5] = [0, 0, -3]  # behind the camera: invzc < 0
+    ur = np.where(rng.random(n1) < 0.7, k1["x"] - rng.uniform(5, 40, n1).astype(np.float32), np.float32(-1)).astype(np.float32)
+    cur_cam, last_cam = hb.test_camera(T_cur, sf, fx, fy, cx, cy, mb, mbf), hb.test_camera(T_last, sf, fx, fy, cx, cy, mb, mbf)
+    # what the oracle is given: the queries the adaptor should have built (ORBmatcher.cc:1604-1625), in feature order
+    u, v, invz = _project_like_the_adaptor(T_cur, world, fx, fy, cx, cy)
+    ok = has_point & ~outlier & ~(invz < 0) & ~(u < 0) & ~(u > 640) & ~(v < 0) & ~(v > 480)
+    src = np.nonzero(ok)[0]
+    q = np.zeros(len(src), hb.PROJ_QUERY)
+    q["u"], q["v"], q["invz"] = u[src], v[src], invz[src]
+    q["octave"], q["angle"], q["desc"], q["has_obs"] = k0["octave"][src], k0["angle"][src], d0[src], obs[src] > 0
+    # bForward / bBackward (ORBmatcher.cc:1588-1599): tlc = Rlw * twc + tlw, twc = -Rcw^T tcw
+    Tc, Tl64 = T_cur.astype(np.float64), T_last.astype(np.float64)
+    twc = (-(Tc[:3, :3].T @ Tc[:3, 3])).astype(np.float32).astype(np.float64)
+    tlc = (Tl64[:3, :3] @ twc + Tl64[:3, 3]).astype(np.float32)
+    mono = motion == "mono"
+    forward, backward = bool(tlc[2] > mb and not mono), bool(-tlc[2] > mb and not mono)
+    assert (forward, backward) == {"sideways": (False, False), "forward": (True, False), "backward": (False, True), "mono": (False, False)}[motion]
+    view, keep = hb.frame_view(k1, d1, ur)
+    for th in (7.0, 15.0):
+        want_n, want = hb.search_frame("oracle", view, q, np.full(n1, -1, np.int32), sf, mbf, th, int(forward), int(backward))
+        got_n, got = hb.ref_search_last_frame(cur_cam, k1, d1, ur, None, last_cam, k0, k0, has_point, outlier, world, d0, obs, th, mono)
+        want_feat = np.where(want >= 0, src[np.maximum(want, 0)], -1)  # query index -> last-frame feature index
+        assert got_n == want_n and np.array_equal(got, want_feat)
+        assert got_n > 30
+    # occupants present on entry (not what Tracking does, but what the signature allows): those with observations block
+    # their feature, the others may be overwritten
+    occ = np.where(rng.random(n1) < 0.15, rng.integers(0, 3, n1), -1).astype(np.int32)
+    cur0 = np.full(n1, -1, np.int32)
+    q2 = np.concatenate([q, np.zeros(int((occ >= 0).sum()), hb.PROJ_QUERY)])
+    q2["u"][len(q):], q2["v"][len(q):] = -1.0e9, -1.0e9
+    q2["has_obs"][len(q):] = occ[occ >= 0] > 0
+    cur0[occ >= 0] = len(q) + np.arange(int((occ >= 0).sum()))
+    want_n, want = hb.search_frame("oracle", view, q2, cur0, sf, mbf, 15.0, int(forward), int(backward))
+    got_n, got = hb.ref_search_last_frame(cur_cam, k1, d1, ur, occ, last_cam, k0, k0, has_point, outlier, world, d0, obs, 15.0, mono)
+    want_feat = np.where(want >= len(q), -2, np.where(want >= 0, src[np.clip(want, 0, len(src) - 1)], -1))
+    assert got_n == want_n and np.array_equal(got, want_feat)
+    assert ((occ > 0) <= (got == -2)).all(), "an occupant with observations is never displaced"
+
+
+def test_reference_signature_search_by_projection_local_points(hb, ob, synth):
+    """int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint*> &vpMapPoints, const float th)
+    (src/ORBmatcher.cc:70): mbTrackInView / isBad filter, the mTrack* members, F.mvpMapPoints written back."""
+    k0, d0, k1, d1, sf = _two_frames(ob, synth, stream=24)
+    rng = np.random.default_rng(12)
+    n0, n1 = len(k0), len(k1)
+    ur = np.where(rng.random(n1) < 0.5, k1["x"] - 20, -1).astype(np.float32)
+    pts = np.zeros(n0, hb.MAP_QUERY)
+    pts["proj_x"], pts["proj_y"] = k0["x"] - 2, k0["y"] - 1
+    pts["proj_xr"] = pts["proj_x"] - 20 + rng.normal(0, 3, n0).astype(np.float32)
+    pts["view_cos"] = rng.choice([0.9, 0.999], n0).astype(np.float32)
+    pts["level"] = np.maximum(k0["octave"], 0)
+    pts["has_obs"] = rng.integers(0, 3, n0)
+    pts["desc"] = d0
+    in_view, bad = rng.random(n0) < 0.85, rng.random(n0) < 0.05
+    src = np.nonzero(in_view & ~bad)[0]
+    cam = hb.test_camera(np.eye(4), sf)
+    view, keep = hb.frame_view(k1, d1, ur)
+    q = pts[src].copy()
+    q["has_obs"] = q["has_obs"] > 0
+    for th in (1.0, 3.0):
+        want_n, want, _ = hb.search_points("oracle", view, q, np.full(n1, -1, np.int32), np.zeros(n1, np.uint8), sf, th)
+        got_n, got = hb.ref_search_local_points(cam, k1, d1, ur, pts, in_view, bad, th)
+        assert got_n == want_n and np.array_equal(got, np.where(want >= 0, src[np.maximum(want, 0)], -1))
+    assert got_n > 50
