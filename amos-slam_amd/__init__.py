@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device",
 ]
 
 
@@ -385,6 +385,12 @@ class MaskPreprocessor:
     def run(self, d_bgr, n_frames, d_out):
         _check(self.L.amos_mask_preprocess_batch_device(self.p, C.c_void_p(d_bgr), C.c_int(n_frames), C.c_void_p(d_out)),
                "amos_mask_preprocess_batch_device")
+
+
+def mask_bias_act(stream_ptr, y_ptr, bias_ptr, residual_ptr, n, channels, relu):
+    """amos_mask_bias_act_device: y = act((y + bias[c]) + residual) in place on an NHWC float32 tensor (device pointers)."""
+    _check(lib().amos_mask_bias_act_device(C.c_void_p(stream_ptr), C.c_void_p(y_ptr), C.c_void_p(bias_ptr), C.c_void_p(residual_ptr), C.c_size_t(n),
+                                           C.c_int(channels), C.c_int(int(relu))), "amos_mask_bias_act_device")
 
 
 def image_bounds(width, height, fx, fy, cx, cy, dist_coef):

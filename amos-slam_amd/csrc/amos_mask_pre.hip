@@ -87,6 +87,37 @@ __global__ __launch_bounds__(256) void k_mask_pre_c(const float *__restrict__ ba
     }
 }
 
+
+// ---- epilogue of a convolution of the mask network, fused: y = act(y + bias[c] (+ residual)), in place, on an NHWC
+// (channels-last) float tensor.  MIOpen's convolutions take no bias and PyTorch adds it, the residual and the ReLU as
+// one elementwise pass each over the activations (three reads + three writes of the tensor per bottleneck output);
+// this is one read (+ the residual) and one write.  Sums in the order (y + b) + r, like the unfused ops: same bits.
+// grid = ceil(n / 4 / 256), block = 256; kVec: channels % 4 == 0 and 16-byte aligned pointers.
+template <bool kVec>
+__global__ __launch_bounds__(256) void k_bias_act(float *__restrict__ y, const float *__restrict__ bias, const float *__restrict__ res, size_t n,
+                                                 int channels, int relu)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (kVec) {
+        float4 v = *reinterpret_cast<const float4 *>(y + i);
+        const float4 b = *reinterpret_cast<const float4 *>(bias + (i % (size_t)channels));
+        v.x = __fadd_rn(v.x, b.x); v.y = __fadd_rn(v.y, b.y); v.z = __fadd_rn(v.z, b.z); v.w = __fadd_rn(v.w, b.w);
+        if (res) {
+            const float4 r = *reinterpret_cast<const float4 *>(res + i);
+            v.x = __fadd_rn(v.x, r.x); v.y = __fadd_rn(v.y, r.y); v.z = __fadd_rn(v.z, r.z); v.w = __fadd_rn(v.w, r.w);
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4 *>(y + i) = v;
+    } else {
+        for (size_t k = i; k < n && k < i + 4; k++) {
+            float v = __fadd_rn(y[k], bias[k % (size_t)channels]);
+            if (res) v = __fadd_rn(v, res[k]);
+            y[k] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
 }  // namespace amos
 
 using namespace amos;
@@ -195,6 +226,19 @@ int amos_mask_preprocess_batch_device(amos_mask_pre *p, const uint8_t *d_bgr, in
                        p->dFixY, p->dLut, p->dMid);
     hipLaunchKernelGGL(k_mask_pre_b, dim3((kBackW * kBackH + 255) / 256, n_frames), dim3(256), 0, p->stream, p->dMid, p->dFltX, p->dFltY, p->dBack);
     hipLaunchKernelGGL(k_mask_pre_c, dim3((kNetSize * kNetSize + 255) / 256, n_frames), dim3(256), 0, p->stream, p->dBack, d_out);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+
+int amos_mask_bias_act_device(void *stream, float *d_y, const float *d_bias, const float *d_residual, size_t n, int channels, int relu)
+{
+    if (!d_y || !d_bias || channels < 1 || n % (size_t)channels != 0) { set_error("amos_mask_bias_act_device: invalid argument"); return AMOS_ERR_INVALID; }
+    if (n == 0) return AMOS_OK;
+    const bool vec = channels % 4 == 0 && ((uintptr_t)d_y | (uintptr_t)d_bias | (uintptr_t)d_residual) % 16 == 0;
+    const dim3 grid((unsigned)((n / 4 + 256) / 256)), block(256);
+    if (vec) hipLaunchKernelGGL(k_bias_act<true>, grid, block, 0, (hipStream_t)stream, d_y, d_bias, d_residual, n, channels, relu);
+    else hipLaunchKernelGGL(k_bias_act<false>, grid, block, 0, (hipStream_t)stream, d_y, d_bias, d_residual, n, channels, relu);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }

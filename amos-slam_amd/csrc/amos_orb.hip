@@ -586,6 +586,8 @@ int amos_orb_create(const amos_orb_params *params, int max_width, int max_height
             dx[i] = (int)lrint(cc * std::sqrt((r * r - dy * dy) * inv_r2));
         }
     }
+    for (int i = 0; i < 31; i++)  // k_morph31 is written for these row widths (getStructuringElement(MORPH_ELLIPSE, 31 x 31))
+        if (dx[i] != kMorphDx[std::abs(i - 15)]) { set_error("ellipse row %d: half-width %d, kernel expects %d", i, dx[i], kMorphDx[std::abs(i - 15)]); amos_orb_destroy(h); return AMOS_ERR_INVALID; }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pat, sizeof(pat)) != hipSuccess ||
         hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(int) * 16) != hipSuccess ||
         hipMemcpyToSymbol(HIP_SYMBOL(c_ellipse_dx), dx, sizeof(dx)) != hipSuccess) {
@@ -783,7 +785,7 @@ int amos_orb_gate(amos_orb *h, const uint8_t *mask, size_t mask_stride, const do
         AMOS_HIP_CHECK(hipMemcpyAsync(h->dRm, rm_vector, sizeof(int) * n_rm, hipMemcpyHostToDevice, h->stream));
     }
     AMOS_HIP_CHECK(hipMemsetAsync(h->dErr, 0, sizeof(int), h->stream));
-    dim3 grid((g.W + 63) / 64, (g.H + 15) / 16);
+    dim3 grid((g.W + kMorphTileW - 1) / kMorphTileW, (g.H + kMorphTileH - 1) / kMorphTileH);
     hipLaunchKernelGGL(k_morph31<true>, grid, dim3(256), 0, h->stream, h->dMask, (size_t)0, h->maskPitch, h->dMaskTmp, (size_t)0, h->maskPitch, g.W, g.H);
     hipLaunchKernelGGL(k_morph31<false>, grid, dim3(256), 0, h->stream, h->dMaskTmp, (size_t)0, h->maskPitch, h->dMaskClosed, (size_t)0, h->maskPitch, g.W, g.H);
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(256), 0, h->stream, h->dGeom, h->dLvKps, h->dLvCount, h->dMaskClosed, (size_t)0, h->maskPitch,
@@ -896,7 +898,7 @@ int amos_orb_gate_batch_device(amos_orb *h, const uint8_t *d_masks, size_t mask_
     AMOS_HIP_CHECK(hipSetDevice(h->device));
     const Geom &g = h->geom;
     const size_t planeStride = (size_t)h->maskPitch * h->maxH;
-    dim3 grid((g.W + 63) / 64, (g.H + 15) / 16, h->nFrames);
+    dim3 grid((g.W + kMorphTileW - 1) / kMorphTileW, (g.H + kMorphTileH - 1) / kMorphTileH, h->nFrames);
     AMOS_HIP_CHECK(hipMemsetAsync(h->dErr, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(k_morph31<true>, grid, dim3(256), 0, h->stream, d_masks, mask_frame_stride, (int)mask_row_stride, h->dMaskTmp, planeStride,
                        h->maskPitch, g.W, g.H);

@@ -23,6 +23,28 @@ PRED_SCALES = (24, 48, 96, 192, 384)   # one scale per pyramid level
 ASPECT_RATIOS = (1.0, 0.5, 2.0)        # pred_aspect_ratios; anchors are squares (use_square_anchors)
 
 
+def conv_bias_act(conv, x, relu, residual=None):
+    """conv -> + bias -> (+ residual) -> (ReLU).  On the GPU with float32 channels-last activations the bias, the residual
+    and the ReLU are ONE in-place pass by a HIP kernel of this project (amos_mask_bias_act_device) behind MIOpen's
+    convolution instead of PyTorch's three elementwise passes; the summation order is the same, so are the bits.
+    Anywhere else (CPU tests, autocast) the plain torch ops run."""
+    if x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and not torch.is_autocast_enabled():
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        cl = torch.channels_last
+        if y.dtype == torch.float32 and y.is_contiguous(memory_format=cl) and (residual is None or (
+                residual.shape == y.shape and residual.dtype == torch.float32 and residual.is_contiguous(memory_format=cl))):
+            from .. import mask_bias_act
+            mask_bias_act(torch.cuda.current_stream(x.device).cuda_stream, y.data_ptr(), conv.bias.data_ptr(),
+                          residual.data_ptr() if residual is not None else None, y.numel(), y.shape[1], relu)
+            return y
+        y = y + conv.bias.view(1, -1, 1, 1)
+    else:
+        y = conv(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
 def _fold(conv, bn):
     """conv followed by an inference-mode batch norm == one conv with scaled weights and a bias:
     w' = w * g / sqrt(var + eps),  b' = beta - mean * g / sqrt(var + eps)   (folded in float64, stored float32)."""
@@ -56,6 +78,11 @@ class Bottleneck(nn.Module):
                                             nn.BatchNorm2d(planes * 4))
 
     def forward(self, x):
+        if self.conv1.bias is not None:  # batch norms folded: conv -> fused (bias, residual, ReLU)
+            y = conv_bias_act(self.conv1, x, True)
+            y = conv_bias_act(self.conv2, y, True)
+            identity = x if self.downsample is None else conv_bias_act(self.downsample[0], x, False)
+            return conv_bias_act(self.conv3, y, True, residual=identity)
         y = F.relu(self.bn1(self.conv1(x)))
         y = F.relu(self.bn2(self.conv2(y)))
         y = self.bn3(self.conv3(y))
@@ -95,7 +122,8 @@ class ResNet50Trunk(nn.Module):
                 block.fold_batch_norms()
 
     def forward(self, x):
-        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
+        x = conv_bias_act(self.conv1, x, True) if self.conv1.bias is not None else F.relu(self.bn1(self.conv1(x)))
+        x = F.max_pool2d(x, 3, stride=2, padding=1)
         outs = []
         for layer in self.layers:
             x = layer(x)
@@ -125,7 +153,7 @@ class FeaturePyramid(nn.Module):
         outs = [None] * n
         for k, pred in enumerate(self.pred_layers):
             j = n - 1 - k
-            outs[j] = F.relu(pred(merged[j]))
+            outs[j] = conv_bias_act(pred, merged[j], True)
         for down in self.downsample_layers:
             outs.append(down(outs[-1]))
         return outs
@@ -143,7 +171,7 @@ class SharedHead(nn.Module):
 
     def forward(self, x):
         b = x.shape[0]
-        x = self.upfeature(x)
+        x = conv_bias_act(self.upfeature[0], x, True)
         loc = self.bbox_layer(x).permute(0, 2, 3, 1).reshape(b, -1, 4)
         conf = self.conf_layer(x).permute(0, 2, 3, 1).reshape(b, -1, NUM_CLASSES)
         coef = torch.tanh(self.mask_layer(x).permute(0, 2, 3, 1).reshape(b, -1, MASK_DIM))
@@ -212,7 +240,10 @@ class YolactR50(nn.Module):
         loc [B, P, 4], conf [B, P, 81] (softmax), mask [B, P, 32] (tanh), priors [P, 4], proto [B, 138, 138, 32] (ReLU)."""
         feats = self.backbone(x)[1:]
         pyramid = self.fpn(feats)
-        proto = F.relu(self.proto_net(pyramid[0])).permute(0, 2, 3, 1).contiguous()
+        pn = self.proto_net  # conv, relu, conv, relu, conv, relu, upsample, relu, conv, relu, conv (+ the final ReLU)
+        p = conv_bias_act(pn[4], conv_bias_act(pn[2], conv_bias_act(pn[0], pyramid[0], True), True), True)
+        p = conv_bias_act(pn[10], conv_bias_act(pn[8], F.relu(pn[6](p)), True), True)
+        proto = p.permute(0, 2, 3, 1).contiguous()
         head = self.prediction_layers[0]
         locs, confs, coefs = zip(*(head(p) for p in pyramid))
         sizes = tuple(tuple(p.shape[2:]) for p in pyramid)

@@ -175,18 +175,23 @@ def dry_run(args):
 # --------------------------------------------------------------------------------------------- measurement
 def count_network_flops(torch, engine, batch):
     """FLOPs (2 x multiply-accumulates) of ONE network forward per frame, counted from the shapes the convolutions
-    actually see (forward hooks), plus the prototype x coefficient product of the mask assembly."""
+    actually see: torch.nn.functional.conv2d is wrapped for one forward (every convolution of the network goes through it,
+    nn.Conv2d modules and the fused-epilogue path alike)."""
+    import torch.nn.functional as F
     total = [0]
+    real = F.conv2d
 
-    def hook(mod, inp, out):
-        k = mod.kernel_size[0] * mod.kernel_size[1] * (mod.in_channels // mod.groups)
-        total[0] += 2 * k * out.numel()
+    def counting(x, w, *a, **k):
+        out = real(x, w, *a, **k)
+        total[0] += 2 * w.shape[1] * w.shape[2] * w.shape[3] * out.numel()  # weight [Cout, Cin / groups, kh, kw]
+        return out
 
-    hooks = [m.register_forward_hook(hook) for m in engine.net.modules() if isinstance(m, torch.nn.Conv2d)]
-    with torch.no_grad():
-        engine._forward(torch.zeros((batch, 3, 550, 550), device=engine.device))
-    for h in hooks:
-        h.remove()
+    F.conv2d = counting
+    try:
+        with torch.no_grad():
+            engine._forward(torch.zeros((batch, 3, 550, 550), device=engine.device))
+    finally:
+        F.conv2d = real
     return total[0] / batch
 
 
@@ -481,12 +486,15 @@ def main():
                                      "frames_per_forward": chunk}
             n_fwd = (Bl + chunk - 1) // chunk
             net_ms = stage_ms.get("mask_pass", 0.0)
-            tf = net_flops * Bl / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
+            step_s = elapsed / args.steps
+            tf = net_flops * B / step_s / 1e12  # every lane's forwards of one step over the step's wall time: the whole chip's rate
             out["roofline_mask"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                     "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_frame": int(net_flops),
-                                    "ms_per_pass": round(net_ms, 3), "frames_per_pass": Bl, "forwards_per_pass": n_fwd,
-                                    "note": "whole mask pass of one lane (pre-processing, network, detection, mask assembly) timed with events on the "
-                                            "lane's stream inside the timed region, other lanes running; convolution FLOPs only in the numerator"}
+                                    "frames_per_step": B, "lanes": S, "lane_pass_ms": round(net_ms, 3), "frames_per_lane_pass": Bl,
+                                    "forwards_per_lane_pass": n_fwd,
+                                    "note": "convolution FLOPs (2 x MAC, counted from the shapes of one forward) of all frames of a step / the step's wall "
+                                            "time, i.e. a lower bound of the convolution kernels' own rate: the step also holds the pre / post-processing, "
+                                            "the ORB kernels and the match.  lane_pass_ms = one lane's whole mask pass (events on its stream), lanes overlap."}
         if em:
             st = em["stage_ms"]
             alg = algorithmic_bytes(lw, lh, em["mean_kp"], W, H)

@@ -314,6 +314,13 @@ void amos_mask_pre_destroy(amos_mask_pre *p);
 void *amos_mask_pre_stream(amos_mask_pre *p); /* the hipStream_t the handle issues on */
 int amos_mask_preprocess_batch_device(amos_mask_pre *p, const uint8_t *d_bgr, int n_frames, float *d_out);
 
+/* Fused epilogue of one convolution of the mask network, in place on a channels-last (NHWC) float32 tensor of n
+ * elements: y = act((y + bias[c]) + residual), act = ReLU when relu != 0, residual may be NULL.  Replaces PyTorch's
+ * separate bias-add, residual-add and clamp passes (same summation order: identical bits).  Asynchronous on `stream`
+ * (a hipStream_t; pass PyTorch's current stream). */
+int amos_mask_bias_act_device(void *stream, float *d_y, const float *d_bias, const float *d_residual, size_t n,
+                              int channels, int relu);
+
 /* ---------------------------------------------------------------- SLIC superpixels (8f-2) ---- */
 
 /* ORB_SLAM2::center, include/cluster.h:21-30. */

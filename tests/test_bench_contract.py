@@ -53,7 +53,7 @@ def test_default_run_is_the_baseline_metric_with_the_mask(gpu_lib):
     assert abs(leg["value"] - 64 * 3 / (leg["ms_per_step"] * 3 * 1e-3)) / leg["value"] < 0.01
     m = d["roofline_mask"]
     assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and m["peak"] == 157.3 and 0 < m["frac"] < 1
-    assert 5e10 < m["flops_per_frame"] < 2e11  # YOLACT-R50 at 550 x 550
+    assert 1.0e11 < m["flops_per_frame"] < 1.4e11  # YOLACT-R50 at 550 x 550: 59 G multiply-accumulates
     assert d["stage_ms_per_launch"]["mask_pass"] > 0
 
 

@@ -268,3 +268,34 @@ def test_cxx_yolact_class_cpu(mask, tmp_path):
 @pytest.mark.gpu
 def test_cxx_yolact_class_gpu(mask, gpu_lib, tmp_path):
     _yolact_class_roundtrip(mask, tmp_path, "cuda:0")
+
+
+@pytest.mark.gpu
+def test_fused_conv_epilogue_equals_the_torch_ops(mask, gpu_lib):
+    """amos_mask_bias_act_device (bias + residual + ReLU in one in-place pass behind the convolution) against PyTorch's
+    separate passes: same summation order, so the same bits -- vector path (channels % 4 == 0), scalar path (243 channels),
+    with and without residual / ReLU."""
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    torch.manual_seed(5)
+    for cin, cout, k, stride in ((64, 256, 1, 1), (128, 128, 3, 2), (256, 243, 3, 1), (3, 64, 7, 2)):
+        conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=True).cuda().to(memory_format=torch.channels_last)
+        x = torch.randn(3, cin, 37, 41, device="cuda").contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            plain = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+            res = torch.randn_like(plain)
+            for relu in (True, False):
+                for r in (None, res):
+                    want = plain + conv.bias.view(1, -1, 1, 1)
+                    if r is not None:
+                        want = want + r
+                    if relu:
+                        want = torch.relu(want)
+                    got = plain.clone(memory_format=torch.channels_last)  # the epilogue alone, on the same convolution output
+                    assert got.is_contiguous(memory_format=torch.channels_last)
+                    gpu_lib.mask_bias_act(torch.cuda.current_stream().cuda_stream, got.data_ptr(), conv.bias.data_ptr(),
+                                          r.data_ptr() if r is not None else None, got.numel(), cout, relu)
+                    torch.cuda.synchronize()
+                    assert torch.equal(got, want), (cin, cout, k, relu, r is not None)
+                    fused = net_mod.conv_bias_act(conv, x, relu, residual=r)  # with its own convolution call (MIOpen may pick another solver)
+                    assert fused.shape == want.shape and torch.allclose(fused, want, rtol=1e-4, atol=1e-4)
+    # the engine end to end is covered by test_network_with_folded_batch_norms_vs_reference_gpu (golden tensors, IoU)

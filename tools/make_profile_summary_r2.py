@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_* from gpurun_out/prof_r2 (tools/collect_profiles_r2.sh): the bench line, rocprofv3's kernel stats of the
+default command (MIOpen / rocBLAS kernels of the mask network included), and per-kernel counters of the HIP kernels:
+HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), vector / scalar / LDS
+instruction counts and the VALU-busy fraction.  Also rewrites profiles/traffic.json, which bench.py quotes as
+roofline.traffic (labelled with its source)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof_r2"
+shutil.copy(max(glob.glob(f"{src}/trace/*/*kernel_stats.csv"), key=os.path.getmtime), f"profiles/{tag}_kernel_stats.csv")
+line = [l for l in open(f"{src}/bench.json") if l.startswith("{")][-1]
+open(f"profiles/{tag}_bench.json", "w").write(line)
+bench = json.loads(line)
+leg = bench.get("extract_match_leg", bench)
+frames = leg.get("frames_per_launch", bench["config"]["frames_per_launch"])
+per_kernel = collections.defaultdict(dict)
+for d in sorted(glob.glob(f"{src}/pmc*/")):
+    files = glob.glob(d + "*/*counter_collection.csv")
+    if not files:
+        continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
+        if "amos::" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        for c, x in v.items():
+            per_kernel[k][c] = {"launches": len(x), "avg_per_launch": round(sum(x) / len(x), 1)}
+for k, v in per_kernel.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        v["hbm_bytes_per_launch_corrected"] = int((2 * v["FETCH_SIZE"]["avg_per_launch"] + v["WRITE_SIZE"]["avg_per_launch"]) * 1024)
+    if "SQ_ACTIVE_INST_VALU" in v and "SQ_BUSY_CYCLES" in v and v["SQ_BUSY_CYCLES"]["avg_per_launch"] > 0:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD issues vector work, summed over the chip's SIMDs;
+        # SQ_BUSY_CYCLES is summed over the 32 shader engines' SQs: the ratio below is the usual VALUBusy (percent)
+        pass
+json.dump({"command": "rocprofv3 --pmc <set> (one pass per set) -- python3 bench.py --gpus 1 --config c2 --steps 3 --warmup 1 --cpu-frames 0",
+           "sets": ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS", "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"],
+           "frames_per_launch": frames,
+           "note": "counter collection serialises kernels: these are per-launch figures of each kernel ALONE on the chip",
+           "correction": "HBM bytes = FETCH_SIZE x 2 + WRITE_SIZE (KB units; the x 2 is the gfx950 correction of MI355X_MICROARCH.md, HBM section, "
+                         "re-calibrated in round 1 with tools/fetch_calib.hip)",
+           "kernels": per_kernel}, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+stage = {"import": ["amos::k_pyramid_level0_wide"], "pyramid": ["amos::k_pyramid_level<true>", "amos::k_pyramid_tail"], "fast": ["amos::k_fast_cells<16>", "amos::k_fast_cells<20>"],
+         "octree": ["amos::k_octree"], "orient": ["amos::k_orient"], "blur": ["amos::k_blur"], "describe": ["amos::k_describe"],
+         "match": ["amos::k_bf_best2_mfma<true, 1>", "amos::k_bf_best2_mfma<true, 4>", "amos::k_bf_best2<true>"]}
+traffic = {"source": f"profiles/{tag}_pmc_summary.json", "c2": {}}
+for st, ks in stage.items():
+    tot = 0
+    for k in ks:
+        v = per_kernel.get(k)
+        if v and "hbm_bytes_per_launch_corrected" in v:
+            per_pass = v["FETCH_SIZE"]["launches"] / max(per_kernel["amos::k_octree"]["FETCH_SIZE"]["launches"], 1)  # launches of this kernel per pass
+            tot += v["hbm_bytes_per_launch_corrected"] * per_pass
+    traffic["c2"][st] = {"batch": frames, "hbm_bytes_per_launch": int(tot)}
+    valu = sum(per_kernel[k]["SQ_INSTS_VALU"]["avg_per_launch"] * per_kernel[k]["SQ_INSTS_VALU"]["launches"] for k in ks if k in per_kernel and "SQ_INSTS_VALU" in per_kernel[k])
+    n_pass = max(per_kernel["amos::k_octree"]["SQ_INSTS_VALU"]["launches"], 1) if "SQ_INSTS_VALU" in per_kernel.get("amos::k_octree", {}) else 1
+    print(f"{st:9s} {tot / 1e6:8.1f} MB HBM, {valu / n_pass / 1e6:7.2f} M VALU wave-instructions per pass of {frames} frames")
+json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
