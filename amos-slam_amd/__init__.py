@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -254,6 +254,15 @@ class OrbExtractor:
         _check(self.L.amos_orb_extract_batch_device_color(self.h, C.c_void_p(d_ptr), C.c_size_t(frame_stride), C.c_size_t(row_stride),
                                                           C.c_int(width), C.c_int(height), C.c_int(n_frames), C.c_int(channels),
                                                           C.c_int(int(rgb_order))), "amos_orb_extract_batch_device_color")
+
+    def detect_color_with_mask_pre_batch_device(self, pre, d_ptr, frame_stride, row_stride, width, height, n_frames, d_net_input, channels=3,
+                                                rgb_order=False):
+        """8f-4: one read of the colour frames -> padded gray level 0 (+ the rest of detect) and the mask network's input tensor."""
+        self.shape = (height, width)
+        _check(self.L.amos_orb_detect_color_with_mask_pre_batch_device(self.h, pre.p, C.c_void_p(d_ptr), C.c_size_t(frame_stride), C.c_size_t(row_stride),
+                                                                       C.c_int(width), C.c_int(height), C.c_int(n_frames), C.c_int(channels),
+                                                                       C.c_int(int(rgb_order)), C.c_void_p(d_net_input)),
+               "amos_orb_detect_color_with_mask_pre_batch_device")
 
     def rgbd_glue_batch_device(self, d_depth, depth_is_u16, depth_map_factor, depth_frame_stride, depth_row_stride, mbf, bounds,
                                d_u_right, d_depth_out, d_grid_cell, d_kps_un=None):

@@ -83,4 +83,21 @@ struct ResizeTap {
     short a0, a1;  // weights, sum 2048
 };
 
+// ---- mask pre-processing handle, as the fused import kernel of amos_orb.hip sees it (amos_mask_pre.hip)
+constexpr int kMaskMidW = 480, kMaskMidH = 640;  // yolact.cc:220 cv::Size(480, 640): the intermediate image of the mask pre-processing
+struct FixTap { int s0, s1, a0, a1; };  // 8-bit cv::resize: source indices and 11-bit weights of one destination index
+struct MaskPreStageA {
+    const FixTap *tx, *ty;        // destination column / row -> taps (kMidW / kMidH entries)
+    const int *firstX, *firstY;   // source column X / row Y -> first destination index whose first tap is >= X (width + 1 / height + 1 entries)
+    const float *lut;             // u8 -> float(double(v) / 255.0) * 255.0f
+    float *mid;                   // [frames][kMidH][kMidW][3]
+    int width, height, maxBatch;
+};
+
+}  // namespace amos
+
+struct amos_mask_pre;
+namespace amos {
+int mask_pre_stage_a(amos_mask_pre *p, MaskPreStageA *out);                              // tables and buffers of stage A
+int mask_pre_finish(amos_mask_pre *p, hipStream_t stream, int n_frames, float *d_out);  // stages B and C on `stream`
 }  // namespace amos

@@ -17,10 +17,9 @@
 namespace amos {
 
 constexpr int kNetSize = 550;            // cfg.max_size
-constexpr int kMidW = 480, kMidH = 640;  // yolact.cc:220  cv::Size(480, 640)
+constexpr int kMidW = kMaskMidW, kMidH = kMaskMidH;  // yolact.cc:220  cv::Size(480, 640)
 constexpr int kBackW = 640, kBackH = 480;  // yolact_interface.py:865
 
-struct FixTap { int s0, s1, a0, a1; };      // 8-bit cv::resize: source indices and 11-bit weights
 struct FltTap { int s0, s1; float f0, f1; };  // float cv::resize: source indices, (1 - f) and f
 
 // A: grid = (ceil(480 * 640 / 256), frames); one thread per intermediate pixel, three channels
@@ -129,6 +128,7 @@ struct amos_mask_pre {
     FixTap *dFixX = nullptr, *dFixY = nullptr;
     FltTap *dFltX = nullptr, *dFltY = nullptr;
     float *dLut = nullptr, *dMid = nullptr, *dBack = nullptr;
+    int *dFirstX = nullptr, *dFirstY = nullptr;  // inverse of the stage-A tap tables (fused import, amos_orb.hip)
 };
 
 // cv::resize INTER_LINEAR source index and fraction per destination index (double -> float as OpenCV does);
@@ -153,6 +153,22 @@ static void axis_taps(int srcN, int dstN, bool clampFraction, std::vector<int> &
 
 static int round_even(float v) { return (int)std::nearbyintf(v); }
 
+namespace amos {
+int mask_pre_stage_a(amos_mask_pre *p, MaskPreStageA *out)
+{
+    if (!p || !out) { set_error("mask pre-processing handle missing"); return AMOS_ERR_INVALID; }
+    *out = MaskPreStageA{p->dFixX, p->dFixY, p->dFirstX, p->dFirstY, p->dLut, p->dMid, p->width, p->height, p->maxBatch};
+    return AMOS_OK;
+}
+int mask_pre_finish(amos_mask_pre *p, hipStream_t stream, int n_frames, float *d_out)
+{
+    hipLaunchKernelGGL(k_mask_pre_b, dim3((kBackW * kBackH + 255) / 256, n_frames), dim3(256), 0, stream, p->dMid, p->dFltX, p->dFltY, p->dBack);
+    hipLaunchKernelGGL(k_mask_pre_c, dim3((kNetSize * kNetSize + 255) / 256, n_frames), dim3(256), 0, stream, p->dBack, d_out);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+}  // namespace amos
+
 extern "C" {
 
 int amos_mask_pre_create(int device, void *stream, int width, int height, int max_batch, amos_mask_pre **out)
@@ -169,13 +185,21 @@ int amos_mask_pre_create(int device, void *stream, int width, int height, int ma
     }
     std::vector<int> s0, s1;
     std::vector<float> f;
-    auto fix = [&](int srcN, int dstN, bool clamp, FixTap **dst) -> hipError_t {
+    auto fix = [&](int srcN, int dstN, bool clamp, FixTap **dst, int **first) -> hipError_t {
         axis_taps(srcN, dstN, clamp, s0, s1, f);
         std::vector<FixTap> t(dstN);
         for (int d = 0; d < dstN; d++) t[d] = FixTap{s0[d], s1[d], round_even((1.f - f[d]) * 2048.f), round_even(f[d] * 2048.f)};
+        // first tap indices are non-decreasing: first[X] = the first destination index whose first tap is >= X
+        std::vector<int> inv(srcN + 1);
+        for (int X = 0, d = 0; X <= srcN; X++) {
+            while (d < dstN && s0[d] < X) d++;
+            inv[X] = d;
+        }
         hipError_t e = hipMalloc((void **)dst, sizeof(FixTap) * dstN);
-        if (e != hipSuccess) return e;
-        return hipMemcpy(*dst, t.data(), sizeof(FixTap) * dstN, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(*dst, t.data(), sizeof(FixTap) * dstN, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)first, sizeof(int) * inv.size());
+        if (e == hipSuccess) e = hipMemcpy(*first, inv.data(), sizeof(int) * inv.size(), hipMemcpyHostToDevice);
+        return e;
     };
     auto flt = [&](int srcN, int dstN, bool clamp, FltTap **dst) -> hipError_t {
         axis_taps(srcN, dstN, clamp, s0, s1, f);
@@ -187,8 +211,8 @@ int amos_mask_pre_create(int device, void *stream, int width, int height, int ma
     };
     float lut[256];
     for (int v = 0; v < 256; v++) lut[v] = (float)((double)v / 255.0) * 255.0f;  // yolact.cc:424-431, yolact_interface.py:864
-    hipError_t e = fix(width, kMidW, true, &p->dFixX);
-    if (e == hipSuccess) e = fix(height, kMidH, false, &p->dFixY);
+    hipError_t e = fix(width, kMidW, true, &p->dFixX, &p->dFirstX);
+    if (e == hipSuccess) e = fix(height, kMidH, false, &p->dFixY, &p->dFirstY);
     if (e == hipSuccess) e = flt(kMidW, kBackW, true, &p->dFltX);
     if (e == hipSuccess) e = flt(kMidH, kBackH, false, &p->dFltY);
     if (e == hipSuccess) e = hipMalloc((void **)&p->dLut, sizeof(lut));
@@ -209,7 +233,7 @@ void amos_mask_pre_destroy(amos_mask_pre *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *ptrs[] = {p->dFixX, p->dFixY, p->dFltX, p->dFltY, p->dLut, p->dMid, p->dBack};
+    void *ptrs[] = {p->dFixX, p->dFixY, p->dFltX, p->dFltY, p->dLut, p->dMid, p->dBack, p->dFirstX, p->dFirstY};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (p->ownStream && p->stream) (void)hipStreamDestroy(p->stream);
     delete p;

@@ -366,7 +366,8 @@ static int set_geometry(amos_orb *h, int W, int Hh)
 }
 
 // ---------------------------------------------------------------------------------------------
-static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, size_t rowStride, int nFrames, int channels = 1, int rgbOrder = 0)
+static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, size_t rowStride, int nFrames, int channels = 1, int rgbOrder = 0,
+                         const MaskPreStageA *fuse = nullptr)
 {
     const Geom &g = h->geom;
     hipEvent_t *ev = (h->maxRecords > 0 && h->nRecords < h->maxRecords) ? &h->events[(size_t)h->nRecords * (kTimingEvents)] : nullptr;
@@ -378,7 +379,10 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
         const LevelGeom &lg = g.lv[l];
         const int groups = (kPadLeft + lg.w + kEdge + 3) / 4;
         dim3 grid((groups + 63) / 64, (lg.h + 2 * kEdge + 4 * kPyrRows - 1) / (4 * kPyrRows), nFrames), block(64, 4);
-        if (l == 0 && channels > 1)
+        if (l == 0 && fuse)
+            hipLaunchKernelGGL(k_import_color_mask, dim3((lg.w + kFuseTileW - 1) / kFuseTileW, (lg.h + kFuseTileH - 1) / kFuseTileH, nFrames), dim3(256), 0,
+                               h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, channels, rgbOrder, *fuse);
+        else if (l == 0 && channels > 1)
             hipLaunchKernelGGL(k_pyramid_level0_color, grid, block, 0, h->stream, dSrc, frameStride, rowStride, h->dPyr, h->dGeom, channels, rgbOrder);
         else if (l == 0) {
             hipLaunchKernelGGL(k_pyramid_level0_wide, dim3((import_threads(lg.w, lg.h) + 255) / 256, 1, nFrames), dim3(256), 0, h->stream, dSrc,
@@ -932,6 +936,29 @@ int amos_orb_extract_batch_device_color(amos_orb *h, const uint8_t *d_color, siz
     rc = launch_detect(h, d_color, frame_stride, row_stride, n_frames, channels, rgb_order != 0);
     if (rc != AMOS_OK) return rc;
     return launch_describe(h, n_frames);
+}
+
+int amos_orb_detect_color_with_mask_pre_batch_device(amos_orb *h, amos_mask_pre *pre, const uint8_t *d_color, size_t frame_stride, size_t row_stride,
+                                                     int width, int height, int n_frames, int channels, int rgb_order, float *d_net_input)
+{
+    if (!h || !pre || !d_color || !d_net_input || n_frames < 1 || width < 1 || height < 1 || (channels != 3 && channels != 4) ||
+        row_stride < (size_t)width * channels) {
+        set_error("amos_orb_detect_color_with_mask_pre_batch_device: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    if (n_frames > h->maxB) { set_error("batch of %d frames exceeds the handle's max_batch %d", n_frames, h->maxB); return AMOS_ERR_CAPACITY; }
+    MaskPreStageA a;
+    int rc = mask_pre_stage_a(pre, &a);
+    if (rc != AMOS_OK) return rc;
+    if (a.width != width || a.height != height) { set_error("mask pre-processing handle made for %dx%d frames, got %dx%d", a.width, a.height, width, height); return AMOS_ERR_INVALID; }
+    if (n_frames > a.maxBatch) { set_error("mask pre-processing handle made for %d frames, got %d", a.maxBatch, n_frames); return AMOS_ERR_CAPACITY; }
+    if (width <= 2 * kEdge + 1 || height <= 2 * kEdge + 1) { set_error("frame too small for the fused import"); return AMOS_ERR_INVALID; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    rc = set_geometry(h, width, height);
+    if (rc != AMOS_OK) return rc;
+    rc = launch_detect(h, d_color, frame_stride, row_stride, n_frames, channels, rgb_order != 0, &a);
+    if (rc != AMOS_OK) return rc;
+    return mask_pre_finish(pre, h->stream, n_frames, d_net_input);  // stages B and C follow on the same stream
 }
 
 static int make_undistort_args(float fx, float fy, float cx, float cy, const float *dist_coef, int n_dist, UndistortArgs &a, const char *who)

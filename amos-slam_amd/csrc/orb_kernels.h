@@ -165,6 +165,79 @@ __global__ __launch_bounds__(256) void k_pyramid_level0_color(const uint8_t *__r
     }
 }
 
+// ONE pass over the colour frame for both of its consumers -- Tracking::GrabImageRGBD's cvtColor into the
+// padded level 0 (Tracking.cc:308-321, as k_pyramid_level0_color) and the first stage of the mask pre-processing,
+// yolact::evalImage's cv::resize of the BGR frame to W480 x H640 with the u8 -> float step (yolact.cc:220, 385-451,
+// as k_mask_pre_a of amos_mask_pre.hip).  A work-group stages a 64 x 16 pixel tile (+ one halo column and row, clamped
+// like the resize taps) in LDS, writes the tile's gray pixels (a dword of four per thread; pixels within 19 of an image
+// edge also go to their reflect-101 positions in the border) and every pixel of the intermediate image whose FIRST tap
+// lies in the tile (the inverse tap tables firstX / firstY give the index ranges; the second tap is the halo at most).
+// grid = (ceil(W / 64), ceil(H / 16), frames), block = 256.
+constexpr int kFuseTileW = 64, kFuseTileH = 16, kFusePitch = (kFuseTileW + 1) * 3 + 1;
+
+__global__ __launch_bounds__(256) void k_import_color_mask(const uint8_t *__restrict__ src, size_t srcFrameStride, size_t srcRowStride,
+                                                          uint8_t *__restrict__ pyr, const Geom *__restrict__ g, int channels, int rgbOrder,
+                                                          const MaskPreStageA a)
+{
+    __shared__ uint8_t tile[kFuseTileH + 1][kFusePitch];
+    const LevelGeom &lg = g->lv[0];
+    const int W = lg.w, H = lg.h, frame = blockIdx.z, tid = threadIdx.x;
+    const int X0 = blockIdx.x * kFuseTileW, Y0 = blockIdx.y * kFuseTileH;
+    const uint8_t *s0 = src + (size_t)frame * srcFrameStride;
+    for (int idx = tid; idx < (kFuseTileH + 1) * (kFuseTileW + 1); idx += 256) {
+        const int r = idx / (kFuseTileW + 1), c = idx - r * (kFuseTileW + 1);
+        const uint8_t *px = s0 + (size_t)min(Y0 + r, H - 1) * srcRowStride + (size_t)min(X0 + c, W - 1) * channels;
+        tile[r][3 * c] = px[0];
+        tile[r][3 * c + 1] = px[1];
+        tile[r][3 * c + 2] = px[2];
+    }
+    __syncthreads();
+    {   // gray: thread = (row, four columns)
+        const int ly = tid >> 4, lx = (tid & 15) * 4, y = Y0 + ly, x = X0 + lx;
+        if (y < H && x < W) {
+            const unsigned c0 = rgbOrder ? 9798u : 3735u, c2 = rgbOrder ? 3735u : 9798u;  // weight of byte 0 / byte 2
+            uint8_t *plane = level_origin(pyr, g, frame, 0);
+            unsigned v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint8_t *t = &tile[ly][3 * (lx + k)];
+                v[k] = (t[0] * c0 + t[1] * 19235u + t[2] * c2 + 16384u) >> 15;
+            }
+            const int yr = (y >= 1 && y <= kEdge) ? -y : (y >= H - 1 - kEdge && y <= H - 2) ? 2 * (H - 1) - y : y;  // reflect-101 image of the row (or itself)
+            if (x + 3 < W) *reinterpret_cast<uint32_t *>(plane + (ptrdiff_t)y * lg.stride + x) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+            else
+                for (int k = 0; k < 4 && x + k < W; k++) plane[(ptrdiff_t)y * lg.stride + x + k] = (uint8_t)v[k];
+            for (int k = 0; k < 4 && x + k < W; k++) {
+                const int xx = x + k;
+                const int xr = (xx >= 1 && xx <= kEdge) ? -xx : (xx >= W - 1 - kEdge && xx <= W - 2) ? 2 * (W - 1) - xx : xx;
+                if (yr != y) plane[(ptrdiff_t)yr * lg.stride + xx] = (uint8_t)v[k];
+                if (xr != xx) {
+                    plane[(ptrdiff_t)y * lg.stride + xr] = (uint8_t)v[k];
+                    if (yr != y) plane[(ptrdiff_t)yr * lg.stride + xr] = (uint8_t)v[k];
+                }
+            }
+        }
+    }
+    // the intermediate image of the mask pass: destination indices whose first taps fall into this tile
+    const int dx0 = a.firstX[X0], dx1 = a.firstX[min(X0 + kFuseTileW, W)], dy0 = a.firstY[Y0], dy1 = a.firstY[min(Y0 + kFuseTileH, H)];
+    const int nx = dx1 - dx0, n = nx * (dy1 - dy0);
+    float *mid = a.mid + (size_t)frame * kMaskMidH * kMaskMidW * 3;
+    for (int idx = tid; idx < n; idx += 256) {
+        const int ry = idx / nx, dy = dy0 + ry, dx = dx0 + (idx - ry * nx);
+        const FixTap ax = a.tx[dx], ay = a.ty[dy];
+        const uint8_t *r0 = tile[ay.s0 - Y0], *r1 = tile[ay.s1 - Y0];
+        const int xa = 3 * (ax.s0 - X0), xb = 3 * (ax.s1 - X0);
+        float *o = mid + ((size_t)dy * kMaskMidW + dx) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int h0 = r0[xa + c] * ax.a0 + r0[xb + c] * ax.a1;
+            const int h1 = r1[xa + c] * ax.a0 + r1[xb + c] * ax.a1;
+            const int v = (((ay.a0 * (h0 >> 4)) >> 16) + ((ay.a1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            o[c] = a.lut[v];  // float(double(v) / 255.0) * 255.0f
+        }
+    }
+}
+
 // Levels >= 1.  Measured on MI355X (profiles/, tools/kt_var.sh): a CU issues about one vector-memory
 // instruction per 16 cycles whatever its width and one VALU instruction per cycle, and this kernel was
 // bound by the former.  So:

@@ -105,6 +105,18 @@ class MaskEngine:
         return self.eval_chw(cxx_marshalling(frame))
 
     @torch.no_grad()
+    def eval_net_input_batch(self, x, chunk=16, height=480, width=640):
+        """x: [B, 3, 550, 550] float32 network input already on the engine's device (amos_orb_detect_color_with_mask_pre_batch_device
+        or amos_mask_preprocess_batch_device wrote it).  Returns [B, height, width] uint8 masks like eval_bgr_batch."""
+        B = x.shape[0]
+        out = torch.zeros((B, height, width), dtype=torch.uint8, device=self.device)
+        for b0 in range(0, B, chunk):
+            pred = self._forward(x[b0:b0 + chunk])
+            masks, _found = person_mask_batch(detect_batch(pred), 640, 480)
+            out[b0:b0 + masks.shape[0]] = masks
+        return out
+
+    @torch.no_grad()
     def eval_bgr_batch(self, frames_u8, chunk=16):
         """frames_u8: [B, H, W, 3] uint8 on the engine's device.  Returns [B, H, W] uint8 masks (zeros where
         the network finds nothing, which is what the reference's caller ends up using, Tracking.cc:305).

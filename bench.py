@@ -50,7 +50,7 @@ CONFIGS = {
                label="configs[1]: 640x480 L8 N1000 extract+match, mask off"),
     # BASELINE.json configs[2]: full front-end incl. the YOLACT mask (network on PyTorch-ROCm, random weights
     # with a biased class head so that ~100 detections exercise the whole post-processing chain)
-    "c3": dict(width=640, height=480, n_features=1000, n_levels=8, mask=True, default_batch=32, default_streams=2,
+    "c3": dict(width=640, height=480, n_features=1000, n_levels=8, mask=True, default_batch=96, default_streams=3,
                label="configs[2]: 640x480 L8 N1000 full front-end: YOLACT-R50 fp32 mask + ORB detect + gate + describe + match"),
     # BASELINE.json configs[4]: synthetic HD stream
     "c5": dict(width=1920, height=1080, n_features=4000, n_levels=12, default_batch=128, default_streams=4,
@@ -315,18 +315,21 @@ def main():
         if masked:
             for ln in active:
                 if ln.bgr is None:
-                    ln.bgr = ln.frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()  # gray as BGR, in HBM
+                    ln.bgr = ln.frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()  # the colour frames (gray replicated), in HBM
+                    ln.pre = pkg.MaskPreprocessor(W, H, bl, device=local_rank, stream=ln.ext.stream)
+                    ln.net_in = torch.empty((bl, 3, 550, 550), dtype=torch.float32, device=dev)
 
         def step(timed):
             for li, ln in enumerate(active):
                 rec = timed and li == 0  # per-kernel events on lane 0 only
                 if masked:
-                    ln.ext.detect_batch_device(ln.frames.data_ptr(), H * W, W, W, H, bl)
+                    # ONE read of the colour frame feeds the gray pyramid (then FAST ... orientation) and the network's input tensor
+                    ln.ext.detect_color_with_mask_pre_batch_device(ln.pre, ln.bgr.data_ptr(), H * W * 3, W * 3, W, H, bl, ln.net_in.data_ptr())
                     with torch.cuda.stream(ln.stream):  # the network runs on the lane's stream: ordering is implicit
                         if rec:
                             m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             m0.record(ln.stream)
-                        ln.masks = engine.eval_bgr_batch(ln.bgr, chunk=chunk)  # kept alive until the stream has consumed it
+                        ln.masks = engine.eval_net_input_batch(ln.net_in, chunk=chunk, height=H, width=W)  # kept alive until the stream has consumed it
                         if rec:
                             m1.record(ln.stream)
                             mask_events.append((m0, m1))

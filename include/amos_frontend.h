@@ -71,6 +71,7 @@ typedef struct amos_orb_params {
 
 typedef struct amos_orb amos_orb;
 typedef struct amos_match amos_match;
+typedef struct amos_mask_pre amos_mask_pre;
 
 /* Result of a best / second-best reduction over one query's candidate list, ties resolved as the
  * reference's sequential `if(dist<best) ... else if(dist<best2)` loop does (first candidate wins). */
@@ -308,11 +309,19 @@ int amos_match_window_best2_batch_device(amos_match *m, const amos_window_search
  * (utils/augmentations.py:616-657: bilinear to 550 x 550, (x - MEANS) / STD, BGR -> RGB).
  * d_bgr: [n_frames][height][width][3] uint8; d_out: [n_frames][3][550][550] float32.  Asynchronous on the
  * handle's stream (pass PyTorch's current stream so that the network simply follows). */
-typedef struct amos_mask_pre amos_mask_pre;
 int amos_mask_pre_create(int device, void *stream, int width, int height, int max_batch, amos_mask_pre **out);
 void amos_mask_pre_destroy(amos_mask_pre *p);
 void *amos_mask_pre_stream(amos_mask_pre *p); /* the hipStream_t the handle issues on */
 int amos_mask_preprocess_batch_device(amos_mask_pre *p, const uint8_t *d_bgr, int n_frames, float *d_out);
+
+/* SURVEY 8f-4, "one pass over the RGB-D frame": the colour frame is read ONCE for both of its consumers -- the gray
+ * conversion into the padded level 0 (Tracking.cc:308-321, then the rest of amos_orb_detect_batch_device) and stage A of
+ * the mask pre-processing (yolact.cc:220, 385-451) -- and the network input appears in d_net_input ([n][3][550][550]
+ * float32) on the extractor's stream.  Same results as amos_orb_extract_batch_device_color's detect part and
+ * amos_mask_preprocess_batch_device; follow with amos_orb_gate_batch_device / amos_orb_describe_batch_device. */
+int amos_orb_detect_color_with_mask_pre_batch_device(amos_orb *h, amos_mask_pre *pre, const uint8_t *d_color,
+                                                     size_t frame_stride, size_t row_stride, int width, int height,
+                                                     int n_frames, int channels, int rgb_order, float *d_net_input);
 
 /* Fused epilogue of one convolution of the mask network, in place on a channels-last (NHWC) float32 tensor of n
  * elements: y = act((y + bias[c]) + residual), act = ReLU when relu != 0, residual may be NULL.  Replaces PyTorch's

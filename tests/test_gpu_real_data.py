@@ -111,11 +111,14 @@ def _biased_engine(mask_mod, device):
     return eng.prepare()
 
 
-def test_configs2_chain_end_to_end(gpu_lib, ob, synth, pkg):
-    """BASELINE configs[2] exactly as bench.py issues it: detect on the lane's stream, the mask network on the SAME
-    stream through torch, gate with the network's device-resident masks, describe, N x N best-2 match of frame k against
-    frame k-1 -- compared frame by frame with the oracle's detect -> gate(the same masks, copied to the host) ->
-    describe and orc bruteforce_best2.  Covers the torch-stream <-> handle-stream hand-off and the device mask pointer."""
+@pytest.mark.parametrize("fused_import", [True, False])
+def test_configs2_chain_end_to_end(gpu_lib, ob, synth, pkg, fused_import):
+    """BASELINE configs[2] exactly as bench.py issues it: the colour frames read once into the gray pyramid and the mask
+    network's input (fused_import; or the separate gray detect + three-kernel mask pre-processing), the rest of detect on
+    the lane's stream, the mask network on the SAME stream through torch, gate with the network's device-resident masks,
+    describe, N x N best-2 match of frame k against frame k-1 -- compared frame by frame with the oracle's detect ->
+    gate(the same masks, copied to the host) -> describe and orc bruteforce_best2.  Covers the torch-stream <->
+    handle-stream hand-off and the device mask pointer."""
     import torch
     mask_mod = importlib.import_module("amos_slam_amd.mask")
     n = 6
@@ -133,10 +136,15 @@ def test_configs2_chain_end_to_end(gpu_lib, ob, synth, pkg):
     pairs_t = (pairs_q - 1) % n
     d_match = torch.full((n, cap, 4), 1 << 30, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
+    pre = pkg.MaskPreprocessor(640, 480, n, stream=ext.stream)
+    net_in = torch.empty((n, 3, 550, 550), dtype=torch.float32, device="cuda")
     for _ in range(2):  # twice: the second pass overwrites a used handle, as every bench step after the first does
-        ext.detect_batch_device(d_frames.data_ptr(), 480 * 640, 640, 640, 480, n)
+        if fused_import:
+            ext.detect_color_with_mask_pre_batch_device(pre, bgr.data_ptr(), 480 * 640 * 3, 640 * 3, 640, 480, n, net_in.data_ptr())
+        else:
+            ext.detect_batch_device(d_frames.data_ptr(), 480 * 640, 640, 640, 480, n)
         with torch.cuda.stream(lane):
-            masks = eng.eval_bgr_batch(bgr, chunk=4)
+            masks = eng.eval_net_input_batch(net_in, chunk=4) if fused_import else eng.eval_bgr_batch(bgr, chunk=4)
             ext.gate_batch_device(masks.data_ptr(), 480 * 640, 640)
             ext.describe_batch_device()
         matcher.bruteforce_best2_batch_device(d_desc, cap * 32, d_counts, pairs_q.data_ptr(), pairs_t.data_ptr(), n, cap, 256, d_match.data_ptr())
@@ -163,3 +171,45 @@ def test_configs2_chain_end_to_end(gpu_lib, ob, synth, pkg):
         want = ob.bruteforce_best2(descs[f], descs[(f - 1) % n])
         got = got_match[f, :len(descs[f])].view(pkg.BEST2_DTYPE).reshape(-1)
         _same(got, want, f"match of frame {f} against frame {(f - 1) % n}")
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (413, 307)])
+def test_fused_colour_import_feeds_pyramid_and_mask_network(gpu_lib, ob, w, h):
+    """amos_orb_detect_color_with_mask_pre_batch_device reads the colour frames once; the padded gray level 0
+    and everything detect derives from it equal the oracle's cvtColor + detect, and the mask network's input tensor equals
+    amos_mask_preprocess_batch_device's bit for bit."""
+    import torch
+    rng = np.random.default_rng(w)
+    n = 3
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    if (w, h) == (640, 480):
+        frames[0] = _load(FRAMES[0])[0][:, :, ::-1]  # a real frame, BGR
+    else:  # smooth structure so that FAST finds corners at the small size
+        yy, xx = np.mgrid[0:h, 0:w]
+        frames[0] = ((90 * ((xx // 16 + yy // 12) % 2))[..., None] + rng.integers(0, 40, (h, w, 3))).astype(np.uint8)
+    d = torch.from_numpy(frames).cuda()
+    nl = 8 if w == 640 else 5
+    ext = gpu_lib.OrbExtractor(n_levels=nl, max_width=w, max_height=h, max_batch=n)
+    pre = gpu_lib.MaskPreprocessor(w, h, n, stream=ext.stream)
+    x = torch.full((n, 3, 550, 550), -7.0, dtype=torch.float32, device="cuda")
+    want_x = torch.empty_like(x)
+    torch.cuda.synchronize()
+    ext.detect_color_with_mask_pre_batch_device(pre, d.data_ptr(), h * w * 3, w * 3, w, h, n, x.data_ptr(), channels=3, rgb_order=False)
+    ext.describe_batch_device()
+    ext.sync()
+    pre.run(d.data_ptr(), n, want_x.data_ptr())  # the three-kernel chain on the same stream
+    ext.sync()
+    torch.cuda.synchronize()
+    assert torch.equal(x, want_x), float((x - want_x).abs().max())
+    for f in range(n):
+        gray = ob.color_to_gray(frames[f], rgb_order=False)
+        orc = ob.Oracle(n_levels=nl)
+        ko, do = orc.extract(gray)
+        kg, dg = ext.batch_fetch(f)
+        _same(kg, ko, f"frame {f} keypoints")
+        _same(dg, do, f"frame {f} descriptors")
+    orc = ob.Oracle(n_levels=nl)
+    orc.detect(ob.color_to_gray(frames[0], rgb_order=False))
+    ext.shape = (h, w)
+    _same(ext.level_image(0, padded=True, frame=0), orc.level_image(0, padded=True), "padded level 0 (reflect-101 border written by the tiles)")
+    assert len(ext.batch_fetch(0)[0]) > 50
