@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -363,6 +363,18 @@ class Slic:
         _check(self.L.amos_slic_batch_device(self.s, C.c_void_p(d_lab), C.c_void_p(d_depth), C.c_int(width), C.c_int(height), C.c_int(n_frames),
                                              C.c_int(length), C.c_int(m), C.c_int(iterations), C.c_void_p(d_labels), C.c_void_p(d_centers)),
                "amos_slic_batch_device")
+
+    def kmeans(self, centers, k=15, seed=1, max_iter=1000):
+        """cluster::randCent + kmeans on the SLIC centres (cluster.cc:353-460, seeded): returns (centres with .id set, passes)."""
+        c = np.ascontiguousarray(centers, SLIC_CENTER_DTYPE).copy()
+        passes = C.c_int(0)
+        _check(self.L.amos_cluster_kmeans(self.s, _p(c), C.c_int(len(c)), C.c_int(k), C.c_uint32(seed), C.c_int(max_iter), C.byref(passes)),
+               "amos_cluster_kmeans")
+        return c, passes.value
+
+    def kmeans_batch_device(self, d_centers, n_centers, n_frames, k=15, seed=1, max_iter=1000, d_passes=None):
+        _check(self.L.amos_cluster_kmeans_batch_device(self.s, C.c_void_p(d_centers), C.c_int(n_centers), C.c_int(n_frames), C.c_int(k),
+                                                       C.c_uint32(seed), C.c_int(max_iter), C.c_void_p(d_passes)), "amos_cluster_kmeans_batch_device")
 
     def sync(self):
         import torch  # noqa: F401  (the HIP runtime is torch's)

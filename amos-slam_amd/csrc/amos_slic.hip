@@ -161,6 +161,96 @@ __global__ void k_fill(T *p, size_t n, T v)
     if (i < n) p[i] = v;
 }
 
+
+// ---- cluster::randCent + cluster::kmeans (src/cluster.cc:353-460): the k-means over the SLIC centres that assigns every
+// superpixel its cluster id.  One work-group per frame; the centres stay in registers (kKmPer per thread), the k
+// centroids in LDS; a pass = nearest centroid of every centre (distEclud :374-387 in doubles with explicit
+// round-to-nearest operations: |dD| / 20000 + sqrt(dx^2 + dy^2) / 800, strict < keeps the first centroid), then the
+// integer means of x, y, D per cluster (wave-level sums, one LDS atomic per wave and cluster), until no assignment
+// changes.  The reference's undefined behaviours are defined as in the oracle (seeded glibc TYPE_0 generator, index
+// rowLen wraps to 0, bounded redraw, zero-initialised accumulator): DESIGN.md section 7.
+constexpr int kKmThreads = 1024, kKmPer = 16, kKmMaxK = 64;
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kKmThreads) void k_kmeans(amos_slic_center *__restrict__ centers, int n, size_t frameStride, int k, uint32_t seed,
+                                                      int maxIter, int *__restrict__ passesOut)
+{
+    __shared__ int cx[kKmMaxK], cy[kKmMaxK], cd[kKmMaxK], sx[kKmMaxK], sy[kKmMaxK], sd[kKmMaxK], cnt[kKmMaxK], changed[2];
+    amos_slic_center *C = centers + (size_t)blockIdx.x * frameStride;
+    const int tid = threadIdx.x;
+    if (tid == 0) {  // randCent, sequential like the reference
+        uint32_t state = seed;
+        auto draw = [&]() { state = state * 1103515245u + 12345u; int idx = (int)((state & 0x7fffffffu) % (uint32_t)n) + 1; return idx >= n ? 0 : idx; };
+        for (int i = 0; i < k; i++) {
+            int idx = draw();
+            for (int tries = 0; C[idx].D <= 0 && tries < 4 * n; tries++) idx = draw();
+            cx[i] = C[idx].x; cy[i] = C[idx].y; cd[i] = C[idx].D;
+        }
+        changed[0] = changed[1] = 0;
+    }
+    int px[kKmPer], py[kKmPer], pd[kKmPer], as[kKmPer];
+#pragma unroll
+    for (int j = 0; j < kKmPer; j++) {
+        const int i = tid + j * kKmThreads;
+        px[j] = i < n ? C[i].x : 0; py[j] = i < n ? C[i].y : 0; pd[j] = i < n ? C[i].D : 0;
+        as[j] = -1;
+    }
+    __syncthreads();
+    int passes = 0;
+    for (;;) {
+        if (passes >= maxIter) { passes = -1; break; }
+        passes++;
+        if (tid < k) { sx[tid] = sy[tid] = sd[tid] = cnt[tid] = 0; }
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < kKmPer; j++) {
+            if (tid + j * kKmThreads < n) {
+                int minIndex = -1;
+                double minDist = 2147483647.0;
+                for (int c = 0; c < k; c++) {
+                    const double sumD = __ddiv_rn((double)abs(pd[j] - cd[c]), 20000.0);
+                    const int dx = cx[c] - px[j], dy = cy[c] - py[j];
+                    const double sumE = __ddiv_rn(__dsqrt_rn((double)(dx * dx + dy * dy)), 800.0);  // sqrt(640^2 + 480^2) = 800
+                    const double dist = __dadd_rn(sumE, sumD);
+                    if (dist < minDist) { minDist = dist; minIndex = c; }
+                }
+                if (as[j] != minIndex) { mine = 1; as[j] = minIndex; }
+            }
+        }
+        if (mine) changed[passes & 1] = 1;  // any writer: the flag of this pass
+        __syncthreads();
+        for (int c = 0; c < k; c++) {  // integer sums per cluster
+            int a = 0, b = 0, d = 0, m = 0;
+#pragma unroll
+            for (int j = 0; j < kKmPer; j++)
+                if (as[j] == c) { a += px[j]; b += py[j]; d += pd[j]; m++; }
+            a = wave_sum(a); b = wave_sum(b); d = wave_sum(d); m = wave_sum(m);
+            if ((tid & 63) == 0 && m) { atomicAdd(&sx[c], a); atomicAdd(&sy[c], b); atomicAdd(&sd[c], d); atomicAdd(&cnt[c], m); }
+        }
+        __syncthreads();
+        const int any = changed[passes & 1];
+        if (tid < k) {
+            const int m = cnt[tid];
+            cx[tid] = m ? sx[tid] / m : 0; cy[tid] = m ? sy[tid] / m : 0; cd[tid] = m ? sd[tid] / m : 0;
+        }
+        if (tid == 0) changed[(passes + 1) & 1] = 0;
+        __syncthreads();
+        if (!any) break;
+    }
+#pragma unroll
+    for (int j = 0; j < kKmPer; j++) {
+        const int i = tid + j * kKmThreads;
+        if (i < n) C[C[i].label - 1].id = as[j];
+    }
+    if (tid == 0 && passesOut) passesOut[blockIdx.x] = passes;
+}
+
 }  // namespace amos
 
 using namespace amos;
@@ -176,6 +266,7 @@ struct amos_slic {
     uint16_t *dDepth = nullptr;
     double *dLabels = nullptr;
     amos_slic_center *dCenters = nullptr;
+    int *dPasses = nullptr;
 };
 
 extern "C" {
@@ -278,6 +369,41 @@ int amos_slic_run(amos_slic *s, const uint8_t *lab, const uint16_t *depth, int w
     AMOS_HIP_CHECK(hipStreamSynchronize(s->stream));
     if (n_centers) *n_centers = ncent;
     return AMOS_OK;
+}
+
+
+int amos_cluster_kmeans_batch_device(amos_slic *s, amos_slic_center *d_centers, int n_centers, int n_frames, int k, uint32_t seed, int max_iter,
+                                     int32_t *d_passes)
+{
+    if (!s || !d_centers || n_centers < 1 || n_frames < 1 || k < 1 || k > kKmMaxK || max_iter < 1 || n_centers > kKmThreads * kKmPer) {
+        set_error("amos_cluster_kmeans_batch_device: invalid argument (1 <= k <= %d, centres <= %d)", kKmMaxK, kKmThreads * kKmPer);
+        return AMOS_ERR_INVALID;
+    }
+    AMOS_HIP_CHECK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(k_kmeans, dim3(n_frames), dim3(kKmThreads), 0, s->stream, d_centers, n_centers, (size_t)n_centers, k, seed, max_iter, d_passes);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_cluster_kmeans(amos_slic *s, amos_slic_center *centers, int n_centers, int k, uint32_t seed, int max_iter, int *passes)
+{
+    if (!s || !centers || n_centers < 1) { set_error("amos_cluster_kmeans: invalid argument"); return AMOS_ERR_INVALID; }
+    AMOS_HIP_CHECK(hipSetDevice(s->device));
+    amos_slic_center *d = nullptr;
+    AMOS_HIP_CHECK(hipMalloc((void **)&d, sizeof(amos_slic_center) * n_centers + sizeof(int)));
+    int *dp = reinterpret_cast<int *>(d + n_centers);
+    int rc = AMOS_OK, p = 0;
+    if (hipMemcpyAsync(d, centers, sizeof(amos_slic_center) * n_centers, hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = AMOS_ERR_DEVICE;
+    if (rc == AMOS_OK) rc = amos_cluster_kmeans_batch_device(s, d, n_centers, 1, k, seed, max_iter, dp);
+    if (rc == AMOS_OK && (hipMemcpyAsync(centers, d, sizeof(amos_slic_center) * n_centers, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                          hipMemcpyAsync(&p, dp, sizeof(int), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                          hipStreamSynchronize(s->stream) != hipSuccess)) {
+        set_error("amos_cluster_kmeans: copy failed");
+        rc = AMOS_ERR_DEVICE;
+    }
+    (void)hipFree(d);
+    if (passes) *passes = p;
+    return rc;
 }
 
 }  // extern "C"

@@ -359,6 +359,19 @@ int amos_slic_run(amos_slic *s, const uint8_t *lab, const uint16_t *depth, int w
 int amos_slic_batch_device(amos_slic *s, const uint8_t *d_lab, const uint16_t *d_depth, int width, int height, int n_frames,
                            int len, int m, int iterations, double *d_labels, amos_slic_center *d_centers);
 
+/* cluster::randCent + cluster::kmeans (src/cluster.cc:353-460): the k-means over the SLIC centres that gives every
+ * superpixel its cluster id (center::id, read by the label gate of amos_orb_gate through center_ids[label - 1]).
+ * k = 15 in the reference (Frame.cc:525).  Distances as cluster::distEclud (:374-387); the loop runs until no
+ * assignment changes (at most max_iter passes; *passes = -1 if the bound was hit).  The reference's undefined
+ * behaviours are given a definition -- rand() becomes glibc's TYPE_0 generator (state * 1103515245 + 12345, low 31
+ * bits) on the caller's seed, the one-past-the-end draw wraps to centre 0, the redraw on zero depth is bounded, the
+ * uninitialised accumulator of the update step is zero -- so the result is a function of (centres, k, seed).
+ * Centres must carry label = index + 1 (as amos_slic_* writes them).  d_centers: [n_frames][n_centers]. */
+int amos_cluster_kmeans_batch_device(amos_slic *s, amos_slic_center *d_centers, int n_centers, int n_frames, int k,
+                                     uint32_t seed, int max_iter, int32_t *d_passes /* [n_frames] or NULL */);
+int amos_cluster_kmeans(amos_slic *s, amos_slic_center *centers, int n_centers, int k, uint32_t seed, int max_iter,
+                        int *passes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1856,3 +1856,66 @@ int orc_slic(const uint8_t *lab, const uint16_t *depth, int w, int h, int len, i
     free(dis_mask);
     return n;
 }
+
+/* ---------------------------------------------------------------- cluster::randCent + kmeans (src/cluster.cc:353-460) ----
+ * The k-means over the SLIC centres that gives every superpixel its cluster id (centers[label - 1].id, cluster.cc:18-24),
+ * loop for loop as the reference, with its three undefined behaviours given a definition:
+ *   - rand() (libc state shared with the viewer thread, FrameDrawer.cc:198) -> glibc's TYPE_0 generator on an explicit seed:
+ *     state = state * 1103515245 + 12345, value = state & 0x7fffffff;
+ *   - dataSet[rand() % rowLen + 1] reads one past the end for the last value (:358) -> index rowLen wraps to 0;
+ *     the `while (temp.D <= 0)` redraw stops after 4 * rowLen draws (the reference spins forever on an all-zero depth map);
+ *   - the accumulator `center vec;` of the update step is uninitialised (:416) -> zero.
+ * distEclud (:374-387): |dD| / 20000 + sqrt(dx^2 + dy^2) / sqrt(640^2 + 480^2), doubles, strict < keeps the first centroid.
+ * The reference loops until no assignment changes; max_iter bounds that (returns the passes made, -1 if the bound was hit). */
+static uint32_t orc_lcg(uint32_t *state)
+{
+    *state = *state * 1103515245u + 12345u;
+    return *state & 0x7fffffffu;
+}
+
+int orc_kmeans(amos_slic_center *centers, int n, int k, uint32_t seed, int max_iter)
+{
+    if (n < 1 || k < 1) return 0;
+    int *cx = (int *)malloc(sizeof(int) * k), *cy = (int *)malloc(sizeof(int) * k), *cd = (int *)malloc(sizeof(int) * k);
+    int *assign = (int *)malloc(sizeof(int) * n);
+    uint32_t state = seed;
+    for (int i = 0; i < k; i++) { /* randCent */
+        int idx = (int)(orc_lcg(&state) % (uint32_t)n) + 1;
+        if (idx >= n) idx = 0;
+        for (int tries = 0; centers[idx].D <= 0 && tries < 4 * n; tries++) {
+            idx = (int)(orc_lcg(&state) % (uint32_t)n) + 1;
+            if (idx >= n) idx = 0;
+        }
+        cx[i] = centers[idx].x; cy[i] = centers[idx].y; cd[i] = centers[idx].D;
+    }
+    for (int i = 0; i < n; i++) assign[i] = -1;
+    const double max_D = 20000, max_E = sqrt((double)(640 * 640 + 480 * 480));
+    int passes = 0, changed = 1;
+    while (changed) {
+        if (passes >= max_iter) { passes = -1; break; }
+        changed = 0;
+        passes++;
+        for (int i = 0; i < n; i++) {
+            int minIndex = -1;
+            double minDist = 2147483647.0;
+            for (int j = 0; j < k; j++) {
+                const double sum_D = abs(centers[i].D - cd[j]) / max_D;
+                const int dx = cx[j] - centers[i].x, dy = cy[j] - centers[i].y;
+                const double sum_E = sqrt((double)(dx * dx + dy * dy)) / max_E;
+                const double dist = 1 * sum_E + 1 * sum_D;
+                if (dist < minDist) { minDist = dist; minIndex = j; }
+            }
+            if (assign[i] != minIndex) { changed = 1; assign[i] = minIndex; }
+        }
+        for (int c = 0; c < k; c++) {
+            int sx = 0, sy = 0, sd = 0, cnt = 0;
+            for (int i = 0; i < n; i++)
+                if (assign[i] == c) { cnt++; sx += centers[i].x; sy += centers[i].y; sd += centers[i].D; }
+            if (cnt != 0) { sx /= cnt; sy /= cnt; sd /= cnt; }
+            cx[c] = sx; cy[c] = sy; cd[c] = sd;
+        }
+    }
+    for (int i = 0; i < n; i++) centers[centers[i].label - 1].id = assign[i]; /* :448-452 + cluster.cc:18-24 */
+    free(cx); free(cy); free(cd); free(assign);
+    return passes;
+}

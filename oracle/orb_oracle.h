@@ -141,6 +141,9 @@ int orc_search_by_sim3(const amos_frame_view *kf1, const amos_frame_view *kf2, c
 int orc_slic(const uint8_t *lab, const uint16_t *depth, int w, int h, int len, int m, int iterations, double *labels,
              amos_slic_center *centers, int cap);
 
+/* cluster::randCent + kmeans with a seeded generator (see orb_oracle.c): writes centers[].id; returns the passes made. */
+int orc_kmeans(amos_slic_center *centers, int n, int k, uint32_t seed, int max_iter);
+
 #ifdef __cplusplus
 }
 #endif

@@ -319,3 +319,10 @@ def slic(lab, depth, length=5, m=10, iterations=5):
                        C.c_int(cap))
     assert 0 < n <= cap
     return labels, centers[:n]
+
+
+def kmeans(centers, k=15, seed=1, max_iter=1000):
+    """orc_kmeans: cluster::randCent + kmeans (cluster.cc:353-460) with the seeded generator.  Returns (centres with id, passes)."""
+    c = np.ascontiguousarray(centers, SLIC_CENTER_DTYPE).copy()
+    passes = lib().orc_kmeans(_p(c), C.c_int(len(c)), C.c_int(k), C.c_uint32(seed), C.c_int(max_iter))
+    return c, passes
