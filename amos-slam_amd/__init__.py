@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -412,6 +412,29 @@ def mask_bias_act(stream_ptr, y_ptr, bias_ptr, residual_ptr, n, channels, relu):
     """amos_mask_bias_act_device: y = act((y + bias[c]) + residual) in place on an NHWC float32 tensor (device pointers)."""
     _check(lib().amos_mask_bias_act_device(C.c_void_p(stream_ptr), C.c_void_p(y_ptr), C.c_void_p(bias_ptr), C.c_void_p(residual_ptr), C.c_size_t(n),
                                            C.c_int(channels), C.c_int(int(relu))), "amos_mask_bias_act_device")
+
+
+class SceneFlowCamera(C.Structure):
+    """amos_scene_flow_camera (include/amos_frontend.h)."""
+    _fields_ = [("cx", C.c_float), ("cy", C.c_float), ("invfx", C.c_float), ("invfy", C.c_float), ("Tlw", C.c_float * 12), ("Rwc", C.c_float * 9),
+                ("Ow", C.c_float * 3)]
+
+
+def flow_check(stream, d_last, last_stride, d_cur, cur_stride, cols, rows, d_pre, d_next, d_state_in, n, d_state_out):
+    _check(lib().amos_flow_check_device(C.c_void_p(stream), C.c_void_p(d_last), C.c_size_t(last_stride), C.c_void_p(d_cur), C.c_size_t(cur_stride),
+                                        C.c_int(cols), C.c_int(rows), C.c_void_p(d_pre), C.c_void_p(d_next), C.c_void_p(d_state_in), C.c_int(n),
+                                        C.c_void_p(d_state_out)), "amos_flow_check_device")
+
+
+def flow_epipolar(stream, d_F, d_pre, d_next, d_state, n, d_dd):
+    _check(lib().amos_flow_epipolar_device(C.c_void_p(stream), C.c_void_p(d_F), C.c_void_p(d_pre), C.c_void_p(d_next), C.c_void_p(d_state), C.c_int(n),
+                                           C.c_void_p(d_dd)), "amos_flow_epipolar_device")
+
+
+def flow_scene_flow(stream, d_depth_last, last_stride, d_depth_cur, cur_stride, d_match_pre, d_match_cur, n, cam, d_out):
+    _check(lib().amos_flow_scene_flow_device(C.c_void_p(stream), C.c_void_p(d_depth_last), C.c_size_t(last_stride), C.c_void_p(d_depth_cur),
+                                             C.c_size_t(cur_stride), C.c_void_p(d_match_pre), C.c_void_p(d_match_cur), C.c_int(n), C.byref(cam),
+                                             C.c_void_p(d_out)), "amos_flow_scene_flow_device")
 
 
 def image_bounds(width, height, fx, fy, cx, cy, dist_coef):

@@ -372,6 +372,34 @@ int amos_cluster_kmeans_batch_device(amos_slic *s, amos_slic_center *d_centers, 
 int amos_cluster_kmeans(amos_slic *s, amos_slic_center *centers, int n_centers, int k, uint32_t seed, int max_iter,
                         int *passes);
 
+/* ---------------------------------------------------------------- scene flow, point arithmetic (8f-3) ---- */
+
+/* The reference's own per-point arithmetic inside Tracking::GetSceneFlowObj (src/Tracking.cc:850-1186), between its
+ * OpenCV calls (goodFeaturesToTrack, cornerSubPix, calcOpticalFlowPyrLK, findFundamentalMat, solvePnPRansac stay with
+ * the caller).  Points are interleaved (x, y) float pairs; all pointers are device pointers; asynchronous on `stream`.
+ *
+ * amos_flow_check_device (:902-925): state_out[i] = 0 when either position lies within 5 px of the image edge or the
+ * 3 x 3 sum of absolute gray differences between (last, pre) and (cur, next) exceeds 2520; else state_in[i].  The
+ * match lists of the reference are the points with state_out != 0, in order. */
+int amos_flow_check_device(void *stream, const uint8_t *d_last_gray, size_t last_stride, const uint8_t *d_cur_gray,
+                           size_t cur_stride, int cols, int rows, const float *d_pre_xy, const float *d_next_xy,
+                           const uint8_t *d_state_in, int n, uint8_t *d_state_out);
+/* (:928-946, 1141-1152): dd[i] = |l . (next, 1)| / sqrt(l0^2 + l1^2) with l = F * (pre, 1), F row-major 3 x 3 doubles on
+ * the device; -1 where d_state (may be NULL) is 0.  The reference keeps dd <= 0.5 for the second F and marks dd > 1. */
+int amos_flow_epipolar_device(void *stream, const double *d_F, const float *d_pre_xy, const float *d_next_xy,
+                              const uint8_t *d_state, int n, double *d_dd);
+/* (:955-990, 1153-1183): per match the world point of the LAST frame's pixel (pre_3d, through mLastFrame.mTcw), of the
+ * CURRENT frame's pixel (cur_3d, through mRwc / mOw), the flow norm sqrt(dx^2 + dz^2) and a validity flag (z1 > 0 &&
+ * z2 > 0): out[i] = {pre_3d.xyz, cur_3d.xyz, sf_norm, valid}.  Depth maps are float32 (rows `stride` floats apart). */
+typedef struct amos_scene_flow_camera {
+    float cx, cy, invfx, invfy; /* Frame::cx, cy, invfx, invfy */
+    float Tlw[12];              /* mLastFrame.mTcw, first three rows (row-major 3 x 4) */
+    float Rwc[9], Ow[3];        /* mCurrentFrame.mRwc (row-major), mOw */
+} amos_scene_flow_camera;
+int amos_flow_scene_flow_device(void *stream, const float *d_depth_last, size_t last_stride, const float *d_depth_cur,
+                                size_t cur_stride, const float *d_match_pre_xy, const float *d_match_cur_xy, int n,
+                                const amos_scene_flow_camera *cam, float *d_out);
+
 #ifdef __cplusplus
 }
 #endif
