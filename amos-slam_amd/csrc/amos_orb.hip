@@ -12,6 +12,7 @@
 #include "orb_kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstring>
 #include <vector>
