@@ -91,16 +91,18 @@ __global__ __launch_bounds__(256) void k_mask_pre_c(const float *__restrict__ ba
 // (channels-last) float tensor.  MIOpen's convolutions take no bias and PyTorch adds it, the residual and the ReLU as
 // one elementwise pass each over the activations (three reads + three writes of the tensor per bottleneck output);
 // this is one read (+ the residual) and one write.  Sums in the order (y + b) + r, like the unfused ops: same bits.
-// grid = ceil(n / 4 / 256), block = 256; kVec: channels % 4 == 0 and 16-byte aligned pointers.
-template <bool kVec>
+// grid = ceil(n / 4 / 256), block = 256; kVec: channels % 4 == 0 and 16-byte aligned pointers; kPow2: channels is a
+// power of two (every ResNet / FPN width), so the channel of an element is a mask, not a 64-bit modulo.
+template <bool kVec, bool kPow2>
 __global__ __launch_bounds__(256) void k_bias_act(float *__restrict__ y, const float *__restrict__ bias, const float *__restrict__ res, size_t n,
                                                  int channels, int relu)
 {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     if (kVec) {
+        const unsigned c = kPow2 ? ((unsigned)i & (unsigned)(channels - 1)) : (unsigned)(i % (size_t)channels);
         float4 v = *reinterpret_cast<const float4 *>(y + i);
-        const float4 b = *reinterpret_cast<const float4 *>(bias + (i % (size_t)channels));
+        const float4 b = *reinterpret_cast<const float4 *>(bias + c);
         v.x = __fadd_rn(v.x, b.x); v.y = __fadd_rn(v.y, b.y); v.z = __fadd_rn(v.z, b.z); v.w = __fadd_rn(v.w, b.w);
         if (res) {
             const float4 r = *reinterpret_cast<const float4 *>(res + i);
@@ -115,6 +117,34 @@ __global__ __launch_bounds__(256) void k_bias_act(float *__restrict__ y, const f
             y[k] = relu ? fmaxf(v, 0.f) : v;
         }
     }
+}
+
+// ---- bilinear resize of an NHWC float tensor (F.interpolate(..., mode="bilinear", align_corners=False): the FPN's
+// top-down path and the prototype network's x2 step, yolact.py:318-329, config mask_proto_net).  PyTorch's channels-last
+// kernel for this took 13 % of the mask pass (5 ms per call at 32 frames); here a thread makes four channels of one
+// output pixel with 16-byte loads / stores.  Source index and weights as PyTorch computes them in float32:
+// src = scale * (dst + 0.5) - 0.5, clamped at 0, scale = 1 / scale_factor when given, else in / out.
+// grid = (ceil(outW * C / 4 / 256), outH, N), block = 256.
+__global__ __launch_bounds__(256) void k_bilinear_nhwc(const float *__restrict__ x, float *__restrict__ y, int inH, int inW, int outH, int outW, int c4,
+                                                      float scaleH, float scaleW)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= outW * c4) return;
+    const int ox = t / c4, q = t - ox * c4, oy = blockIdx.y, n = blockIdx.z;
+    float fy = __fsub_rn(__fmul_rn(scaleH, __fadd_rn((float)oy, 0.5f)), 0.5f), fx = __fsub_rn(__fmul_rn(scaleW, __fadd_rn((float)ox, 0.5f)), 0.5f);
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < inH - 1 ? 1 : 0), x1 = x0 + (x0 < inW - 1 ? 1 : 0);
+    const float ly = __fsub_rn(fy, (float)y0), lx = __fsub_rn(fx, (float)x0), hy = __fsub_rn(1.f, ly), hx = __fsub_rn(1.f, lx);
+    const float4 *src = reinterpret_cast<const float4 *>(x) + (size_t)n * inH * inW * c4;
+    const float4 a = src[((size_t)y0 * inW + x0) * c4 + q], b = src[((size_t)y0 * inW + x1) * c4 + q];
+    const float4 c = src[((size_t)y1 * inW + x0) * c4 + q], d = src[((size_t)y1 * inW + x1) * c4 + q];
+    auto mix = [&](float p, float r, float s, float u) {  // h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d)
+        return __fadd_rn(__fmul_rn(hy, __fadd_rn(__fmul_rn(hx, p), __fmul_rn(lx, r))), __fmul_rn(ly, __fadd_rn(__fmul_rn(hx, s), __fmul_rn(lx, u))));
+    };
+    reinterpret_cast<float4 *>(y)[(((size_t)n * outH + oy) * outW + ox) * c4 + q] =
+        make_float4(mix(a.x, b.x, c.x, d.x), mix(a.y, b.y, c.y, d.y), mix(a.z, b.z, c.z, d.z), mix(a.w, b.w, c.w, d.w));
 }
 
 }  // namespace amos
@@ -261,8 +291,26 @@ int amos_mask_bias_act_device(void *stream, float *d_y, const float *d_bias, con
     if (n == 0) return AMOS_OK;
     const bool vec = channels % 4 == 0 && ((uintptr_t)d_y | (uintptr_t)d_bias | (uintptr_t)d_residual) % 16 == 0;
     const dim3 grid((unsigned)((n / 4 + 256) / 256)), block(256);
-    if (vec) hipLaunchKernelGGL(k_bias_act<true>, grid, block, 0, (hipStream_t)stream, d_y, d_bias, d_residual, n, channels, relu);
-    else hipLaunchKernelGGL(k_bias_act<false>, grid, block, 0, (hipStream_t)stream, d_y, d_bias, d_residual, n, channels, relu);
+    const bool pow2 = (channels & (channels - 1)) == 0;
+    if (vec && pow2) hipLaunchKernelGGL((k_bias_act<true, true>), grid, block, 0, (hipStream_t)stream, d_y, d_bias, d_residual, n, channels, relu);
+    else if (vec) hipLaunchKernelGGL((k_bias_act<true, false>), grid, block, 0, (hipStream_t)stream, d_y, d_bias, d_residual, n, channels, relu);
+    else hipLaunchKernelGGL((k_bias_act<false, false>), grid, block, 0, (hipStream_t)stream, d_y, d_bias, d_residual, n, channels, relu);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+
+int amos_mask_bilinear_nhwc_device(void *stream, const float *d_x, float *d_y, int n, int in_h, int in_w, int out_h, int out_w, int channels,
+                                   float scale_h, float scale_w)
+{
+    if (!d_x || !d_y || n < 1 || in_h < 1 || in_w < 1 || out_h < 1 || out_w < 1 || channels < 4 || channels % 4 != 0 ||
+        ((uintptr_t)d_x | (uintptr_t)d_y) % 16 != 0 || out_h > 65535 || n > 65535) {
+        set_error("amos_mask_bilinear_nhwc_device: invalid argument (channels % 4 == 0, 16-byte aligned tensors)");
+        return AMOS_ERR_INVALID;
+    }
+    const int c4 = channels / 4;
+    hipLaunchKernelGGL(k_bilinear_nhwc, dim3((out_w * c4 + 255) / 256, out_h, n), dim3(256), 0, (hipStream_t)stream, d_x, d_y, in_h, in_w, out_h, out_w, c4,
+                       scale_h, scale_w);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }

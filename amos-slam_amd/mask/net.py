@@ -45,6 +45,27 @@ def conv_bias_act(conv, x, relu, residual=None):
     return F.relu(y) if relu else y
 
 
+def bilinear(x, size=None, scale_factor=None):
+    """F.interpolate(x, mode="bilinear", align_corners=False).  Float32 channels-last tensors on the GPU go through this
+    project's HIP kernel (amos_mask_bilinear_nhwc_device: PyTorch's channels-last kernel was 13 % of the mask pass); the
+    source index and the weights are computed as PyTorch computes them."""
+    if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last):
+        n, c, h, w = x.shape
+        if size is not None:
+            oh, ow = int(size[0]), int(size[1])
+            sh, sw = float(torch.tensor(h, dtype=torch.float32) / oh), float(torch.tensor(w, dtype=torch.float32) / ow)
+        else:
+            oh, ow = int(h * scale_factor), int(w * scale_factor)
+            sh = sw = float(torch.tensor(1.0, dtype=torch.float32) / scale_factor)
+        y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+        from .. import mask_bilinear_nhwc
+        mask_bilinear_nhwc(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), y.data_ptr(), n, h, w, oh, ow, c, sh, sw)
+        return y
+    if size is not None:
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    return F.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=False)
+
+
 def _fold(conv, bn):
     """conv followed by an inference-mode batch norm == one conv with scaled weights and a bias:
     w' = w * g / sqrt(var + eps),  b' = beta - mean * g / sqrt(var + eps)   (folded in float64, stored float32)."""
@@ -148,7 +169,7 @@ class FeaturePyramid(nn.Module):
             j = n - 1 - k
             x = lat(feats[j])
             if top is not None:
-                x = x + F.interpolate(top, size=feats[j].shape[2:], mode="bilinear", align_corners=False)
+                x = x + bilinear(top, size=feats[j].shape[2:])
             merged[j] = top = x
         outs = [None] * n
         for k, pred in enumerate(self.pred_layers):
@@ -184,7 +205,7 @@ class _NoParams(nn.Module):
 
 class _Upsample2x(nn.Module):
     def forward(self, x):
-        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        return bilinear(x, scale_factor=2)
 
 
 def build_priors(conv_sizes, device="cpu"):

@@ -330,6 +330,12 @@ int amos_orb_detect_color_with_mask_pre_batch_device(amos_orb *h, amos_mask_pre 
 int amos_mask_bias_act_device(void *stream, float *d_y, const float *d_bias, const float *d_residual, size_t n,
                               int channels, int relu);
 
+/* F.interpolate(x, mode="bilinear", align_corners=False) of a channels-last float32 tensor [n][in_h][in_w][channels] ->
+ * [n][out_h][out_w][channels] (the FPN's top-down path and the prototype network's x2 step).  scale_h / scale_w as
+ * PyTorch derives them: 1 / scale_factor when a scale factor was given, else in / out (float32).  channels % 4 == 0. */
+int amos_mask_bilinear_nhwc_device(void *stream, const float *d_x, float *d_y, int n, int in_h, int in_w, int out_h,
+                                   int out_w, int channels, float scale_h, float scale_w);
+
 /* ---------------------------------------------------------------- SLIC superpixels (8f-2) ---- */
 
 /* ORB_SLAM2::center, include/cluster.h:21-30. */

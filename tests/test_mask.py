@@ -299,3 +299,20 @@ def test_fused_conv_epilogue_equals_the_torch_ops(mask, gpu_lib):
                     fused = net_mod.conv_bias_act(conv, x, relu, residual=r)  # with its own convolution call (MIOpen may pick another solver)
                     assert fused.shape == want.shape and torch.allclose(fused, want, rtol=1e-4, atol=1e-4)
     # the engine end to end is covered by test_network_with_folded_batch_norms_vs_reference_gpu (golden tensors, IoU)
+
+
+@pytest.mark.gpu
+def test_hip_bilinear_nhwc_equals_torch_interpolate(mask, gpu_lib):
+    """amos_mask_bilinear_nhwc_device against F.interpolate(mode="bilinear", align_corners=False) on channels-last tensors: the FPN's
+    size-given form (35 -> 69, 18 -> 35) and the prototype network's scale_factor = 2 (69 -> 138).  Same source indices and
+    weights; PyTorch's kernel contracts multiply-adds, hence a few ulp."""
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    torch.manual_seed(6)
+    for (n, c, h, w), kw in (((3, 256, 35, 35), dict(size=(69, 69))), ((2, 256, 18, 18), dict(size=(35, 35))), ((2, 256, 69, 69), dict(scale_factor=2)),
+                             ((1, 8, 5, 7), dict(size=(11, 13)))):
+        x = torch.randn(n, c, h, w, device="cuda").contiguous(memory_format=torch.channels_last)
+        got = net_mod.bilinear(x, **kw)
+        want = torch.nn.functional.interpolate(x, mode="bilinear", align_corners=False, **kw)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max())), (n, c, h, w, kw)

@@ -62,3 +62,38 @@ for st, ks in stage.items():
     n_pass = max(per_kernel["amos::k_octree"]["SQ_INSTS_VALU"]["launches"], 1) if "SQ_INSTS_VALU" in per_kernel.get("amos::k_octree", {}) else 1
     print(f"{st:9s} {tot / 1e6:8.1f} MB HBM, {valu / n_pass / 1e6:7.2f} M VALU wave-instructions per pass of {frames} frames")
 json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
+
+# ---- steady-state per-kernel table of the traced command (rocprofv3's own kernel_stats.csv covers the whole process,
+# including MIOpen's solver search on the first call of every convolution shape, whose naive reference kernels dwarf
+# everything else): the timed steps of the mask-on region and of the mask-off leg, from kernel_trace.csv
+trace = max(glob.glob(f"{src}/trace/*/*kernel_trace.csv"), key=os.path.getmtime)
+rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
+
+
+def window(first_kernel, n_last):
+    idx = [i for i, r in enumerate(rows) if first_kernel in r["Kernel_Name"]]
+    if len(idx) < n_last + 1:
+        return []
+    return rows[idx[-n_last - 1]:idx[-1]]
+
+
+def table(rs, path, what):
+    acc = collections.defaultdict(list)
+    for r in rs:
+        acc[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    total = sum(sum(v) for v in acc.values())
+    span = int(rs[-1]["End_Timestamp"]) - int(rs[0]["Start_Timestamp"]) if rs else 0
+    with open(path, "w") as f:
+        f.write(f"# {what}; window {span / 1e6:.3f} ms wall, {total / 1e6:.3f} ms of kernel time (kernels of different lanes overlap)\n")
+        f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage"\n')
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            f.write(f'"{k[:160]}",{len(v)},{sum(v)},{sum(v) / len(v):.1f},{100.0 * sum(v) / max(total, 1):.2f}\n')
+
+
+lanes = bench["config"]["lanes_per_gpu"]
+on = window("k_import_color_mask", 3 * lanes)  # the last three timed steps of the mask-on region
+if on:
+    table(on, f"profiles/{tag}_steady_mask_on_kernel_stats.csv", "last 3 steps of the default command's timed region (BASELINE configs[2], mask on)")
+off = window("k_pyramid_level0_wide", 8 * leg.get("lanes_per_gpu", 4))  # eight steps of the mask-off leg
+if off:
+    table(off, f"profiles/{tag}_steady_mask_off_kernel_stats.csv", "8 steps of the extract+match leg (BASELINE configs[1], mask off)")
