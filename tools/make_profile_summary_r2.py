@@ -35,10 +35,12 @@ for d in sorted(glob.glob(f"{src}/pmc*/")):
 for k, v in per_kernel.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch_corrected"] = int((2 * v["FETCH_SIZE"]["avg_per_launch"] + v["WRITE_SIZE"]["avg_per_launch"]) * 1024)
-    if "SQ_ACTIVE_INST_VALU" in v and "SQ_BUSY_CYCLES" in v and v["SQ_BUSY_CYCLES"]["avg_per_launch"] > 0:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD issues vector work, summed over the chip's SIMDs;
-        # SQ_BUSY_CYCLES is summed over the 32 shader engines' SQs: the ratio below is the usual VALUBusy (percent)
-        pass
+    if "SQ_INSTS_VALU" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"]["avg_per_launch"] > 0:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = the launch's duration in shader clocks.  A CU issues one vector
+        # wave-instruction per cycle (4 SIMDs x one per 4 cycles): instructions / (256 CUs x cycles) = vector-issue utilisation
+        cycles = v["GRBM_GUI_ACTIVE"]["avg_per_launch"] / 8.0
+        v["duration_shader_cycles"] = round(cycles, 1)
+        v["valu_issue_utilisation"] = round(v["SQ_INSTS_VALU"]["avg_per_launch"] / (256.0 * cycles), 4)
 json.dump({"command": "rocprofv3 --pmc <set> (one pass per set) -- python3 bench.py --gpus 1 --config c2 --steps 3 --warmup 1 --cpu-frames 0",
            "sets": ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS", "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"],
            "frames_per_launch": frames,
