@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bilinear_nhwc_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bilinear_nhwc_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -441,6 +441,37 @@ def mask_bilinear_nhwc(stream_ptr, x_ptr, y_ptr, n, in_h, in_w, out_h, out_w, ch
     _check(lib().amos_mask_bilinear_nhwc_device(C.c_void_p(stream_ptr), C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_int(n), C.c_int(in_h), C.c_int(in_w),
                                                 C.c_int(out_h), C.c_int(out_w), C.c_int(channels), C.c_float(scale_h), C.c_float(scale_w)),
            "amos_mask_bilinear_nhwc_device")
+
+
+class LkTracker:
+    """cv::calcOpticalFlowPyrLK on given points (Tracking.cc:896: 22 x 22 window, 5 levels, 20 iterations / 0.01), device resident."""
+
+    def __init__(self, width=640, height=480, win_size=22, max_level=5, device=0, stream=None):
+        self.L = lib()
+        k = C.c_void_p()
+        _check(self.L.amos_lk_create(C.c_int(device), C.c_void_p(stream), C.c_int(width), C.c_int(height), C.c_int(win_size), C.c_int(max_level), C.byref(k)),
+               "amos_lk_create")
+        self.k = k
+        self.L.amos_lk_stream.restype = C.c_void_p
+        self.L.amos_lk_stream.argtypes = [C.c_void_p]
+        self.L.amos_lk_destroy.argtypes = [C.c_void_p]
+        self.L.amos_lk_destroy.restype = None
+        self.levels = self.L.amos_lk_levels(self.k)
+        self.stream = self.L.amos_lk_stream(self.k)
+
+    def close(self):
+        if getattr(self, "k", None):
+            self.L.amos_lk_destroy(self.k)
+            self.k = None
+
+    def __del__(self):
+        self.close()
+
+    def track_device(self, d_prev, prev_stride, d_next, next_stride, d_prev_xy, n, d_next_xy, d_status, d_err=None, max_count=20, epsilon=0.01,
+                     min_eig=1e-4):
+        _check(self.L.amos_lk_track_device(self.k, C.c_void_p(d_prev), C.c_size_t(prev_stride), C.c_void_p(d_next), C.c_size_t(next_stride),
+                                           C.c_void_p(d_prev_xy), C.c_int(n), C.c_int(max_count), C.c_double(epsilon), C.c_float(min_eig),
+                                           C.c_void_p(d_next_xy), C.c_void_p(d_status), C.c_void_p(d_err)), "amos_lk_track_device")
 
 
 def image_bounds(width, height, fx, fy, cx, cy, dist_coef):

@@ -9,6 +9,8 @@
 // RANSACs draw from OpenCV's RNG): they stay with the caller -- DESIGN.md section 7.
 #include "amos_common.h"
 
+#include <algorithm>
+
 namespace amos {
 
 struct FlowPoint {
@@ -95,6 +97,219 @@ __global__ __launch_bounds__(256) void k_scene_flow_3d(const float *__restrict__
     o[7] = 1.f;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// cv::calcOpticalFlowPyrLK as Tracking::GetSceneFlowObj calls it (Tracking.cc:896: 22 x 22 window, maxLevel 5, 20 iterations /
+// epsilon 0.01, minEigThreshold 1e-4), restated from OpenCV 4.5's published algorithm like its CPU checker (lk_oracle.c of the test infrastructure: PARITY
+// UNPINNED; the float accumulation order is defined as the scalar path's, row by row, left to right).
+//   k_lk_level0 / k_lk_pyrdown   buildOpticalFlowPyramid: levels with a REFLECT_101 border of `win` pixels, pyrDown 5 x 5
+//   k_lk_scharr                  calcScharrDeriv into a zero-bordered (dx, dy) plane
+//   k_lk_track                   ONE WAVE PER POINT, all levels in one launch: the 484 window pixels are interpolated in
+//                                parallel (14-bit fixed point), their products go to LDS and every lane adds them up in the
+//                                defined order (same bits in all lanes: no broadcast, no divergence)
+constexpr int kLkMaxLevels = 8;
+
+struct LkLevel {
+    int w, h, pw;        // level size, padded row pitch (w + 2 win)
+    size_t imgOff;       // offset of the padded plane inside one image's pyramid (bytes)
+    size_t derivOff;     // offset of the padded (dx, dy) plane (int16 pairs)
+};
+struct LkArgs {
+    LkLevel lv[kLkMaxLevels];
+    int top, win, maxCount;
+    double epsilon2;
+    float minEig;
+    const uint8_t *prevPyr, *nextPyr;
+    const short *deriv;
+};
+
+__device__ __forceinline__ int lk_refl(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        if (i >= n) i = 2 * n - 2 - i;
+    }
+    return i;
+}
+
+// grid = (ceil(pw * ph / 256), 2 images), block 256: padded level 0 from the gray frames
+__global__ __launch_bounds__(256) void k_lk_level0(const uint8_t *__restrict__ g0, size_t s0, const uint8_t *__restrict__ g1, size_t s1, int w, int h, int win,
+                                                  uint8_t *__restrict__ p0, uint8_t *__restrict__ p1)
+{
+    const int pw = w + 2 * win, ph = h + 2 * win, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= pw * ph) return;
+    const int y = i / pw - win, x = i - (i / pw) * pw - win;
+    const uint8_t *g = blockIdx.y ? g1 : g0;
+    const size_t st = blockIdx.y ? s1 : s0;
+    (blockIdx.y ? p1 : p0)[i] = g[(size_t)lk_refl(y, h) * st + lk_refl(x, w)];
+}
+
+// padded level l from padded level l - 1 (both images): cv::pyrDown at the reflected destination coordinate
+__global__ __launch_bounds__(256) void k_lk_pyrdown(const uint8_t *__restrict__ s0, const uint8_t *__restrict__ s1, int sw, int sh, int spw, int win,
+                                                   uint8_t *__restrict__ d0, uint8_t *__restrict__ d1, int dw, int dh)
+{
+    const int pw = dw + 2 * win, ph = dh + 2 * win, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= pw * ph) return;
+    const int y = lk_refl(i / pw - win, dh), x = lk_refl(i - (i / pw) * pw - win, dw);
+    const uint8_t *src = (blockIdx.y ? s1 : s0) + (size_t)win * spw + win;
+    const int k[5] = {1, 4, 6, 4, 1};
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const uint8_t *row = src + (size_t)lk_refl(2 * y + j - 2, sh) * spw;
+        int hs = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) hs += k[q] * row[lk_refl(2 * x + q - 2, sw)];
+        sum += k[j] * hs;
+    }
+    (blockIdx.y ? d1 : d0)[i] = (uint8_t)((sum + 128) >> 8);
+}
+
+// calcScharrDeriv on the interior of the padded previous-image level; the border of the derivative plane stays zero
+__global__ __launch_bounds__(256) void k_lk_scharr(const uint8_t *__restrict__ img, int w, int h, int pw, int win, short *__restrict__ deriv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    const uint8_t *base = img + (size_t)win * pw + win;
+    auto px = [&](int yy, int xx) { return (int)base[(size_t)lk_refl(yy, h) * pw + lk_refl(xx, w)]; };
+    auto t0 = [&](int xx) { return (int)(short)((px(y - 1, xx) + px(y + 1, xx)) * 3 + px(y, xx) * 10); };  // vertical [3 10 3]
+    auto t1 = [&](int xx) { return (int)(short)(px(y + 1, xx) - px(y - 1, xx)); };                          // vertical [-1 0 1]
+    short *d = deriv + 2 * ((size_t)(y + win) * pw + x + win);
+    d[0] = (short)(t0(x + 1) - t0(x - 1));
+    d[1] = (short)((t1(x + 1) + t1(x - 1)) * 3 + t1(x) * 10);
+}
+
+constexpr int kLkMaxWin = 22, kLkWinPx = kLkMaxWin * kLkMaxWin;
+
+__device__ __forceinline__ float lk_div(float a, float b) { return (float)__ddiv_rn((double)a, (double)b); }   // correctly rounded
+__device__ __forceinline__ float lk_sqrt(float a) { return (float)__dsqrt_rn((double)a); }
+
+// sum of n floats of an LDS array in index order, identically in every lane
+__device__ __forceinline__ float lk_ordered_sum(const float *v, int n)
+{
+    float s = 0.f;
+    for (int i = 0; i < n; i++) s = __fadd_rn(s, v[i]);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_lk_track(const LkArgs a, const float *__restrict__ prevPts, int n, float *__restrict__ nextPts,
+                                                 uint8_t *__restrict__ status, float *__restrict__ err)
+{
+    __shared__ short sI[4][kLkWinPx], sdI[4][2 * kLkWinPx];
+    __shared__ float sP[4][3][kLkWinPx + 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, pt = blockIdx.x * 4 + wv;
+    if (pt >= n) return;  // wave-uniform
+    short *Iw = sI[wv], *dIw = sdI[wv];
+    float *P0 = sP[wv][0], *P1 = sP[wv][1], *P2 = sP[wv][2];
+    const int win = a.win, npx = win * win;
+    const float half = __fmul_rn((float)(win - 1), 0.5f), scale20 = 1.f / (1 << 20);
+    const float ptx = prevPts[2 * pt], pty = prevPts[2 * pt + 1];
+    float outx = 0.f, outy = 0.f, errv = 0.f;
+    int st = 1;
+    auto weights = [](float fa, float fb, int &w00, int &w01, int &w10, int &w11) {
+        w00 = __float2int_rn(__fmul_rn(__fmul_rn(__fsub_rn(1.f, fa), __fsub_rn(1.f, fb)), 16384.f));
+        w01 = __float2int_rn(__fmul_rn(__fmul_rn(fa, __fsub_rn(1.f, fb)), 16384.f));
+        w10 = __float2int_rn(__fmul_rn(__fmul_rn(__fsub_rn(1.f, fa), fb), 16384.f));
+        w11 = 16384 - w00 - w01 - w10;
+    };
+    for (int level = a.top; level >= 0; level--) {
+        const LkLevel L = a.lv[level];
+        const uint8_t *I = a.prevPyr + L.imgOff, *J = a.nextPyr + L.imgOff;
+        const short *dI = a.deriv + 2 * L.derivOff;
+        const int pw = L.pw;
+        const float sc = (float)(1. / (1 << level));
+        float px = __fmul_rn(ptx, sc), py = __fmul_rn(pty, sc), nx, ny;
+        if (level == a.top) { nx = px; ny = py; }
+        else { nx = __fmul_rn(outx, 2.f); ny = __fmul_rn(outy, 2.f); }
+        outx = nx; outy = ny;
+        px = __fsub_rn(px, half); py = __fsub_rn(py, half);
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -win || ipx >= L.w || ipy < -win || ipy >= L.h) {
+            if (level == 0) { st = 0; errv = 0.f; }
+            continue;
+        }
+        int w00, w01, w10, w11;
+        weights(__fsub_rn(px, (float)ipx), __fsub_rn(py, (float)ipy), w00, w01, w10, w11);
+        for (int idx = lane; idx < npx; idx += 64) {  // the window of the first image and its derivatives
+            const int y = idx / win, x = idx - y * win;
+            const uint8_t *src = I + (size_t)(y + ipy + win) * pw + ipx + win + x;
+            const short *ds = dI + 2 * ((size_t)(y + ipy + win) * pw + ipx + win + x);
+            const int ival = (src[0] * w00 + src[1] * w01 + src[pw] * w10 + src[pw + 1] * w11 + (1 << 8)) >> 9;
+            const int ix = (ds[0] * w00 + ds[2] * w01 + ds[2 * pw] * w10 + ds[2 * pw + 2] * w11 + (1 << 13)) >> 14;
+            const int iy = (ds[1] * w00 + ds[3] * w01 + ds[2 * pw + 1] * w10 + ds[2 * pw + 3] * w11 + (1 << 13)) >> 14;
+            Iw[idx] = (short)ival; dIw[2 * idx] = (short)ix; dIw[2 * idx + 1] = (short)iy;
+            P0[idx] = (float)(ix * ix); P1[idx] = (float)(ix * iy); P2[idx] = (float)(iy * iy);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float A11 = __fmul_rn(lk_ordered_sum(P0, npx), scale20), A12 = __fmul_rn(lk_ordered_sum(P1, npx), scale20),
+                    A22 = __fmul_rn(lk_ordered_sum(P2, npx), scale20);
+        float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
+        const float dA = __fsub_rn(A11, A22);
+        const float minEig = lk_div(__fsub_rn(__fadd_rn(A22, A11), lk_sqrt(__fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12)))),
+                                    (float)(2 * win * win));
+        __builtin_amdgcn_wave_barrier();
+        if (minEig < a.minEig || D < 1.1920929e-7f) {
+            if (level == 0) st = 0;
+            continue;
+        }
+        D = lk_div(1.f, D);
+        nx = __fsub_rn(nx, half); ny = __fsub_rn(ny, half);
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < a.maxCount; j++) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
+                if (level == 0) st = 0;
+                break;
+            }
+            weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny), w00, w01, w10, w11);
+            for (int idx = lane; idx < npx; idx += 64) {
+                const int y = idx / win, x = idx - y * win;
+                const uint8_t *Jp = J + (size_t)(y + iny + win) * pw + inx + win + x;
+                const int diff = ((Jp[0] * w00 + Jp[1] * w01 + Jp[pw] * w10 + Jp[pw + 1] * w11 + (1 << 8)) >> 9) - Iw[idx];
+                P0[idx] = (float)(diff * dIw[2 * idx]); P1[idx] = (float)(diff * dIw[2 * idx + 1]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float b1 = __fmul_rn(lk_ordered_sum(P0, npx), scale20), b2 = __fmul_rn(lk_ordered_sum(P1, npx), scale20);
+            __builtin_amdgcn_wave_barrier();
+            const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, b2), __fmul_rn(A22, b1)), D);
+            const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, b1), __fmul_rn(A11, b2)), D);
+            nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
+            outx = __fadd_rn(nx, half); outy = __fadd_rn(ny, half);
+            if (__dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy)) <= a.epsilon2) break;
+            if (j > 0 && (double)fabsf(__fadd_rn(dx, pdx)) < 0.01 && (double)fabsf(__fadd_rn(dy, pdy)) < 0.01) {
+                outx = __fsub_rn(outx, __fmul_rn(dx, 0.5f)); outy = __fsub_rn(outy, __fmul_rn(dy, 0.5f));
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (st && level == 0) {  // the residual of the final position
+            const float ex = __fsub_rn(outx, half), ey = __fsub_rn(outy, half);
+            const int iex = (int)floorf(ex), iey = (int)floorf(ey);
+            if (iex < -win || iex >= L.w || iey < -win || iey >= L.h) { st = 0; continue; }
+            weights(__fsub_rn(ex, (float)iex), __fsub_rn(ey, (float)iey), w00, w01, w10, w11);
+            for (int idx = lane; idx < npx; idx += 64) {
+                const int y = idx / win, x = idx - y * win;
+                const uint8_t *Jp = J + (size_t)(y + iey + win) * pw + iex + win + x;
+                const int diff = ((Jp[0] * w00 + Jp[1] * w01 + Jp[pw] * w10 + Jp[pw + 1] * w11 + (1 << 8)) >> 9) - Iw[idx];
+                P0[idx] = fabsf((float)diff);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            errv = lk_div(__fmul_rn(lk_ordered_sum(P0, npx), 1.f), (float)(32 * win * win));  // errval * 1.f / (32 * w * h): a division
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0) {
+        nextPts[2 * pt] = outx; nextPts[2 * pt + 1] = outy;
+        status[pt] = (uint8_t)st;
+        if (err) err[pt] = errv;
+    }
+}
+
 }  // namespace amos
 
 using namespace amos;
@@ -138,6 +353,101 @@ int amos_flow_scene_flow_device(void *stream, const float *d_depth_last, size_t 
     for (int k = 0; k < 3; k++) a.Ow[k] = cam->Ow[k];
     hipLaunchKernelGGL(k_scene_flow_3d, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_depth_last, d_depth_cur, last_stride, cur_stride,
                        (const FlowPoint *)d_match_pre_xy, (const FlowPoint *)d_match_cur_xy, n, a, d_out);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+
+struct amos_lk {
+    int device = 0, w = 0, h = 0, win = 22, maxLevel = 5, top = 0, maxPoints = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    LkArgs args{};
+    uint8_t *dPrev = nullptr, *dNext = nullptr;
+    short *dDeriv = nullptr;
+    size_t pyrBytes = 0;
+};
+
+int amos_lk_create(int device, void *stream, int width, int height, int win_size, int max_level, amos_lk **out)
+{
+    if (!out || win_size < 3 || win_size > kLkMaxWin || max_level < 0 || max_level >= kLkMaxLevels || width <= win_size || height <= win_size) {
+        set_error("amos_lk_create: invalid argument (3 <= win_size <= %d, frame larger than the window)", kLkMaxWin);
+        return AMOS_ERR_INVALID;
+    }
+    AMOS_HIP_CHECK(hipSetDevice(device));
+    amos_lk *k = new amos_lk();
+    k->device = device; k->w = width; k->h = height; k->win = win_size; k->maxLevel = max_level;
+    if (stream) k->stream = (hipStream_t)stream;
+    else {
+        if (hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete k; return AMOS_ERR_DEVICE; }
+        k->ownStream = true;
+    }
+    size_t off = 0;
+    int w = width, h = height, level = 0;
+    for (;; level++) {  // buildOpticalFlowPyramid's level count
+        LkLevel &L = k->args.lv[level];
+        L.w = w; L.h = h; L.pw = w + 2 * win_size;
+        L.imgOff = off; L.derivOff = off;
+        off += ((size_t)L.pw * (h + 2 * win_size) + 255) / 256 * 256;
+        if (level == max_level) break;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        if (w <= win_size || h <= win_size) break;
+    }
+    k->top = k->args.top = level;
+    k->args.win = win_size;
+    k->pyrBytes = off;
+    hipError_t e = hipMalloc((void **)&k->dPrev, off + 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&k->dNext, off + 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&k->dDeriv, sizeof(short) * 2 * off + 64);
+    if (e == hipSuccess) e = hipMemsetAsync(k->dDeriv, 0, sizeof(short) * 2 * off + 64, k->stream);  // the derivative border is zero and never written
+    if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
+    if (e != hipSuccess) { set_error("amos_lk_create: %s", hipGetErrorString(e)); amos_lk_destroy(k); return AMOS_ERR_DEVICE; }
+    k->args.prevPyr = k->dPrev; k->args.nextPyr = k->dNext; k->args.deriv = k->dDeriv;
+    *out = k;
+    return AMOS_OK;
+}
+
+void amos_lk_destroy(amos_lk *k)
+{
+    if (!k) return;
+    (void)hipSetDevice(k->device);
+    if (k->stream) (void)hipStreamSynchronize(k->stream);
+    for (void *p : {(void *)k->dPrev, (void *)k->dNext, (void *)k->dDeriv}) if (p) (void)hipFree(p);
+    if (k->ownStream && k->stream) (void)hipStreamDestroy(k->stream);
+    delete k;
+}
+
+void *amos_lk_stream(amos_lk *k) { return k ? (void *)k->stream : nullptr; }
+int amos_lk_levels(const amos_lk *k) { return k ? k->top : AMOS_ERR_INVALID; }
+
+int amos_lk_track_device(amos_lk *k, const uint8_t *d_prev_gray, size_t prev_stride, const uint8_t *d_next_gray, size_t next_stride, const float *d_prev_xy,
+                         int n, int max_count, double epsilon, float min_eig_threshold, float *d_next_xy, uint8_t *d_status, float *d_err)
+{
+    if (!k || !d_prev_gray || !d_next_gray || !d_prev_xy || !d_next_xy || !d_status || n < 0 || prev_stride < (size_t)k->w || next_stride < (size_t)k->w) {
+        set_error("amos_lk_track_device: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    if (n == 0) return AMOS_OK;
+    AMOS_HIP_CHECK(hipSetDevice(k->device));
+    const int win = k->win;
+    const LkLevel &L0 = k->args.lv[0];
+    hipLaunchKernelGGL(k_lk_level0, dim3((L0.pw * (L0.h + 2 * win) + 255) / 256, 2), dim3(256), 0, k->stream, d_prev_gray, prev_stride, d_next_gray, next_stride,
+                       k->w, k->h, win, k->dPrev, k->dNext);
+    for (int l = 1; l <= k->top; l++) {
+        const LkLevel &S = k->args.lv[l - 1], &D = k->args.lv[l];
+        hipLaunchKernelGGL(k_lk_pyrdown, dim3((D.pw * (D.h + 2 * win) + 255) / 256, 2), dim3(256), 0, k->stream, k->dPrev + S.imgOff, k->dNext + S.imgOff, S.w,
+                           S.h, S.pw, win, k->dPrev + D.imgOff, k->dNext + D.imgOff, D.w, D.h);
+    }
+    for (int l = 0; l <= k->top; l++) {
+        const LkLevel &L = k->args.lv[l];
+        hipLaunchKernelGGL(k_lk_scharr, dim3((L.w * L.h + 255) / 256), dim3(256), 0, k->stream, k->dPrev + L.imgOff, L.w, L.h, L.pw, win, k->dDeriv + 2 * L.derivOff);
+    }
+    LkArgs a = k->args;
+    a.maxCount = std::min(std::max(max_count, 0), 100);
+    const double eps = std::min(std::max(epsilon, 0.), 10.);
+    a.epsilon2 = eps * eps;
+    a.minEig = min_eig_threshold;
+    hipLaunchKernelGGL(k_lk_track, dim3((n + 3) / 4), dim3(256), 0, k->stream, a, d_prev_xy, n, d_next_xy, d_status, d_err);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }

@@ -406,6 +406,21 @@ int amos_flow_scene_flow_device(void *stream, const float *d_depth_last, size_t 
                                 size_t cur_stride, const float *d_match_pre_xy, const float *d_match_cur_xy, int n,
                                 const amos_scene_flow_camera *cam, float *d_out);
 
+/* cv::calcOpticalFlowPyrLK(imlast, gray, prepoint, nextpoint, state, err, Size(22, 22), 5, TermCriteria(COUNT | EPS, 20, 0.01))
+ * (Tracking.cc:896) on given points: pyramids of both gray frames (pyrDown, REFLECT_101 borders of the window size), Scharr
+ * derivatives of the previous one, the iterative tracker from the top level down -- one wave per point.  Restated from OpenCV
+ * 4.5's published algorithm; the float accumulation order is defined as the scalar path's (row by row, left to right) because
+ * OpenCV's own depends on the SIMD width of its build: PARITY UNPINNED.  win_size <= 22.
+ * amos_lk_levels = buildOpticalFlowPyramid's return (4 for 640 x 480: the 20 x 15 level is smaller than the window). */
+typedef struct amos_lk amos_lk;
+int amos_lk_create(int device, void *stream, int width, int height, int win_size, int max_level, amos_lk **out);
+void amos_lk_destroy(amos_lk *k);
+void *amos_lk_stream(amos_lk *k);
+int amos_lk_levels(const amos_lk *k);
+int amos_lk_track_device(amos_lk *k, const uint8_t *d_prev_gray, size_t prev_stride, const uint8_t *d_next_gray,
+                         size_t next_stride, const float *d_prev_xy, int n, int max_count, double epsilon,
+                         float min_eig_threshold, float *d_next_xy, uint8_t *d_status, float *d_err /* or NULL */);
+
 #ifdef __cplusplus
 }
 #endif

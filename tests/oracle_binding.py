@@ -22,7 +22,7 @@ class OrbParams(C.Structure):
 
 
 def build_oracle():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("orb_oracle.c", "orb_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("orb_oracle.c", "lk_oracle.c", "orb_oracle.h")]
     if (not os.path.exists(ORACLE_SO)
             or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(s) for s in srcs if os.path.exists(s))):
         if os.path.exists(srcs[0]):
@@ -326,3 +326,30 @@ def kmeans(centers, k=15, seed=1, max_iter=1000):
     c = np.ascontiguousarray(centers, SLIC_CENTER_DTYPE).copy()
     passes = lib().orc_kmeans(_p(c), C.c_int(len(c)), C.c_int(k), C.c_uint32(seed), C.c_int(max_iter))
     return c, passes
+
+
+def lk_track(prev, nxt, pts, win=22, max_level=5, max_count=20, epsilon=0.01, min_eig=1e-4):
+    """orc_lk_track: cv::calcOpticalFlowPyrLK as Tracking::GetSceneFlowObj calls it (Tracking.cc:896).  Returns (next_pts, status, err, top level)."""
+    prev, nxt = np.ascontiguousarray(prev, np.uint8), np.ascontiguousarray(nxt, np.uint8)
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    h, w = prev.shape
+    out = np.zeros_like(pts)
+    status = np.zeros(len(pts), np.uint8)
+    err = np.zeros(len(pts), np.float32)
+    f = lib().orc_lk_track
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float,
+                  C.c_void_p, C.c_void_p, C.c_void_p]
+    top = f(_p(prev), prev.strides[0], _p(nxt), nxt.strides[0], w, h, _p(pts), len(pts), win, max_level, max_count, epsilon, min_eig, _p(out), _p(status), _p(err))
+    assert top >= 0
+    return out, status, err, top
+
+
+def lk_pyramid_level(gray, level, win=22, max_level=5):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    img = np.zeros((h, w), np.uint8)
+    deriv = np.zeros((h, w, 2), np.int16)
+    lw, lh = C.c_int(0), C.c_int(0)
+    top = lib().orc_lk_pyramid_level(_p(gray), C.c_size_t(gray.strides[0]), w, h, win, max_level, level, _p(img), _p(deriv), C.byref(lw), C.byref(lh))
+    assert top >= 0
+    return img.reshape(-1)[:lw.value * lh.value].reshape(lh.value, lw.value), deriv.reshape(-1)[:2 * lw.value * lh.value].reshape(lh.value, lw.value, 2), top
