@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bilinear_nhwc_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bilinear_nhwc_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -363,6 +363,11 @@ class Slic:
         _check(self.L.amos_slic_batch_device(self.s, C.c_void_p(d_lab), C.c_void_p(d_depth), C.c_int(width), C.c_int(height), C.c_int(n_frames),
                                              C.c_int(length), C.c_int(m), C.c_int(iterations), C.c_void_p(d_labels), C.c_void_p(d_centers)),
                "amos_slic_batch_device")
+
+    def bgr2lab_batch_device(self, d_bgr, n_pixels, d_lab, rgb_order=False):
+        """cv::cvtColor(COLOR_BGR2Lab), 8-bit (cluster.cc:310)."""
+        _check(self.L.amos_cluster_bgr2lab_batch_device(self.s, C.c_void_p(d_bgr), C.c_size_t(n_pixels), C.c_int(int(rgb_order)), C.c_void_p(d_lab)),
+               "amos_cluster_bgr2lab_batch_device")
 
     def kmeans(self, centers, k=15, seed=1, max_iter=1000):
         """cluster::randCent + kmeans on the SLIC centres (cluster.cc:353-460, seeded): returns (centres with .id set, passes)."""

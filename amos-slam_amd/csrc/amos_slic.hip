@@ -251,6 +251,33 @@ __global__ __launch_bounds__(kKmThreads) void k_kmeans(amos_slic_center *__restr
     if (tid == 0 && passesOut) passesOut[blockIdx.x] = passes;
 }
 
+
+// ---- cv::cvtColor(image, imageLAB, COLOR_BGR2Lab) on 8-bit pixels (src/cluster.cc:310), OpenCV 4.5's fixed-point RGB2Lab_b:
+// sRGB gamma table (256 entries, 3 extra bits), 12-bit XYZ / white-point coefficients, cube-root table (3072 entries, 15
+// fractional bits), L = (296 fY - 1336934) >> 15 etc. with rounding, saturated.  Tables are built on the host in double
+// (OpenCV builds them with its softfloat pow / cbrt: PARITY UNPINNED at the level of single table entries); the primaries and
+// grays come out at OpenCV's documented values (blue 82/207/20, green 224/42/211, red 136/208/195, white 255/128/128).
+// grid = ceil(n / 256), block 256: one pixel per thread.
+struct LabTables {
+    const unsigned short *gamma, *cbrt;
+    int c[9];  // by (R, G, B) for X, Y, Z
+};
+
+__global__ __launch_bounds__(256) void k_bgr2lab(const uint8_t *__restrict__ src, size_t n, int blueIdx, const LabTables t, uint8_t *__restrict__ dst)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int R = t.gamma[src[3 * i + (blueIdx ^ 2)]], G = t.gamma[src[3 * i + 1]], B = t.gamma[src[3 * i + blueIdx]];
+    const int fX = t.cbrt[(R * t.c[0] + G * t.c[1] + B * t.c[2] + 2048) >> 12];
+    const int fY = t.cbrt[(R * t.c[3] + G * t.c[4] + B * t.c[5] + 2048) >> 12];
+    const int fZ = t.cbrt[(R * t.c[6] + G * t.c[7] + B * t.c[8] + 2048) >> 12];
+    const int Lscale = (116 * 255 + 50) / 100, Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
+    auto sat = [](int v) { return (uint8_t)min(max(v, 0), 255); };
+    dst[3 * i] = sat((Lscale * fY + Lshift + (1 << 14)) >> 15);
+    dst[3 * i + 1] = sat((500 * (fX - fY) + 128 * (1 << 15) + (1 << 14)) >> 15);
+    dst[3 * i + 2] = sat((200 * (fY - fZ) + 128 * (1 << 15) + (1 << 14)) >> 15);
+}
+
 }  // namespace amos
 
 using namespace amos;
@@ -267,6 +294,8 @@ struct amos_slic {
     double *dLabels = nullptr;
     amos_slic_center *dCenters = nullptr;
     int *dPasses = nullptr;
+    unsigned short *dLabTabs = nullptr;  // gamma [256] then cube root [3072]
+    int labCoeffs[9] = {0};
 };
 
 extern "C" {
@@ -309,6 +338,7 @@ int amos_slic_create(int device, void *stream, int max_width, int max_height, in
 void amos_slic_destroy(amos_slic *s)
 {
     if (!s) return;
+    if (s->dLabTabs) (void)hipFree(s->dLabTabs);
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     void *ptrs[] = {s->dDis, s->dCk, s->dLab, s->dDepth, s->dLabels, s->dCenters};
@@ -404,6 +434,40 @@ int amos_cluster_kmeans(amos_slic *s, amos_slic_center *centers, int n_centers, 
     (void)hipFree(d);
     if (passes) *passes = p;
     return rc;
+}
+
+
+int amos_cluster_bgr2lab_batch_device(amos_slic *s, const uint8_t *d_bgr, size_t n_pixels, int rgb_order, uint8_t *d_lab)
+{
+    if (!s || !d_bgr || !d_lab) { set_error("amos_cluster_bgr2lab_batch_device: invalid argument"); return AMOS_ERR_INVALID; }
+    if (n_pixels == 0) return AMOS_OK;
+    AMOS_HIP_CHECK(hipSetDevice(s->device));
+    if (!s->dLabTabs) {  // built once per handle, in double like the checker
+        std::vector<unsigned short> tabs(256 + 3072);
+        for (int i = 0; i < 256; i++) {
+            const float x = (float)i / 255.f;
+            const double g = x <= 0.04045f ? (double)x / 12.92 : std::pow(((double)x + 0.055) / 1.055, 2.4);
+            tabs[i] = (unsigned short)std::lrint(255.0 * 8.0 * g);
+        }
+        for (int i = 0; i < 3072; i++) {
+            const float x = (float)i / (255.f * 8.f);
+            const double f = x < 0.008856f ? (double)x * 7.787 + 0.13793103448275862 : std::cbrt((double)x);
+            tabs[256 + i] = (unsigned short)std::lrint(32768.0 * f);
+        }
+        static const double xyz[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+        static const double white[3] = {0.950456, 1., 1.088754};
+        for (int i = 0; i < 3; i++)
+            for (int k = 0; k < 3; k++) s->labCoeffs[3 * i + k] = (int)std::lrint(4096.0 * xyz[3 * i + k] / white[i]);
+        AMOS_HIP_CHECK(hipMalloc((void **)&s->dLabTabs, sizeof(unsigned short) * tabs.size()));
+        AMOS_HIP_CHECK(hipMemcpy(s->dLabTabs, tabs.data(), sizeof(unsigned short) * tabs.size(), hipMemcpyHostToDevice));
+    }
+    LabTables t;
+    t.gamma = s->dLabTabs;
+    t.cbrt = s->dLabTabs + 256;
+    for (int i = 0; i < 9; i++) t.c[i] = s->labCoeffs[i];
+    hipLaunchKernelGGL(k_bgr2lab, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, s->stream, d_bgr, n_pixels, rgb_order ? 2 : 0, t, d_lab);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
 }
 
 }  // extern "C"

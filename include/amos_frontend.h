@@ -365,6 +365,13 @@ int amos_slic_run(amos_slic *s, const uint8_t *lab, const uint16_t *depth, int w
 int amos_slic_batch_device(amos_slic *s, const uint8_t *d_lab, const uint16_t *d_depth, int width, int height, int n_frames,
                            int len, int m, int iterations, double *d_labels, amos_slic_center *d_centers);
 
+/* cv::cvtColor(image, imageLAB, COLOR_BGR2Lab) of cluster::SLIC (src/cluster.cc:310), 8-bit: OpenCV 4.5's fixed-point RGB2Lab_b
+ * (gamma and cube-root tables, 12-bit XYZ coefficients over the D65 white point).  Tables are built in double on the host
+ * (OpenCV uses its softfloat: PARITY UNPINNED at the level of single table entries; primaries and grays match OpenCV's
+ * documented values).  d_bgr / d_lab: n_pixels x 3 bytes; rgb_order != 0 for RGB input.  With amos_slic_batch_device and
+ * amos_cluster_kmeans_batch_device this is the whole `cluster` constructor (cluster.cc:9-43) on the device. */
+int amos_cluster_bgr2lab_batch_device(amos_slic *s, const uint8_t *d_bgr, size_t n_pixels, int rgb_order, uint8_t *d_lab);
+
 /* cluster::randCent + cluster::kmeans (src/cluster.cc:353-460): the k-means over the SLIC centres that gives every
  * superpixel its cluster id (center::id, read by the label gate of amos_orb_gate through center_ids[label - 1]).
  * k = 15 in the reference (Frame.cc:525).  Distances as cluster::distEclud (:374-387); the loop runs until no

@@ -239,3 +239,58 @@ int orc_lk_pyramid_level(const uint8_t *gray, size_t stride, int w, int h, int w
     lk_free(P, top);
     return top;
 }
+
+/* ---------------------------------------------------------------- cv::cvtColor(COLOR_BGR2Lab), 8-bit (src/cluster.cc:310) ----
+ * OpenCV 4.5's RGB2Lab_b: gamma table (sRGB, 3 extra bits), 12-bit XYZ coefficients divided by the D65 white point, cube-root table
+ * of 3072 entries with 15 fractional bits, L = (296 fY - 1336934 + 2^14) >> 15, a = (500 (fX - fY) + 128 * 2^15 + 2^14) >> 15,
+ * b = (200 (fY - fZ) + 128 * 2^15 + 2^14) >> 15, saturated to 8 bits.  PARITY UNPINNED: OpenCV builds the two tables with its softfloat
+ * pow / cbrt; here they come from libm in double (an entry can differ by one where a value falls within an ulp of a rounding
+ * boundary).  blue_idx = 0 for BGR input, 2 for RGB. */
+static int lab_tables_ready = 0;
+static uint16_t lab_gamma_tab[256], lab_cbrt_tab[3072];
+static int lab_coeffs[9];
+
+static void lab_init(void)
+{
+    if (lab_tables_ready) return;
+    for (int i = 0; i < 256; i++) {
+        const float x = (float)i / 255.f;
+        const double g = x <= 0.04045f ? (double)x / 12.92 : pow(((double)x + 0.055) / 1.055, 2.4);
+        lab_gamma_tab[i] = (uint16_t)lrint(255.0 * 8.0 * g);
+    }
+    for (int i = 0; i < 3072; i++) {
+        const float x = (float)i / (255.f * 8.f);
+        const double f = x < 0.008856f ? (double)x * 7.787 + 0.13793103448275862 : cbrt((double)x);
+        lab_cbrt_tab[i] = (uint16_t)lrint(32768.0 * f);
+    }
+    static const double xyz[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+    static const double white[3] = {0.950456, 1., 1.088754};
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) lab_coeffs[3 * i + k] = (int)lrint(4096.0 * xyz[3 * i + k] / white[i]);  /* by (R, G, B) */
+    lab_tables_ready = 1;
+}
+
+void orc_lab_tables(uint16_t *gamma, uint16_t *cbrt_tab, int32_t *coeffs)
+{
+    lab_init();
+    if (gamma) memcpy(gamma, lab_gamma_tab, sizeof(lab_gamma_tab));
+    if (cbrt_tab) memcpy(cbrt_tab, lab_cbrt_tab, sizeof(lab_cbrt_tab));
+    if (coeffs) for (int i = 0; i < 9; i++) coeffs[i] = lab_coeffs[i];
+}
+
+static uint8_t lab_sat(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+void orc_bgr_to_lab(const uint8_t *src, size_t n_px, int blue_idx, uint8_t *dst)
+{
+    lab_init();
+    const int Lscale = (116 * 255 + 50) / 100, Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
+    for (size_t i = 0; i < n_px; i++) {
+        const int R = lab_gamma_tab[src[3 * i + (blue_idx ^ 2)]], G = lab_gamma_tab[src[3 * i + 1]], B = lab_gamma_tab[src[3 * i + blue_idx]];
+        const int fX = lab_cbrt_tab[LK_DESCALE(R * lab_coeffs[0] + G * lab_coeffs[1] + B * lab_coeffs[2], 12)];
+        const int fY = lab_cbrt_tab[LK_DESCALE(R * lab_coeffs[3] + G * lab_coeffs[4] + B * lab_coeffs[5], 12)];
+        const int fZ = lab_cbrt_tab[LK_DESCALE(R * lab_coeffs[6] + G * lab_coeffs[7] + B * lab_coeffs[8], 12)];
+        dst[3 * i] = lab_sat(LK_DESCALE(Lscale * fY + Lshift, 15));
+        dst[3 * i + 1] = lab_sat(LK_DESCALE(500 * (fX - fY) + 128 * (1 << 15), 15));
+        dst[3 * i + 2] = lab_sat(LK_DESCALE(200 * (fY - fZ) + 128 * (1 << 15), 15));
+    }
+}

@@ -353,3 +353,11 @@ def lk_pyramid_level(gray, level, win=22, max_level=5):
     top = lib().orc_lk_pyramid_level(_p(gray), C.c_size_t(gray.strides[0]), w, h, win, max_level, level, _p(img), _p(deriv), C.byref(lw), C.byref(lh))
     assert top >= 0
     return img.reshape(-1)[:lw.value * lh.value].reshape(lh.value, lw.value), deriv.reshape(-1)[:2 * lw.value * lh.value].reshape(lh.value, lw.value, 2), top
+
+
+def bgr_to_lab(img, rgb_order=False):
+    """orc_bgr_to_lab: cv::cvtColor(COLOR_BGR2Lab / RGB2Lab) on 8-bit pixels (OpenCV 4.5's fixed-point path, restated)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    lib().orc_bgr_to_lab(_p(img), C.c_size_t(img.size // 3), C.c_int(2 if rgb_order else 0), _p(out))
+    return out

@@ -130,3 +130,66 @@ def test_gpu_kmeans_batch_after_slic(gpu_lib, ob):
         want, passes = ob.kmeans(centres, 15, 11)
         assert int(d_passes[f]) == passes
         assert np.array_equal(got[f].reshape(-1), want.view(np.int32).reshape(-1))
+
+
+def _python_lab(bgr):
+    """OpenCV 4.5 RGB2Lab_b written from its published form, in numpy (independent of the C oracle's code)."""
+    x = np.arange(256, dtype=np.float32) / np.float32(255)
+    lin = np.where(x <= np.float32(0.04045), x.astype(np.float64) / 12.92, ((x.astype(np.float64) + 0.055) / 1.055) ** 2.4)
+    gamma = np.rint(255.0 * 8.0 * lin).astype(np.int64)
+    y = np.arange(3072, dtype=np.float32) / np.float32(255 * 8)
+    cb = np.rint(32768.0 * np.where(y < np.float32(0.008856), y.astype(np.float64) * 7.787 + 0.13793103448275862, np.cbrt(y.astype(np.float64)))).astype(np.int64)
+    m = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    coef = np.rint(4096.0 * m / np.array([0.950456, 1.0, 1.088754])[:, None]).astype(np.int64)
+    B, G, R = (gamma[bgr[..., c]] for c in range(3))
+    f = [cb[(R * coef[i, 0] + G * coef[i, 1] + B * coef[i, 2] + 2048) >> 12] for i in range(3)]
+    L = (296 * f[1] - 1336934 + 16384) >> 15
+    a = (500 * (f[0] - f[1]) + 128 * 32768 + 16384) >> 15
+    b = (200 * (f[1] - f[2]) + 128 * 32768 + 16384) >> 15
+    return np.clip(np.stack([L, a, b], -1), 0, 255).astype(np.uint8)
+
+
+def test_oracle_bgr2lab_known_values_and_numpy(ob):
+    """cv::cvtColor(COLOR_BGR2Lab) 8-bit: OpenCV's documented values for the primaries / grays, and an independent numpy form."""
+    src = np.array([[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 128, 128]], np.uint8)  # BGR
+    assert ob.bgr_to_lab(src).tolist() == [[0, 128, 128], [255, 128, 128], [82, 207, 20], [224, 42, 211], [136, 208, 195], [137, 128, 128]]
+    assert ob.bgr_to_lab(src[:, ::-1].copy(), rgb_order=True).tolist() == ob.bgr_to_lab(src).tolist()
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)
+    assert np.array_equal(ob.bgr_to_lab(img), _python_lab(img))
+
+
+@pytest.mark.gpu
+def test_gpu_bgr2lab_then_slic_then_kmeans(gpu_lib, ob):
+    """The cluster constructor (cluster.cc:9-43) on the device from the BGR frame: BGR2Lab -> SLIC -> k-means, each vs the oracle."""
+    import torch
+    rng = np.random.default_rng(12)
+    h, w = 240, 320
+    bgr = np.kron(rng.integers(0, 256, (h // 16, w // 16, 3)), np.ones((16, 16, 1))).astype(np.uint8)
+    bgr = np.clip(bgr.astype(np.int64) + rng.integers(-20, 21, bgr.shape), 0, 255).astype(np.uint8)
+    depth = (6000 + 3000 * (np.arange(w)[None, :] > w // 2) + rng.integers(0, 80, (h, w))).astype(np.uint16)
+    s = gpu_lib.Slic(max_width=w, max_height=h, max_batch=1)
+    n, _, _ = s.center_count(w, h)
+    d_bgr, d_depth = torch.from_numpy(bgr).cuda(), torch.from_numpy(depth).cuda()
+    d_lab = torch.zeros_like(d_bgr)
+    d_labels = torch.zeros((1, h, w), dtype=torch.float64, device="cuda")
+    d_centers = torch.zeros((1, n, 8), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    s.bgr2lab_batch_device(d_bgr.data_ptr(), h * w, d_lab.data_ptr())
+    s.run_batch_device(d_lab.data_ptr(), d_depth.data_ptr(), w, h, 1, d_labels.data_ptr(), d_centers.data_ptr())
+    s.kmeans_batch_device(d_centers.data_ptr(), n, 1, k=15, seed=3)
+    s.sync()
+    torch.cuda.synchronize()
+    lab = ob.bgr_to_lab(bgr)
+    assert np.array_equal(d_lab.cpu().numpy(), lab)
+    labels, centres = ob.slic(lab, depth)
+    want, _ = ob.kmeans(centres, 15, 3)
+    assert np.array_equal(d_labels.cpu().numpy()[0], labels)
+    assert np.array_equal(d_centers.cpu().numpy()[0].reshape(-1), want.view(np.int32).reshape(-1))
+    # all 2^24 colours: the kernel's table path against the oracle's
+    allc = np.stack(np.meshgrid(np.arange(256), np.arange(256), np.arange(0, 256, 5), indexing="ij"), -1).reshape(-1, 3).astype(np.uint8)
+    d_all = torch.from_numpy(allc).cuda()
+    d_out = torch.zeros_like(d_all)
+    s.bgr2lab_batch_device(d_all.data_ptr(), len(allc), d_out.data_ptr())
+    s.sync()
+    assert np.array_equal(d_out.cpu().numpy(), ob.bgr_to_lab(allc))

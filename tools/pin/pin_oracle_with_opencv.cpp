@@ -6,7 +6,7 @@
 // mismatch (or "identical").  A mismatch localises the wrong recalled constant / rounding rule; all identical pins the
 // oracle, and with it every GPU parity test, to OpenCV.
 //
-//   g++ -O2 -std=c++17 tools/pin/pin_oracle_with_opencv.cpp oracle/orb_oracle.c -Iinclude -Ioracle \
+//   g++ -O2 -std=c++17 tools/pin/pin_oracle_with_opencv.cpp oracle/orb_oracle.c oracle/lk_oracle.c -Iinclude -Ioracle \
 //       $(pkg-config --cflags --libs opencv4) -lm -o pin_oracle && ./pin_oracle
 //
 // NOT BUILT in this project's image (no OpenCV headers there): it is a tool for the reference's maintainer, outside
@@ -23,6 +23,7 @@
 
 extern "C" {
 #include "orb_oracle.h"
+void orc_bgr_to_lab(const uint8_t *src, size_t n_px, int blue_idx, uint8_t *dst);  // oracle/lk_oracle.c
 }
 
 static int g_failures = 0;
@@ -140,6 +141,17 @@ int main()
         cv::cvtColor(src, want, rgb ? cv::COLOR_RGB2GRAY : cv::COLOR_BGR2GRAY);
         orc_color_to_gray(src.data, src.step, 640, 480, 3, rgb, got.data, got.step);
         report(rgb ? "cvtColor RGB2GRAY" : "cvtColor BGR2GRAY", want, got);
+    }
+    // cvtColor BGR2Lab, 8-bit (cluster.cc:310): every (B, G) pair over a coarse R grid
+    {
+        cv::Mat src(256, 256 * 16, CV_8UC3);
+        for (int b = 0; b < 256; b++)
+            for (int g = 0; g < 256; g++)
+                for (int r = 0; r < 16; r++) src.at<cv::Vec3b>(b, g * 16 + r) = cv::Vec3b((uchar)b, (uchar)g, (uchar)(r * 17));
+        cv::Mat want, got(src.size(), CV_8UC3);
+        cv::cvtColor(src, want, cv::COLOR_BGR2Lab);
+        orc_bgr_to_lab(src.data, (size_t)src.rows * src.cols, 0, got.data);
+        report("cvtColor BGR2Lab", want, got);
     }
     // cv::undistortPoints with the TUM1 coefficients (Frame.cc:1052-1118)
     {
