@@ -387,25 +387,31 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // time (two co-resident waves running the same phases in step do not overlap): while the 16 MFMAs of query tiles
 // 2, 3 run, the best-two update of tiles 0, 1 and the bit spreading of the NEXT train tile issue between them, then
 // the 16 MFMAs of tiles 0, 1 of the next train tile run over the update of tiles 2, 3.
-template <bool kGate, int kWaves>
-__global__ __launch_bounds__(64 * kWaves) void k_bf_best2_mfma(const uint8_t *__restrict__ descBaseQ, const uint8_t *__restrict__ descBaseT,
+// kQ = independent 128-query groups per block (each with its own kWaves waves): single-wave work-groups are only ever placed
+// on half of a CU's SIMDs (measured: 1 024 one-wave blocks run in two rounds of 512), multi-wave blocks use all four.
+template <bool kGate, int kWaves, int kQ>
+__global__ __launch_bounds__(64 * kWaves * kQ) void k_bf_best2_mfma(const uint8_t *__restrict__ descBaseQ, const uint8_t *__restrict__ descBaseT,
                                                              size_t frameStrideBytes, const int *__restrict__ counts,
                                                              const int *__restrict__ pairsQ, const int *__restrict__ pairsT,
                                                              int nqFixed, int ntFixed, int capacity, int initDist,
                                                              amos_best2 *__restrict__ out)
 {
-    __shared__ unsigned mB[2 * kWaves][128], mS[2 * kWaves][128];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ unsigned mBq[kQ][2 * kWaves][128], mSq[kQ][2 * kWaves][128];
+    const int lane = threadIdx.x & 63, waveAll = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qg = waveAll / kWaves, wave = waveAll - qg * kWaves, tid = threadIdx.x - qg * 64 * kWaves;  // query group, train-split wave, thread of the group
+    unsigned (*mB)[128] = mBq[qg], (*mS)[128] = mSq[qg];
     const int r = lane & 31, h = lane >> 5;
     const int pair = blockIdx.y;
     const int fq = pairsQ ? pairsQ[pair] : 0, ft = pairsT ? pairsT[pair] : 0;
     const int nq = counts ? min(counts[fq], capacity) : nqFixed;
     const int nt = counts ? min(counts[ft], capacity) : ntFixed;
-    const int q0 = blockIdx.x * 128;
-    if (q0 >= nq) return;  // whole block idle (uniform)
+    const int q0 = (blockIdx.x * kQ + qg) * 128;
+    if (blockIdx.x * kQ * 128 >= nq) return;  // whole block idle (uniform)
+    const bool groupActive = q0 < nq;          // wave-uniform; idle groups of a live block only keep the barrier company
     const uint8_t *qb = descBaseQ + (size_t)fq * frameStrideBytes;
     const uint8_t *tb = descBaseT + (size_t)ft * frameStrideBytes;
     constexpr unsigned M = 0x01010101u;
+    if (groupActive) {
     // B operand: -+1 bytes of the lane's four queries (zero for queries beyond nq)
     v4i Bq[4][4][2];
 #pragma unroll
@@ -550,7 +556,9 @@ __global__ __launch_bounds__(64 * kWaves) void k_bf_best2_mfma(const uint8_t *__
         mB[wave * 2 + h][32 * c + r] = best[c];
         mS[wave * 2 + h][32 * c + r] = second[c];
     }
+    }  // groupActive
     __syncthreads();
+    if (!groupActive) return;
     for (int qq = tid; qq < 128; qq += 64 * kWaves) {
         const int qi = q0 + qq;
         if (qi >= nq) break;
@@ -608,13 +616,19 @@ static void launch_bf(amos_match *m, bool mfma, dim3 gridPop, dim3 gridMfma, con
                       const int *pq, const int *pt, int nq, int nt, int capacity, int initDist, amos_best2 *out)
 {
     static const int forced = getenv("AMOS_MM_WAVES") ? atoi(getenv("AMOS_MM_WAVES")) : 0;  // experiment switch
-    const int waves = forced ? forced : ((size_t)gridMfma.x * gridMfma.y >= 512 ? 1 : 4);
-    if (mfma && waves == 1)  // enough 128-query blocks to fill the chip with one wave each
-        hipLaunchKernelGGL((k_bf_best2_mfma<kGate, 1>), gridMfma, dim3(64), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
-    else if (mfma && waves == 2)
-        hipLaunchKernelGGL((k_bf_best2_mfma<kGate, 2>), gridMfma, dim3(128), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
-    else if (mfma)
-        hipLaunchKernelGGL((k_bf_best2_mfma<kGate, 4>), gridMfma, dim3(256), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
+    // experiment switch: AMOS_MM_WAVES = 10 * (query groups per block) + (train-split waves per group), e.g. 21, 41, 14
+    const int waves = forced ? forced : ((size_t)gridMfma.x * gridMfma.y >= 512 ? 21 : 14);
+    const int cap128 = (int)gridMfma.x;  // 128-query groups per pair
+    if (mfma && waves == 21)   // batched launches: two independent one-wave groups per block
+        hipLaunchKernelGGL((k_bf_best2_mfma<kGate, 1, 2>), dim3((cap128 + 1) / 2, gridMfma.y), dim3(128), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
+    else if (mfma && waves == 41)
+        hipLaunchKernelGGL((k_bf_best2_mfma<kGate, 1, 4>), dim3((cap128 + 3) / 4, gridMfma.y), dim3(256), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
+    else if (mfma && waves == 11)
+        hipLaunchKernelGGL((k_bf_best2_mfma<kGate, 1, 1>), gridMfma, dim3(64), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
+    else if (mfma && waves == 12)
+        hipLaunchKernelGGL((k_bf_best2_mfma<kGate, 2, 1>), gridMfma, dim3(128), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
+    else if (mfma)             // a single pair: four waves split the train tiles of each 128-query group
+        hipLaunchKernelGGL((k_bf_best2_mfma<kGate, 4, 1>), gridMfma, dim3(256), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
     else
         hipLaunchKernelGGL(k_bf_best2<kGate>, gridPop, dim3(256), 0, m->stream, dq, dt, stride, counts, pq, pt, nq, nt, capacity, initDist, out);
 }
