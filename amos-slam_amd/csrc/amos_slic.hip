@@ -246,7 +246,10 @@ __global__ __launch_bounds__(kKmThreads) void k_kmeans(amos_slic_center *__restr
 #pragma unroll
     for (int j = 0; j < kKmPer; j++) {
         const int i = tid + j * kKmThreads;
-        if (i < n) C[C[i].label - 1].id = as[j];
+        if (i < n) {
+            const int lab = C[i].label;  // 1 .. n as the SLIC entry points write them; anything else is left alone
+            if (lab >= 1 && lab <= n) C[lab - 1].id = as[j];
+        }
     }
     if (tid == 0 && passesOut) passesOut[blockIdx.x] = passes;
 }

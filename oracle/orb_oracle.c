@@ -1915,7 +1915,8 @@ int orc_kmeans(amos_slic_center *centers, int n, int k, uint32_t seed, int max_i
             cx[c] = sx; cy[c] = sy; cd[c] = sd;
         }
     }
-    for (int i = 0; i < n; i++) centers[centers[i].label - 1].id = assign[i]; /* :448-452 + cluster.cc:18-24 */
+    for (int i = 0; i < n; i++) /* :448-452 + cluster.cc:18-24 */
+        if (centers[i].label >= 1 && centers[i].label <= n) centers[centers[i].label - 1].id = assign[i];
     free(cx); free(cy); free(cd); free(assign);
     return passes;
 }
