@@ -1,0 +1,217 @@
+// amos_conv1x1.hip -- the 1 x 1 convolutions of the mask network (a15: the ResNet-50 bottlenecks' conv1 / conv3 / downsample and the
+// FPN laterals of yolact.py / backbone.py, 36 of the network's 75 convolutions) as ONE fp32 MFMA GEMM with the
+// bias, the residual and the ReLU in its epilogue.
+//
+// Channels-last activations make a 1 x 1 convolution a plain GEMM:  Y[m][n] = sum_k X[row(m)][k] * W[n][k]  with m = output pixel
+// (batch, y, x), k = input channel (contiguous), n = output channel; a stride only changes row(m).  MIOpen's fp32 implicit-GEMM
+// kernels reach 44 - 96 TFLOP/s on these shapes (tools/conv_fuse_probe.py) and leave the bias / residual / ReLU to a second pass over
+// the output (amos_mask_bias_act_device, 12 % of the mask pass); here the epilogue is free and the low-K layers (64 -> 256 at
+// 138 x 138: 25 FLOP per byte) run at the memory rate.
+//
+// Kernel: work-group = 4 waves, wave tile 64 x 64 (2 x 2 v_mfma_f32_32x32x2_f32 accumulators, 64 VGPRs), work-group tile 128 x 128
+// (128 x 64 with 32 x 64 wave tiles when the output channels are not a multiple of 128).  K advances 32 at a time through double-buffered LDS: every thread fetches its 16-byte pieces
+// of the next X and W tiles into registers before the MFMAs of the current stage and writes them to the other buffer after, one
+// barrier per stage.  LDS rows are 36 floats apart, so the sixteen rows a ds_read_b128 phase touches start 4 banks apart: conflict-free.
+// The sum over k is order-free, so lanes 0-31 take k = 8j .. 8j+3 and lanes 32-63 k = 8j+4 .. 8j+7 of a row with ONE ds_read_b128 and
+// feed four MFMAs from it (MFMA t multiplies k = 8j+t of the low half with k = 8j+4+t of the high half, for X and W alike).
+// Work-group ids are dealt so that the tiles of one row block (all n for the same m) run on the same XCD back to back: X is read from
+// HBM once and from that XCD's L2 afterwards.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/amos_frontend.h"
+#include "amos_common.h"
+
+namespace amos {
+
+constexpr int kGemmBK = 32;                 // k per stage
+constexpr int kGemmPitch = kGemmBK + 4;     // floats between LDS rows
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Conv1x1Args {
+    const float *x, *w, *bias, *res;
+    float *y;
+    int M, N, K;                 // output pixels, output channels, input channels
+    int outW, outHW, inW, inHW;  // row(m): b = m / outHW, (oy, ox) of the rest; input pixel (b * inHW + oy * stride * inW + ox * stride)
+    int stride, relu, mTiles, nTiles;
+};
+
+template <int WM, int WN, int TI>  // waves along m and n; a wave's tile is 32 TI x 64
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_conv1x1(const Conv1x1Args a)  // LDS admits two groups per CU: 256 registers
+{
+    constexpr int BM = 32 * TI * WM, BN = 64 * WN;
+    constexpr int XP = BM / 32, WP = BN / 32;  // 16-byte pieces per thread and stage
+    constexpr int kStage = (BM + BN) * kGemmPitch;  // floats of one stage: the X tile, then the W tile
+    static_assert(2 * kStage >= BM * BN, "the epilogue stages the output tile in the same LDS");
+    __shared__ __align__(16) float smem[2 * kStage];
+    float(*Xs)[kStage] = reinterpret_cast<float(*)[kStage]>(smem);
+    float(*Ws)[kStage] = reinterpret_cast<float(*)[kStage]>(smem + BM * kGemmPitch);
+    // id -> (m tile, n tile): ids are dealt round-robin over the 8 XCDs; within an XCD consecutive work-groups walk the n tiles of one m tile
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int nt = seq % a.nTiles, mt = (seq / a.nTiles) * 8 + xcd;
+    if (mt >= a.mTiles) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int pc = t & 7, pr = t >> 3;  // piece column (4 floats), first row of this thread's pieces
+    const float *xsrc[XP];
+#pragma unroll
+    for (int i = 0; i < XP; i++) {
+        const int m = min(mt * BM + pr + 32 * i, a.M - 1);  // rows past the end repeat the last one; their results are not stored
+        size_t pix = (size_t)m;
+        if (a.stride != 1) {
+            const int b = m / a.outHW, rem = m - b * a.outHW, oy = rem / a.outW, ox = rem - oy * a.outW;
+            pix = (size_t)b * a.inHW + (size_t)oy * a.stride * a.inW + (size_t)ox * a.stride;
+        }
+        xsrc[i] = a.x + pix * a.K + 4 * pc;
+    }
+    const float *wsrc[WP];
+#pragma unroll
+    for (int j = 0; j < WP; j++) wsrc[j] = a.w + (size_t)(nt * BN + pr + 32 * j) * a.K + 4 * pc;
+    static_assert(XP == 4 && (WP == 2 || WP == 4), "the staging registers below are named one by one");
+    float4 x0, x1, x2, x3, w0, w1, w2 = {}, w3 = {};  // (arrays of these end up in scratch once the scheduling fences below are in place)
+#define AMOS_GEMM_FETCH(k0)                                            \
+    {                                                                  \
+        x0 = *reinterpret_cast<const float4 *>(xsrc[0] + (k0));       \
+        x1 = *reinterpret_cast<const float4 *>(xsrc[1] + (k0));       \
+        x2 = *reinterpret_cast<const float4 *>(xsrc[2] + (k0));       \
+        x3 = *reinterpret_cast<const float4 *>(xsrc[3] + (k0));       \
+        w0 = *reinterpret_cast<const float4 *>(wsrc[0] + (k0));       \
+        w1 = *reinterpret_cast<const float4 *>(wsrc[1] + (k0));       \
+        if (WP == 4) {                                                 \
+            w2 = *reinterpret_cast<const float4 *>(wsrc[WP - 2] + (k0)); \
+            w3 = *reinterpret_cast<const float4 *>(wsrc[WP - 1] + (k0)); \
+        }                                                              \
+    }
+#define AMOS_GEMM_STASH(buf)                                                                          \
+    {                                                                                                 \
+        float *xs = &Xs[buf][pr * kGemmPitch + 4 * pc], *ws = &Ws[buf][pr * kGemmPitch + 4 * pc];     \
+        *reinterpret_cast<float4 *>(xs) = x0;                                                         \
+        *reinterpret_cast<float4 *>(xs + 32 * kGemmPitch) = x1;                                       \
+        *reinterpret_cast<float4 *>(xs + 64 * kGemmPitch) = x2;                                       \
+        *reinterpret_cast<float4 *>(xs + 96 * kGemmPitch) = x3;                                       \
+        *reinterpret_cast<float4 *>(ws) = w0;                                                         \
+        *reinterpret_cast<float4 *>(ws + 32 * kGemmPitch) = w1;                                       \
+        if (WP == 4) {                                                                                \
+            *reinterpret_cast<float4 *>(ws + 64 * kGemmPitch) = w2;                                   \
+            *reinterpret_cast<float4 *>(ws + 96 * kGemmPitch) = w3;                                   \
+        }                                                                                             \
+    }
+#define AMOS_GEMM_COMPUTE(buf)                                                                                                                   \
+    _Pragma("unroll") for (int kk = 0; kk < kGemmBK / 8; kk++) {                                                                                \
+        float4 xa[TI], wb[2];                                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < TI; i++) xa[i] = *reinterpret_cast<const float4 *>(&Xs[buf][xoff + i * 32 * kGemmPitch + 8 * kk]); \
+        _Pragma("unroll") for (int j = 0; j < 2; j++) wb[j] = *reinterpret_cast<const float4 *>(&Ws[buf][woff + j * 32 * kGemmPitch + 8 * kk]);  \
+        _Pragma("unroll") for (int i = 0; i < TI; i++) _Pragma("unroll") for (int j = 0; j < 2; j++) {                                           \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].x, wb[j].x, acc[i][j], 0, 0, 0);                                              \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].y, wb[j].y, acc[i][j], 0, 0, 0);                                              \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].z, wb[j].z, acc[i][j], 0, 0, 0);                                              \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].w, wb[j].w, acc[i][j], 0, 0, 0);                                              \
+        }                                                                                                                                        \
+    }
+    f32x16 acc[TI][2];
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int xoff = (wm * 32 * TI + (lane & 31)) * kGemmPitch + 4 * (lane >> 5);
+    const int woff = (wn * 64 + (lane & 31)) * kGemmPitch + 4 * (lane >> 5);
+    AMOS_GEMM_FETCH(0);
+    AMOS_GEMM_STASH(0);
+    __syncthreads();
+    const int stages = a.K / kGemmBK;
+    for (int s = 0; s + 1 < stages; s++) {
+        const int buf = s & 1;
+        AMOS_GEMM_FETCH((s + 1) * kGemmBK);
+        __builtin_amdgcn_sched_barrier(0);  // the loads of the next stage are in flight under this stage's MFMAs, not after them
+        AMOS_GEMM_COMPUTE(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        AMOS_GEMM_STASH(buf ^ 1);  // last read in stage s - 1, which every wave left before the barrier that ended it
+        __syncthreads();
+    }
+    {
+        const int buf = (stages - 1) & 1;
+        AMOS_GEMM_COMPUTE(buf);
+    }
+#undef AMOS_GEMM_FETCH
+#undef AMOS_GEMM_STASH
+#undef AMOS_GEMM_COMPUTE
+    // epilogue.  Accumulator register r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31: the tile goes
+    // through LDS (row-major, BN floats per row; a half-wave writes 32 consecutive floats) so that every thread then handles
+    // 16-byte pieces of output rows: bias, residual and ReLU on float4, one coalesced residual load and one store per piece.
+    __syncthreads();  // every wave is done with the last stage's operands
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                smem[(wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+    __syncthreads();
+    constexpr int kCols = BN / 4, kRowsPerPass = 256 / kCols, kPasses = BM / kRowsPerPass;  // float4 columns; rows per sweep of the group
+    const int oc = t % kCols, orow = t / kCols;
+    const int n0 = nt * BN + 4 * oc;
+    const float4 bv = a.bias ? *reinterpret_cast<const float4 *>(a.bias + n0) : float4{0.f, 0.f, 0.f, 0.f};
+    constexpr int kBatch = 8;  // residual loads in flight per thread
+#pragma unroll
+    for (int p0 = 0; p0 < kPasses; p0 += kBatch) {
+        float4 rv[kBatch];
+#pragma unroll
+        for (int q = 0; q < kBatch; q++) {
+            const int m = mt * BM + (p0 + q) * kRowsPerPass + orow;
+            rv[q] = (a.res && m < a.M) ? *reinterpret_cast<const float4 *>(a.res + (size_t)m * a.N + n0) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < kBatch; q++) {
+            const int row = (p0 + q) * kRowsPerPass + orow, m = mt * BM + row;
+            if (m >= a.M) continue;
+            float4 v = *reinterpret_cast<const float4 *>(&smem[row * BN + 4 * oc]);
+            v.x = (v.x + bv.x) + rv[q].x; v.y = (v.y + bv.y) + rv[q].y; v.z = (v.z + bv.z) + rv[q].z; v.w = (v.w + bv.w) + rv[q].w;
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4 *>(a.y + (size_t)m * a.N + n0) = v;
+        }
+    }
+}
+
+}  // namespace amos
+
+using namespace amos;
+
+extern "C" {
+
+// 0 = this shape is served by amos_mask_conv1x1_device, otherwise AMOS_ERR_INVALID (the caller keeps its library convolution)
+int amos_mask_conv1x1_supported(int cin, int cout, int stride)
+{
+    return (cin >= kGemmBK && cin % kGemmBK == 0 && cout >= 64 && cout % 64 == 0 && stride >= 1 && stride <= 4) ? AMOS_OK : AMOS_ERR_INVALID;
+}
+
+int amos_mask_conv1x1_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual, float *d_y, int batch,
+                             int in_h, int in_w, int cin, int cout, int stride, int relu)
+{
+    if (!d_x || !d_w || !d_y || batch < 1 || in_h < 1 || in_w < 1 || amos_mask_conv1x1_supported(cin, cout, stride) != AMOS_OK ||
+        ((uintptr_t)d_x | (uintptr_t)d_w | (uintptr_t)d_y) % 16 != 0) {
+        set_error("amos_mask_conv1x1_device: invalid argument (cin % 32 == 0, cout % 64 == 0, stride 1..4, 16-byte aligned channels-last tensors)");
+        return AMOS_ERR_INVALID;
+    }
+    const int oh = (in_h - 1) / stride + 1, ow = (in_w - 1) / stride + 1;
+    const long long M = (long long)batch * oh * ow;
+    if (M > 0x7fffffffLL / 4) { set_error("amos_mask_conv1x1_device: too many output pixels"); return AMOS_ERR_INVALID; }
+    Conv1x1Args a;
+    a.x = d_x; a.w = d_w; a.bias = d_bias; a.res = d_residual; a.y = d_y;
+    a.M = (int)M; a.N = cout; a.K = cin;
+    a.outW = ow; a.outHW = oh * ow; a.inW = in_w; a.inHW = in_h * in_w;
+    a.stride = stride; a.relu = relu;
+    const bool wide = cout % 128 == 0;
+    const int BM = 128, BN = wide ? 128 : 64;
+    a.mTiles = (int)((M + BM - 1) / BM);
+    a.nTiles = cout / BN;
+    const unsigned grid = (unsigned)(((a.mTiles + 7) / 8) * 8 * a.nTiles);
+    if (wide) hipLaunchKernelGGL((k_conv1x1<2, 2, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_conv1x1<4, 1, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+}  // extern "C"

@@ -260,6 +260,14 @@ __device__ __forceinline__ unsigned mul_hi_u24(unsigned a, unsigned b)
     return r;
 }
 
+// the same with the first factor wave-uniform (an SGPR operand: no copy into a vector register)
+__device__ __forceinline__ unsigned mul_hi_u24_s(unsigned uniform, unsigned b)
+{
+    unsigned r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(b));
+    return r;
+}
+
 // Raw buffer descriptor over [p, p + bytes).  Word 3 = 0x00020000: raw 32-bit data format of gfx9.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_buffer(const void *p, unsigned bytes)
 {
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr
 #pragma unroll
     for (int r = 0; r < kPyrRows; r++) {
         need0[r] = r == 0 || ty[r].ofs != ty[r - 1].ofs1;
-        need1[r] = ty[r].ofs1 != ty[r].ofs;
+        need1[r] = true;  // ofs1 == ofs only where cv::resize clamps the second row (a1 == 0): loading it again costs less than a copy in every row
         if (need0[r]) {
             const int so = __builtin_amdgcn_readfirstlane(__mul24((int)ty[r].ofs, pstride));
             if (kWide) W0[r] = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(src, (int)base, so, 0));
@@ -336,37 +344,36 @@ __global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr
                 for (int k = 0; k < 4; k++) Q1[r][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(src, (int)ofs[k], so, 0);
         }
     }
+    // H comes out with its low four bits cleared: that is the form both vertical products want ((b*(H>>4))>>16 as
+    // v_mul_hi_u32_u24 of b << 12 and H & ~15), and a row of H serves two output rows
     auto hsum = [&](const uint2v &w, const unsigned (&q)[4], unsigned (&H)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const unsigned pair = kWide ? __builtin_amdgcn_perm(w.y, w.x, sel[k]) : __builtin_amdgcn_perm(0u, q[k], 0x0c010c00u);
-            H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pair), wgt[k], 0u, false);
+            H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pair), wgt[k], 0u, false) & ~15u;
         }
     };
-    unsigned H1[4] = {0, 0, 0, 0};
+    // Two register sets that swap roles every row: the first source row of an even output row lives in HP and its second
+    // in HQ, an odd row has them the other way round, so "the second source row of row r is the first of row r + 1"
+    // (the usual case) needs no copy at all.
+    unsigned HP[4] = {0, 0, 0, 0}, HQ[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < kPyrRows; r++) {
         const int row = row0 + r;
         if (row >= nrows) break;  // wave-uniform
-        unsigned H0[4];
-        if (need0[r]) {
-            hsum(W0[r], Q0[r], H0);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) H0[k] = H1[k];
-        }
-        if (need1[r]) {
-            hsum(W1[r], Q1[r], H1);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) H1[k] = H0[k];
-        }
-        const unsigned b0 = (unsigned)ty[r].a0 << 12, b1 = (unsigned)ty[r].a1 << 12;  // <= 2^23
+        unsigned(&H0)[4] = (r & 1) ? HQ : HP;
+        unsigned(&H1)[4] = (r & 1) ? HP : HQ;
+        if (need0[r]) hsum(W0[r], Q0[r], H0);  // otherwise H0 is the H1 of the row before: same registers
+        hsum(W1[r], Q1[r], H1);
+        const unsigned b0 = (unsigned)ty[r].a0 << 12, b1 = (unsigned)ty[r].a1 << 12;  // <= 2^23, wave-uniform
         unsigned v[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++)  // ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2, H < 2^20
-            v[k] = (mul_hi_u24(b0, H0[k] & ~15u) + mul_hi_u24(b1, H1[k] & ~15u) + 2u) >> 2;
-        const uint32_t packed = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);  // each <= 255
+        for (int k = 0; k < 4; k++)  // ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2, then >> 2 while packing; H < 2^20
+            v[k] = mul_hi_u24_s(b0, H0[k]) + mul_hi_u24_s(b1, H1[k]) + 2u;
+        unsigned packed = v[0] >> 2;  // each sum >> 2 is <= 255: the shifted byte is written into its place
+        asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(v[1]));
+        asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(v[2]));
+        asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(v[3]));
         if (active) __builtin_amdgcn_raw_buffer_store_b32(packed, dst, gx * 4, __builtin_amdgcn_readfirstlane(__mul24(row, dstride)), 0);
     }
 }

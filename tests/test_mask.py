@@ -302,6 +302,62 @@ def test_fused_conv_epilogue_equals_the_torch_ops(mask, gpu_lib):
 
 
 @pytest.mark.gpu
+def test_mfma_conv1x1_against_float64(mask, gpu_lib, monkeypatch):
+    """amos_mask_conv1x1_device (fp32 MFMA GEMM, bias + residual + ReLU in the epilogue) against a float64 convolution: both
+    work-group shapes (output channels % 128 == 0 and 64 / 192), strides 1 and 2, a row count that is not a multiple of the tile,
+    with and without bias / residual / ReLU.  Tolerance: float32 rounding of a K-term sum (1e-5 relative to the sum of |terms|),
+    and no worse than the library convolution's own error.  Then the same through conv_bias_act's dispatch, both forced sides."""
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    F = torch.nn.functional
+    torch.manual_seed(7)
+    cl = torch.channels_last
+    st = torch.cuda.current_stream().cuda_stream
+    assert gpu_lib.mask_conv1x1_supported(64, 256, 1) and gpu_lib.mask_conv1x1_supported(2048, 64, 2)
+    assert not gpu_lib.mask_conv1x1_supported(3, 64, 1) and not gpu_lib.mask_conv1x1_supported(256, 32, 1) and not gpu_lib.mask_conv1x1_supported(80, 64, 1)
+    for b, cin, cout, stride, h, w in ((3, 64, 256, 1, 37, 41), (2, 256, 64, 1, 23, 19), (2, 512, 1024, 2, 35, 33), (1, 2048, 512, 1, 18, 18),
+                                       (2, 128, 192, 1, 9, 7), (1, 32, 128, 3, 10, 11)):
+        x = torch.randn(b, cin, h, w, device="cuda").contiguous(memory_format=cl)
+        wgt = (torch.randn(cout, cin, 1, 1, device="cuda") / cin ** 0.5)
+        bias = torch.randn(cout, device="cuda")
+        oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+        res = torch.randn(b, cout, oh, ow, device="cuda").contiguous(memory_format=cl)
+        exact = F.conv2d(x.double(), wgt.double(), None, stride)
+        bound = 1e-5 * F.conv2d(x.double().abs(), wgt.double().abs(), None, stride) + 1e-6
+        for wfmt in (torch.contiguous_format, cl):
+            wt = wgt.contiguous(memory_format=wfmt)
+            for use_bias, use_res, relu in ((True, True, True), (True, False, True), (False, True, False), (False, False, False), (True, False, False)):
+                y = torch.full((b, cout, oh, ow), float("nan"), device="cuda").contiguous(memory_format=cl)
+                gpu_lib.mask_conv1x1(st, x.data_ptr(), wt.data_ptr(), bias.data_ptr() if use_bias else None, res.data_ptr() if use_res else None,
+                                     y.data_ptr(), b, h, w, cin, cout, stride, relu)
+                torch.cuda.synchronize()
+                want = exact + (bias.double().view(1, -1, 1, 1) if use_bias else 0) + (res.double() if use_res else 0)
+                if relu:
+                    want = want.relu()
+                err = (y.double() - want).abs()
+                assert torch.isfinite(y).all() and bool((err <= bound).all()), (cin, cout, stride, use_bias, use_res, relu, err.max().item())
+        conv = torch.nn.Conv2d(cin, cout, 1, stride=stride, bias=True).cuda().to(memory_format=cl)
+        with torch.no_grad():
+            conv.weight.copy_(wgt)
+            conv.bias.copy_(bias)
+            outs = {}
+            for side in ("0", "1"):
+                monkeypatch.setenv("AMOS_MASK_CONV1X1", side)
+                outs[side] = net_mod.conv_bias_act(conv, x, True, residual=res)
+            want = (exact + bias.double().view(1, -1, 1, 1) + res.double()).relu()
+            for side, y in outs.items():
+                assert y.is_contiguous(memory_format=cl) and bool(((y.double() - want).abs() <= bound).all()), (side, cin, cout)
+    monkeypatch.delenv("AMOS_MASK_CONV1X1")
+    # the rule of the automatic choice: large launches with <= 512 input channels
+    big, small = torch.empty(32, 64, 138, 138, device="meta"), torch.empty(1, 64, 138, 138, device="meta")
+    c = torch.nn.Conv2d(64, 256, 1)
+    assert net_mod._gemm_conv1x1(c, big) and not net_mod._gemm_conv1x1(c, small)
+    assert not net_mod._gemm_conv1x1(torch.nn.Conv2d(1024, 256, 1), torch.empty(32, 1024, 35, 35, device="meta"))
+    assert not net_mod._gemm_conv1x1(torch.nn.Conv2d(256, 256, 3, padding=1), big)
+    with pytest.raises(RuntimeError):
+        gpu_lib.mask_conv1x1(st, 0, 0, None, None, 0, 1, 8, 8, 64, 64, 1, True)
+
+
+@pytest.mark.gpu
 def test_hip_bilinear_nhwc_equals_torch_interpolate(mask, gpu_lib):
     """amos_mask_bilinear_nhwc_device against F.interpolate(mode="bilinear", align_corners=False) on channels-last tensors: the FPN's
     size-given form (35 -> 69, 18 -> 35) and the prototype network's scale_factor = 2 (69 -> 138).  Same source indices and

@@ -50,9 +50,10 @@ json.dump({"command": "rocprofv3 --pmc <set> (one pass per set) -- python3 bench
            "kernels": per_kernel}, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 stage = {"import": ["amos::k_pyramid_level0_wide"], "pyramid": ["amos::k_pyramid_level<true>", "amos::k_pyramid_tail"], "fast": ["amos::k_fast_cells<16>", "amos::k_fast_cells<20>"],
          "octree": ["amos::k_octree"], "orient": ["amos::k_orient"], "blur": ["amos::k_blur"], "describe": ["amos::k_describe"],
-         "match": ["amos::k_bf_best2_mfma<true, 1>", "amos::k_bf_best2_mfma<true, 4>", "amos::k_bf_best2<true>"]}
+         "match": ["amos::k_bf_best2_mfma<true", "amos::k_bf_best2<true>"]}
 traffic = {"source": f"profiles/{tag}_pmc_summary.json", "c2": {}}
-for st, ks in stage.items():
+for st, prefixes in stage.items():
+    ks = [k for k in per_kernel if any(k.startswith(p) for p in prefixes)]  # template arguments of the instance that ran
     tot = 0
     for k in ks:
         v = per_kernel.get(k)
