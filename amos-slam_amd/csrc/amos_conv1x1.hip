@@ -29,16 +29,20 @@ constexpr int kGemmPitch = kGemmBK + 4;     // floats between LDS rows
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct Conv1x1Args {
+struct ConvGemmArgs {
     const float *x, *w, *bias, *res;
     float *y;
-    int M, N, K;                 // output pixels, output channels, input channels
-    int outW, outHW, inW, inHW;  // row(m): b = m / outHW, (oy, ox) of the rest; input pixel (b * inHW + oy * stride * inW + ox * stride)
+    int M, N, K;                 // output pixels, output channels, input channels (the GEMM's k runs over taps x K)
+    int outW, outHW, inW, inH;   // row(m): b = m / outHW, (oy, ox) of the rest; tap (dy, dx) reads input pixel (oy * stride - pad + dy, ox * stride - pad + dx)
     int stride, relu, mTiles, nTiles;
+    int kh, kw, pad;             // kTaps == false: 1, 1, 0
 };
 
-template <int WM, int WN, int TI>  // waves along m and n; a wave's tile is 32 TI x 64
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_conv1x1(const Conv1x1Args a)  // LDS admits two groups per CU: 256 registers
+// kTaps: a kh x kw convolution as an implicit GEMM.  The weight is [cout][kh][kw][cin] (a channels-last Conv2d weight), so the W tile
+// of stage s is simply 32 more floats along each row; the X tile of a stage belongs to ONE tap (cin % 32 == 0): row m reads input
+// pixel (oy * stride - pad + dy, ox * stride - pad + dx), or zeros outside the image.
+template <int WM, int WN, int TI, bool kTaps>  // waves along m and n; a wave's tile is 32 TI x 64
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_conv_gemm(const ConvGemmArgs a)  // LDS admits two groups per CU: 256 registers
 {
     constexpr int BM = 32 * TI * WM, BN = 64 * WN;
     constexpr int XP = BM / 32, WP = BN / 32;  // 16-byte pieces per thread and stage
@@ -55,33 +59,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int wm = wave / WN, wn = wave % WN;
     const int pc = t & 7, pr = t >> 3;  // piece column (4 floats), first row of this thread's pieces
     const float *xsrc[XP];
+    int iy0[XP], ix0[XP];  // kTaps: input coordinates of tap (0, 0)
 #pragma unroll
     for (int i = 0; i < XP; i++) {
         const int m = min(mt * BM + pr + 32 * i, a.M - 1);  // rows past the end repeat the last one; their results are not stored
-        size_t pix = (size_t)m;
-        if (a.stride != 1) {
+        iy0[i] = ix0[i] = 0;
+        if (!kTaps && a.stride == 1) {
+            xsrc[i] = a.x + (size_t)m * a.K + 4 * pc;
+        } else {
             const int b = m / a.outHW, rem = m - b * a.outHW, oy = rem / a.outW, ox = rem - oy * a.outW;
-            pix = (size_t)b * a.inHW + (size_t)oy * a.stride * a.inW + (size_t)ox * a.stride;
+            iy0[i] = oy * a.stride - a.pad;
+            ix0[i] = ox * a.stride - a.pad;
+            // (for a border row this points outside the image; it is only dereferenced at taps that fall inside)
+            xsrc[i] = a.x + (((ptrdiff_t)b * a.inH + iy0[i]) * a.inW + ix0[i]) * a.K + 4 * pc;
         }
-        xsrc[i] = a.x + pix * a.K + 4 * pc;
     }
+    const int kcPerTap = a.K / kGemmBK, wRow = a.K * a.kh * a.kw;  // stages per tap; floats of one weight row
     const float *wsrc[WP];
 #pragma unroll
-    for (int j = 0; j < WP; j++) wsrc[j] = a.w + (size_t)(nt * BN + pr + 32 * j) * a.K + 4 * pc;
+    for (int j = 0; j < WP; j++) wsrc[j] = a.w + (size_t)(nt * BN + pr + 32 * j) * wRow + 4 * pc;
     static_assert(XP == 4 && (WP == 2 || WP == 4), "the staging registers below are named one by one");
     float4 x0, x1, x2, x3, w0, w1, w2 = {}, w3 = {};  // (arrays of these end up in scratch once the scheduling fences below are in place)
-#define AMOS_GEMM_FETCH(k0)                                            \
-    {                                                                  \
-        x0 = *reinterpret_cast<const float4 *>(xsrc[0] + (k0));       \
-        x1 = *reinterpret_cast<const float4 *>(xsrc[1] + (k0));       \
-        x2 = *reinterpret_cast<const float4 *>(xsrc[2] + (k0));       \
-        x3 = *reinterpret_cast<const float4 *>(xsrc[3] + (k0));       \
-        w0 = *reinterpret_cast<const float4 *>(wsrc[0] + (k0));       \
-        w1 = *reinterpret_cast<const float4 *>(wsrc[1] + (k0));       \
-        if (WP == 4) {                                                 \
-            w2 = *reinterpret_cast<const float4 *>(wsrc[WP - 2] + (k0)); \
-            w3 = *reinterpret_cast<const float4 *>(wsrc[WP - 1] + (k0)); \
-        }                                                              \
+#define AMOS_GEMM_FETCH(stage)                                                                                               \
+    {                                                                                                                        \
+        const int k0 = (stage) * kGemmBK;                                                                                    \
+        if (kTaps) {                                                                                                         \
+            const int tap = (stage) / kcPerTap, kc = (stage) - tap * kcPerTap, dy = tap / a.kw, dx = tap - dy * a.kw;        \
+            const ptrdiff_t off = (ptrdiff_t)(dy * a.inW + dx) * a.K + kc * kGemmBK;                                         \
+            const float4 zero = {0.f, 0.f, 0.f, 0.f};                                                                        \
+            x0 = ((unsigned)(iy0[0] + dy) < (unsigned)a.inH && (unsigned)(ix0[0] + dx) < (unsigned)a.inW) ? *reinterpret_cast<const float4 *>(xsrc[0] + off) : zero; \
+            x1 = ((unsigned)(iy0[1] + dy) < (unsigned)a.inH && (unsigned)(ix0[1] + dx) < (unsigned)a.inW) ? *reinterpret_cast<const float4 *>(xsrc[1] + off) : zero; \
+            x2 = ((unsigned)(iy0[2] + dy) < (unsigned)a.inH && (unsigned)(ix0[2] + dx) < (unsigned)a.inW) ? *reinterpret_cast<const float4 *>(xsrc[2] + off) : zero; \
+            x3 = ((unsigned)(iy0[3] + dy) < (unsigned)a.inH && (unsigned)(ix0[3] + dx) < (unsigned)a.inW) ? *reinterpret_cast<const float4 *>(xsrc[3] + off) : zero; \
+        } else {                                                                                                             \
+            x0 = *reinterpret_cast<const float4 *>(xsrc[0] + k0);                                                            \
+            x1 = *reinterpret_cast<const float4 *>(xsrc[1] + k0);                                                            \
+            x2 = *reinterpret_cast<const float4 *>(xsrc[2] + k0);                                                            \
+            x3 = *reinterpret_cast<const float4 *>(xsrc[3] + k0);                                                            \
+        }                                                                                                                    \
+        w0 = *reinterpret_cast<const float4 *>(wsrc[0] + k0);                                                                \
+        w1 = *reinterpret_cast<const float4 *>(wsrc[1] + k0);                                                                \
+        if (WP == 4) {                                                                                                       \
+            w2 = *reinterpret_cast<const float4 *>(wsrc[WP - 2] + k0);                                                       \
+            w3 = *reinterpret_cast<const float4 *>(wsrc[WP - 1] + k0);                                                       \
+        }                                                                                                                    \
     }
 #define AMOS_GEMM_STASH(buf)                                                                          \
     {                                                                                                 \
@@ -97,8 +118,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             *reinterpret_cast<float4 *>(ws + 96 * kGemmPitch) = w3;                                   \
         }                                                                                             \
     }
-#define AMOS_GEMM_COMPUTE(buf)                                                                                                                   \
-    _Pragma("unroll") for (int kk = 0; kk < kGemmBK / 8; kk++) {                                                                                \
+#define AMOS_GEMM_COMPUTE(buf, kk0, kk1)                                                                                                         \
+    _Pragma("unroll") for (int kk = kk0; kk < kk1; kk++) {                                                                                      \
         float4 xa[TI], wb[2];                                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < TI; i++) xa[i] = *reinterpret_cast<const float4 *>(&Xs[buf][xoff + i * 32 * kGemmPitch + 8 * kk]); \
         _Pragma("unroll") for (int j = 0; j < 2; j++) wb[j] = *reinterpret_cast<const float4 *>(&Ws[buf][woff + j * 32 * kGemmPitch + 8 * kk]);  \
@@ -118,22 +139,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     const int xoff = (wm * 32 * TI + (lane & 31)) * kGemmPitch + 4 * (lane >> 5);
     const int woff = (wn * 64 + (lane & 31)) * kGemmPitch + 4 * (lane >> 5);
+    // Staging schedule: the registers of tile s + 1 are written to the other LDS buffer in the MIDDLE of stage s (that buffer was
+    // last read in stage s - 1, which every wave left before the barrier that ended it) and re-loaded with tile s + 2 at once,
+    // so a global load has a whole stage of MFMAs to land and the stage ends with nothing but the barrier.
+    const int stages = kcPerTap * a.kh * a.kw;
     AMOS_GEMM_FETCH(0);
     AMOS_GEMM_STASH(0);
+    if (stages > 1) AMOS_GEMM_FETCH(1);
     __syncthreads();
-    const int stages = a.K / kGemmBK;
-    for (int s = 0; s + 1 < stages; s++) {
+    for (int s = 0; s < stages; s++) {
         const int buf = s & 1;
-        AMOS_GEMM_FETCH((s + 1) * kGemmBK);
-        __builtin_amdgcn_sched_barrier(0);  // the loads of the next stage are in flight under this stage's MFMAs, not after them
-        AMOS_GEMM_COMPUTE(buf);
         __builtin_amdgcn_sched_barrier(0);
-        AMOS_GEMM_STASH(buf ^ 1);  // last read in stage s - 1, which every wave left before the barrier that ended it
+        AMOS_GEMM_COMPUTE(buf, 0, kGemmBK / 16);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < stages) {
+            AMOS_GEMM_STASH(buf ^ 1);
+            if (s + 2 < stages) AMOS_GEMM_FETCH(s + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        AMOS_GEMM_COMPUTE(buf, kGemmBK / 16, kGemmBK / 8);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-    }
-    {
-        const int buf = (stages - 1) & 1;
-        AMOS_GEMM_COMPUTE(buf);
     }
 #undef AMOS_GEMM_FETCH
 #undef AMOS_GEMM_STASH
@@ -181,37 +207,49 @@ using namespace amos;
 
 extern "C" {
 
-// 0 = this shape is served by amos_mask_conv1x1_device, otherwise AMOS_ERR_INVALID (the caller keeps its library convolution)
-int amos_mask_conv1x1_supported(int cin, int cout, int stride)
+// 0 = this shape is served by amos_mask_conv_device, otherwise AMOS_ERR_INVALID (the caller keeps its library convolution)
+int amos_mask_conv_supported(int cin, int cout, int kh, int kw, int stride, int pad)
 {
-    return (cin >= kGemmBK && cin % kGemmBK == 0 && cout >= 64 && cout % 64 == 0 && stride >= 1 && stride <= 4) ? AMOS_OK : AMOS_ERR_INVALID;
+    return (cin >= kGemmBK && cin % kGemmBK == 0 && cout >= 64 && cout % 64 == 0 && stride >= 1 && stride <= 4 && kh >= 1 && kh <= 7 && kw >= 1 && kw <= 7 &&
+            pad >= 0 && pad < kh && pad < kw) ? AMOS_OK : AMOS_ERR_INVALID;
 }
+
+int amos_mask_conv_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual, float *d_y, int batch,
+                          int in_h, int in_w, int cin, int cout, int kh, int kw, int stride, int pad, int relu)
+{
+    if (!d_x || !d_w || !d_y || batch < 1 || in_h < 1 || in_w < 1 || amos_mask_conv_supported(cin, cout, kh, kw, stride, pad) != AMOS_OK ||
+        in_h + 2 * pad < kh || in_w + 2 * pad < kw || ((uintptr_t)d_x | (uintptr_t)d_w | (uintptr_t)d_y | (uintptr_t)d_bias | (uintptr_t)d_residual) % 16 != 0) {
+        set_error("amos_mask_conv_device: invalid argument (cin %% 32 == 0, cout %% 64 == 0, kernel <= 7 x 7, pad < kernel, stride 1..4, 16-byte aligned channels-last tensors)");
+        return AMOS_ERR_INVALID;
+    }
+    const int oh = (in_h + 2 * pad - kh) / stride + 1, ow = (in_w + 2 * pad - kw) / stride + 1;
+    const long long M = (long long)batch * oh * ow;
+    if (M > 0x7fffffffLL / 4 || (long long)batch * in_h * in_w * cin > 0x7fffffffffLL) { set_error("amos_mask_conv_device: tensor too large"); return AMOS_ERR_INVALID; }
+    ConvGemmArgs a;
+    a.x = d_x; a.w = d_w; a.bias = d_bias; a.res = d_residual; a.y = d_y;
+    a.M = (int)M; a.N = cout; a.K = cin;
+    a.outW = ow; a.outHW = oh * ow; a.inW = in_w; a.inH = in_h;
+    a.stride = stride; a.relu = relu; a.kh = kh; a.kw = kw; a.pad = pad;
+    const bool wide = cout % 128 == 0, taps = kh * kw > 1 || pad > 0;
+    const int BM = 128, BN = wide ? 128 : 64;
+    a.mTiles = (int)((M + BM - 1) / BM);
+    a.nTiles = cout / BN;
+    const dim3 grid((unsigned)(((a.mTiles + 7) / 8) * 8 * a.nTiles)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (wide && taps) hipLaunchKernelGGL((k_conv_gemm<2, 2, 2, true>), grid, block, 0, st, a);
+    else if (wide) hipLaunchKernelGGL((k_conv_gemm<2, 2, 2, false>), grid, block, 0, st, a);
+    else if (taps) hipLaunchKernelGGL((k_conv_gemm<4, 1, 1, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_conv_gemm<4, 1, 1, false>), grid, block, 0, st, a);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_mask_conv1x1_supported(int cin, int cout, int stride) { return amos_mask_conv_supported(cin, cout, 1, 1, stride, 0); }
 
 int amos_mask_conv1x1_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual, float *d_y, int batch,
                              int in_h, int in_w, int cin, int cout, int stride, int relu)
 {
-    if (!d_x || !d_w || !d_y || batch < 1 || in_h < 1 || in_w < 1 || amos_mask_conv1x1_supported(cin, cout, stride) != AMOS_OK ||
-        ((uintptr_t)d_x | (uintptr_t)d_w | (uintptr_t)d_y) % 16 != 0) {
-        set_error("amos_mask_conv1x1_device: invalid argument (cin % 32 == 0, cout % 64 == 0, stride 1..4, 16-byte aligned channels-last tensors)");
-        return AMOS_ERR_INVALID;
-    }
-    const int oh = (in_h - 1) / stride + 1, ow = (in_w - 1) / stride + 1;
-    const long long M = (long long)batch * oh * ow;
-    if (M > 0x7fffffffLL / 4) { set_error("amos_mask_conv1x1_device: too many output pixels"); return AMOS_ERR_INVALID; }
-    Conv1x1Args a;
-    a.x = d_x; a.w = d_w; a.bias = d_bias; a.res = d_residual; a.y = d_y;
-    a.M = (int)M; a.N = cout; a.K = cin;
-    a.outW = ow; a.outHW = oh * ow; a.inW = in_w; a.inHW = in_h * in_w;
-    a.stride = stride; a.relu = relu;
-    const bool wide = cout % 128 == 0;
-    const int BM = 128, BN = wide ? 128 : 64;
-    a.mTiles = (int)((M + BM - 1) / BM);
-    a.nTiles = cout / BN;
-    const unsigned grid = (unsigned)(((a.mTiles + 7) / 8) * 8 * a.nTiles);
-    if (wide) hipLaunchKernelGGL((k_conv1x1<2, 2, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_conv1x1<4, 1, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    AMOS_HIP_CHECK(hipGetLastError());
-    return AMOS_OK;
+    return amos_mask_conv_device(stream, d_x, d_w, d_bias, d_residual, d_y, batch, in_h, in_w, cin, cout, 1, 1, stride, 0, relu);
 }
 
 }  // extern "C"

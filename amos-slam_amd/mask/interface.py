@@ -4,6 +4,8 @@
 returns the 8-bit person mask (480 x 640, values 0 / 255, overlaps wrapping modulo 256);
 `eval_bgr(frame)` takes the raw BGR frame and performs the C++ marshalling on the GPU as well.
 """
+import os
+
 import torch
 
 from .detect import detect, detect_batch
@@ -43,8 +45,11 @@ class MaskEngine:
 
     def prepare(self):
         """Inference form of the network: batch norms folded into the convolutions (same function up to float32
-        rounding of the folded weights; tests/test_mask.py holds it to the golden tensors and IoU >= 1 - 1e-3)."""
+        rounding of the folded weights; tests/test_mask.py holds it to the golden tensors and IoU >= 1 - 1e-3); on the GPU
+        also the prediction head's three output convolutions merged into one."""
         self.net.fold_batch_norms()
+        if self.device.type == "cuda" and os.environ.get("AMOS_MASK_MERGE_HEADS", "1") != "0":  # (the switch is for A/B runs)
+            self.net.merge_head_outputs()  # the prediction head's three output convolutions as one (net.py SharedHead.merge_output_layers)
         if self.channels_last:
             self.net.to(memory_format=torch.channels_last)
         return self

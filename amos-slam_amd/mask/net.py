@@ -223,9 +223,38 @@ class SharedHead(nn.Module):
         self.conf_layer = nn.Conv2d(FPN_FEATURES, num_priors * NUM_CLASSES, 3, padding=1)
         self.mask_layer = nn.Conv2d(FPN_FEATURES, num_priors * MASK_DIM, 3, padding=1)
 
+    def merge_output_layers(self):
+        """Inference form: the three output convolutions read the same tensor, so they run as ONE 3 x 3 convolution with
+        12 + 243 + 96 (+ 1 zero filter: 352 = a multiple of 4 for the vector epilogue) output channels -- one pass over the
+        upfeature tensor and one launch instead of three, with better output-channel tiles than 12 or 243 give (measured
+        on MI355X, 32 frames at 69 x 69: 2.09 ms against 0.40 + 1.63 + 0.78).  Same sums per channel; MIOpen may pick
+        another solver for the wider layer, hence float32 rounding.  Built from the loaded weights: call after
+        load_state_dict.  Idempotent."""
+        if getattr(self, "merged", None) is None:
+            layers = (self.bbox_layer, self.conf_layer, self.mask_layer)
+            n = sum(l.out_channels for l in layers)
+            pad = (-n) % 4
+            merged = nn.Conv2d(FPN_FEATURES, n + pad, 3, padding=1).to(device=self.bbox_layer.weight.device, dtype=self.bbox_layer.weight.dtype)
+            with torch.no_grad():
+                merged.weight.zero_()
+                merged.bias.zero_()
+                merged.weight[:n].copy_(torch.cat([l.weight for l in layers], 0))
+                merged.bias[:n].copy_(torch.cat([l.bias for l in layers], 0))
+            # not a registered sub-module: the state dict keeps the reference's keys
+            object.__setattr__(self, "merged", merged.requires_grad_(False))
+        return self
+
     def forward(self, x):
         b = x.shape[0]
         x = conv_bias_act(self.upfeature[0], x, True)
+        merged = getattr(self, "merged", None)
+        if merged is not None:
+            y = conv_bias_act(merged, x, False).permute(0, 2, 3, 1)  # [b, h, w, 352]: channels last in memory, so this is a view
+            n0, n1, n2 = self.bbox_layer.out_channels, self.conf_layer.out_channels, self.mask_layer.out_channels
+            loc = y[..., :n0].reshape(b, -1, 4)
+            conf = y[..., n0:n0 + n1].reshape(b, -1, NUM_CLASSES)
+            coef = torch.tanh(y[..., n0 + n1:n0 + n1 + n2].reshape(b, -1, MASK_DIM))
+            return loc, conf, coef
         loc = self.bbox_layer(x).permute(0, 2, 3, 1).reshape(b, -1, 4)
         conf = self.conf_layer(x).permute(0, 2, 3, 1).reshape(b, -1, NUM_CLASSES)
         coef = torch.tanh(self.mask_layer(x).permute(0, 2, 3, 1).reshape(b, -1, MASK_DIM))
@@ -287,6 +316,17 @@ class YolactR50(nn.Module):
         if not getattr(self, "_folded", False):
             self.backbone.fold_batch_norms()
             self._folded = True
+        return self
+
+    def merge_head_outputs(self):
+        self.prediction_layers[0].merge_output_layers()
+        return self
+
+    def _apply(self, fn, *args, **kwargs):  # .to(device / memory format) after the merge carries the merged layer along
+        super()._apply(fn, *args, **kwargs)
+        merged = getattr(self.prediction_layers[0], "merged", None)
+        if merged is not None:
+            merged._apply(fn, *args, **kwargs)
         return self
 
     def forward(self, x):

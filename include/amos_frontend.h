@@ -330,15 +330,21 @@ int amos_orb_detect_color_with_mask_pre_batch_device(amos_orb *h, amos_mask_pre 
 int amos_mask_bias_act_device(void *stream, float *d_y, const float *d_bias, const float *d_residual, size_t n,
                               int channels, int relu);
 
-/* A 1 x 1 convolution of the mask network (the ResNet-50 bottlenecks' conv1 / conv3 / downsample and the FPN laterals:
- * backbone.py Bottleneck.forward, yolact.py FPN.forward as amos-slam_amd/mask/net.py restates them) on channels-last float32
- * tensors as one fp32 MFMA GEMM with the epilogue of amos_mask_bias_act_device fused:
- *   y[b][oy][ox][n] = act( sum_k x[b][oy*stride][ox*stride][k] * w[n][k]  + bias[n]  (+ residual[b][oy][ox][n]) )
- * x: [batch][in_h][in_w][cin], w: [cout][cin] (a Conv2d weight [cout][cin][1][1] in either memory format), y and residual:
- * [batch][oh][ow][cout] with oh = (in_h - 1) / stride + 1; bias and residual may be NULL.  Requires cin % 32 == 0,
- * cout % 64 == 0, 16-byte aligned pointers (amos_mask_conv1x1_supported returns AMOS_OK for such a shape, AMOS_ERR_INVALID
- * otherwise: the caller then keeps its library convolution).  The sum over k is taken in another order than MIOpen's, so the
- * results agree to float32 rounding, not bit for bit.  Asynchronous on `stream`. */
+/* A convolution of the mask network (yolact.py / backbone.py as amos-slam_amd/mask/net.py restates them: the ResNet-50
+ * bottlenecks, the FPN, the prototype network, the prediction heads) on channels-last float32 tensors as one fp32 MFMA
+ * (implicit) GEMM with the epilogue of amos_mask_bias_act_device fused:
+ *   y[b][oy][ox][n] = act( sum_{dy,dx,k} x[b][oy*stride - pad + dy][ox*stride - pad + dx][k] * w[n][dy][dx][k]
+ *                          + bias[n]  (+ residual[b][oy][ox][n]) )        (zeros outside the image, dilation 1, groups 1)
+ * x: [batch][in_h][in_w][cin]; w: [cout][kh][kw][cin], i.e. a Conv2d weight in channels-last memory format (for 1 x 1 either
+ * format); y and residual: [batch][oh][ow][cout] with oh = (in_h + 2 pad - kh) / stride + 1; bias and residual may be NULL.
+ * Requires cin % 32 == 0, cout % 64 == 0, kernel <= 7 x 7, pad < kernel, stride 1..4, 16-byte aligned pointers
+ * (amos_mask_conv_supported returns AMOS_OK for such a shape, AMOS_ERR_INVALID otherwise: the caller then keeps its library
+ * convolution).  The sum is taken in another order than MIOpen's: results agree to float32 rounding, not bit for bit.
+ * Asynchronous on `stream`.  amos_mask_conv1x1_* are the kh = kw = 1, pad = 0 case. */
+int amos_mask_conv_supported(int cin, int cout, int kh, int kw, int stride, int pad);
+int amos_mask_conv_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual,
+                          float *d_y, int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride, int pad,
+                          int relu);
 int amos_mask_conv1x1_supported(int cin, int cout, int stride);
 int amos_mask_conv1x1_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual,
                              float *d_y, int batch, int in_h, int in_w, int cin, int cout, int stride, int relu);

@@ -346,6 +346,26 @@ def test_mfma_conv1x1_against_float64(mask, gpu_lib, monkeypatch):
             want = (exact + bias.double().view(1, -1, 1, 1) + res.double()).relu()
             for side, y in outs.items():
                 assert y.is_contiguous(memory_format=cl) and bool(((y.double() - want).abs() <= bound).all()), (side, cin, cout)
+    # the general entry point: k x k taps as an implicit GEMM (weight [cout][kh][kw][cin] = a channels-last Conv2d weight)
+    assert gpu_lib.mask_conv_supported(256, 384, 3, 3, 1, 1) and not gpu_lib.mask_conv_supported(256, 243, 3, 3, 1, 1) and not gpu_lib.mask_conv_supported(64, 64, 3, 3, 1, 3)
+    for b, cin, cout, k, stride, pad, h, w in ((2, 64, 64, 3, 1, 1, 21, 17), (1, 128, 128, 3, 2, 1, 30, 31), (2, 256, 384, 3, 1, 1, 9, 9), (1, 32, 64, 3, 1, 0, 12, 7),
+                                               (1, 64, 128, 5, 2, 2, 13, 16), (2, 32, 64, 1, 2, 0, 7, 7)):
+        x = torch.randn(b, cin, h, w, device="cuda").contiguous(memory_format=cl)
+        wgt = (torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5).contiguous(memory_format=cl)
+        bias = torch.randn(cout, device="cuda")
+        exact = F.conv2d(x.double(), wgt.double(), bias.double(), stride, pad)
+        bound = 1e-5 * F.conv2d(x.double().abs(), wgt.double().abs(), None, stride, pad) + 1e-6
+        res = torch.randn(exact.shape, device="cuda").contiguous(memory_format=cl)
+        for use_res, relu in ((False, True), (True, False)):
+            y = torch.full(exact.shape, float("nan"), device="cuda").contiguous(memory_format=cl)
+            gpu_lib.mask_conv(st, x.data_ptr(), wgt.data_ptr(), bias.data_ptr(), res.data_ptr() if use_res else None, y.data_ptr(), b, h, w, cin, cout, k, k,
+                              stride, pad, relu)
+            torch.cuda.synchronize()
+            want = exact + (res.double() if use_res else 0)
+            if relu:
+                want = want.relu()
+            err = (y.double() - want).abs()
+            assert torch.isfinite(y).all() and bool((err <= bound).all()), (cin, cout, k, stride, pad, use_res, relu, err.max().item())
     monkeypatch.delenv("AMOS_MASK_CONV1X1")
     # the rule of the automatic choice: large launches with <= 512 input channels
     big, small = torch.empty(32, 64, 138, 138, device="meta"), torch.empty(1, 64, 138, 138, device="meta")
