@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void k_bias_act(float *__restrict__ y, const f
 // output pixel with 16-byte loads / stores.  Source index and weights as PyTorch computes them in float32:
 // src = scale * (dst + 0.5) - 0.5, clamped at 0, scale = 1 / scale_factor when given, else in / out.
 // grid = (ceil(outW * C / 4 / 256), outH, N), block = 256.
+template <bool kRelu>
 __global__ __launch_bounds__(256) void k_bilinear_nhwc(const float *__restrict__ x, float *__restrict__ y, int inH, int inW, int outH, int outW, int c4,
                                                       float scaleH, float scaleW)
 {
@@ -141,10 +142,50 @@ __global__ __launch_bounds__(256) void k_bilinear_nhwc(const float *__restrict__
     const float4 a = src[((size_t)y0 * inW + x0) * c4 + q], b = src[((size_t)y0 * inW + x1) * c4 + q];
     const float4 c = src[((size_t)y1 * inW + x0) * c4 + q], d = src[((size_t)y1 * inW + x1) * c4 + q];
     auto mix = [&](float p, float r, float s, float u) {  // h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d)
-        return __fadd_rn(__fmul_rn(hy, __fadd_rn(__fmul_rn(hx, p), __fmul_rn(lx, r))), __fmul_rn(ly, __fadd_rn(__fmul_rn(hx, s), __fmul_rn(lx, u))));
+        const float v = __fadd_rn(__fmul_rn(hy, __fadd_rn(__fmul_rn(hx, p), __fmul_rn(lx, r))), __fmul_rn(ly, __fadd_rn(__fmul_rn(hx, s), __fmul_rn(lx, u))));
+        return kRelu ? (v < 0.f ? 0.f : v) : v;  // a NaN stays a NaN, as through torch.relu
     };
     reinterpret_cast<float4 *>(y)[(((size_t)n * outH + oy) * outW + ox) * c4 + q] =
         make_float4(mix(a.x, b.x, c.x, d.x), mix(a.y, b.y, c.y, d.y), mix(a.z, b.z, c.z, d.z), mix(a.w, b.w, c.w, d.w));
+}
+
+// Fast NMS suppression term (layers/functions/detection.py:103-170 fast_nms as mask/detect.py restates it): for every class list of
+// k score-sorted boxes, out[j] = max over i < j of IoU(box i, box j) (the column maxima of the upper-triangular IoU matrix; 0 for
+// j = 0).  PyTorch spends nine elementwise passes over the [lists][k][k] matrix on this (410 MB at 32 frames x 80 classes x 200);
+// here a work-group keeps one list's boxes in LDS and every thread walks its column.  box_utils.jaccard's arithmetic in its order:
+// intersection = clamp(min(x2) - max(x1), 0) * clamp(min(y2) - max(y1), 0); IoU = inter / ((area_i + area_j) - inter), correctly
+// rounded; a NaN (0 / 0) wins the maximum as it does in torch.max.
+// grid = lists, block = 256 (k <= 256).
+__global__ __launch_bounds__(256) void k_nms_column_max(const float4 *__restrict__ boxes, float *__restrict__ out, int k)
+{
+    __shared__ float4 sb[256];
+    __shared__ float sarea[256];
+    const int j = threadIdx.x;
+    const float4 *b = boxes + (size_t)blockIdx.x * k;
+    float4 me = {0.f, 0.f, 0.f, 0.f};
+    float myArea = 0.f;
+    if (j < k) {
+        me = b[j];
+        myArea = __fmul_rn(__fsub_rn(me.z, me.x), __fsub_rn(me.w, me.y));
+        sb[j] = me;
+        sarea[j] = myArea;
+    }
+    __syncthreads();
+    if (j >= k) return;
+    float best = 0.f;
+    bool nan = false;
+    for (int i = 0; i < j; i++) {
+        const float4 o = sb[i];  // the same address for every lane: a broadcast
+        float w = __fsub_rn(fminf(o.z, me.z), fmaxf(o.x, me.x)), h = __fsub_rn(fminf(o.w, me.w), fmaxf(o.y, me.y));
+        w = w < 0.f ? 0.f : w;
+        h = h < 0.f ? 0.f : h;
+        const float inter = __fmul_rn(w, h);
+        const float uni = __fsub_rn(__fadd_rn(sarea[i], myArea), inter);
+        const float iou = (float)((double)inter / (double)uni);  // == the correctly rounded float quotient
+        nan = nan || iou != iou;
+        best = iou > best ? iou : best;
+    }
+    out[(size_t)blockIdx.x * k + j] = nan ? __builtin_nanf("") : best;
 }
 
 }  // namespace amos
@@ -300,8 +341,8 @@ int amos_mask_bias_act_device(void *stream, float *d_y, const float *d_bias, con
 }
 
 
-int amos_mask_bilinear_nhwc_device(void *stream, const float *d_x, float *d_y, int n, int in_h, int in_w, int out_h, int out_w, int channels,
-                                   float scale_h, float scale_w)
+int amos_mask_bilinear_nhwc_act_device(void *stream, const float *d_x, float *d_y, int n, int in_h, int in_w, int out_h, int out_w, int channels,
+                                       float scale_h, float scale_w, int relu)
 {
     if (!d_x || !d_y || n < 1 || in_h < 1 || in_w < 1 || out_h < 1 || out_w < 1 || channels < 4 || channels % 4 != 0 ||
         ((uintptr_t)d_x | (uintptr_t)d_y) % 16 != 0 || out_h > 65535 || n > 65535) {
@@ -309,8 +350,27 @@ int amos_mask_bilinear_nhwc_device(void *stream, const float *d_x, float *d_y, i
         return AMOS_ERR_INVALID;
     }
     const int c4 = channels / 4;
-    hipLaunchKernelGGL(k_bilinear_nhwc, dim3((out_w * c4 + 255) / 256, out_h, n), dim3(256), 0, (hipStream_t)stream, d_x, d_y, in_h, in_w, out_h, out_w, c4,
-                       scale_h, scale_w);
+    const dim3 grid((out_w * c4 + 255) / 256, out_h, n), block(256);
+    if (relu) hipLaunchKernelGGL(k_bilinear_nhwc<true>, grid, block, 0, (hipStream_t)stream, d_x, d_y, in_h, in_w, out_h, out_w, c4, scale_h, scale_w);
+    else hipLaunchKernelGGL(k_bilinear_nhwc<false>, grid, block, 0, (hipStream_t)stream, d_x, d_y, in_h, in_w, out_h, out_w, c4, scale_h, scale_w);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_mask_bilinear_nhwc_device(void *stream, const float *d_x, float *d_y, int n, int in_h, int in_w, int out_h, int out_w, int channels,
+                                   float scale_h, float scale_w)
+{
+    return amos_mask_bilinear_nhwc_act_device(stream, d_x, d_y, n, in_h, in_w, out_h, out_w, channels, scale_h, scale_w, 0);
+}
+
+int amos_mask_nms_column_max_device(void *stream, const float *d_boxes, float *d_out, int n_lists, int k)
+{
+    if (!d_boxes || !d_out || n_lists < 0 || k < 1 || k > 256 || (uintptr_t)d_boxes % 16 != 0) {
+        set_error("amos_mask_nms_column_max_device: invalid argument (1 <= k <= 256, 16-byte aligned boxes)");
+        return AMOS_ERR_INVALID;
+    }
+    if (n_lists == 0) return AMOS_OK;
+    hipLaunchKernelGGL(k_nms_column_max, dim3(n_lists), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4 *>(d_boxes), d_out, k);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }

@@ -28,6 +28,21 @@ def _pairwise_iou(boxes):
     return inter / (area[:, :, None] + area[:, None, :] - inter)
 
 
+def _suppression_term(cand_boxes):
+    """cand_boxes [B, C, k, 4], score-sorted along k -> [B, C, k]: for box j the largest IoU with a higher-scored box of its list
+    (`jaccard.triu_(diagonal=1).max(dim=1)` of fast_nms).  On the GPU one HIP kernel of this project (amos_mask_nms_column_max_device:
+    same float32 arithmetic, no k x k matrices -- PyTorch's nine elementwise passes over 410 MB at 32 frames); elsewhere the torch ops."""
+    B, n_cls, k = cand_boxes.shape[:3]
+    if cand_boxes.is_cuda and cand_boxes.dtype == torch.float32 and k <= 256:
+        from .. import mask_nms_column_max
+        cb = cand_boxes.contiguous()
+        out = torch.empty((B, n_cls, k), dtype=torch.float32, device=cb.device)
+        mask_nms_column_max(torch.cuda.current_stream(cb.device).cuda_stream, cb.data_ptr(), out.data_ptr(), B * n_cls, k)
+        return out
+    iou = _pairwise_iou(cand_boxes.reshape(B * n_cls, k, 4)).triu_(diagonal=1).view(B, n_cls, k, k)
+    return iou.max(dim=2)[0]
+
+
 def fast_nms(boxes, coefs, scores):
     """scores [80, K] over the K surviving priors.  Per class: sort, keep 200, drop a box when a
     higher-scored box of its class overlaps it by more than 0.5; then the best 100 over all classes."""
@@ -78,8 +93,7 @@ def detect_batch(pred):
     cand_boxes = torch.gather(boxes, 1, gather[..., None].expand(-1, -1, 4)).view(B, -1, k, 4)
     cand_coefs = torch.gather(coef, 1, gather[..., None].expand(-1, -1, coef.shape[-1])).view(B, -1, k, coef.shape[-1])
     n_cls = cand_boxes.shape[1]
-    iou = _pairwise_iou(cand_boxes.view(B * n_cls, k, 4)).triu_(diagonal=1).view(B, n_cls, k, k)
-    alive = (iou.max(dim=2)[0] <= NMS_THRESH) & (scores > 0)
+    alive = (_suppression_term(cand_boxes) <= NMS_THRESH) & (scores > 0)
     flat_scores = torch.where(alive, scores, torch.full_like(scores, -1.0)).view(B, -1)
     top_scores, order = flat_scores.topk(MAX_DETECTIONS, dim=1)       # [B, 100]
     classes = order // k

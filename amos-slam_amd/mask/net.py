@@ -79,10 +79,10 @@ def conv_bias_act(conv, x, relu, residual=None):
     return F.relu(y) if relu else y
 
 
-def bilinear(x, size=None, scale_factor=None):
-    """F.interpolate(x, mode="bilinear", align_corners=False).  Float32 channels-last tensors on the GPU go through this
-    project's HIP kernel (amos_mask_bilinear_nhwc_device: PyTorch's channels-last kernel was 13 % of the mask pass); the
-    source index and the weights are computed as PyTorch computes them."""
+def bilinear(x, size=None, scale_factor=None, relu=False):
+    """F.interpolate(x, mode="bilinear", align_corners=False), then a ReLU when asked.  Float32 channels-last tensors on the GPU
+    go through this project's HIP kernel (amos_mask_bilinear_nhwc_act_device: PyTorch's channels-last kernel was 13 % of the mask
+    pass); the source index and the weights are computed as PyTorch computes them."""
     if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last):
         n, c, h, w = x.shape
         if size is not None:
@@ -91,13 +91,15 @@ def bilinear(x, size=None, scale_factor=None):
         else:
             oh, ow = int(h * scale_factor), int(w * scale_factor)
             sh = sw = float(torch.tensor(1.0, dtype=torch.float32) / scale_factor)
-        y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+        y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         from .. import mask_bilinear_nhwc
-        mask_bilinear_nhwc(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), y.data_ptr(), n, h, w, oh, ow, c, sh, sw)
+        mask_bilinear_nhwc(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), y.data_ptr(), n, h, w, oh, ow, c, sh, sw, relu)
         return y
     if size is not None:
-        return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
-    return F.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=False)
+        y = F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    else:
+        y = F.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=False)
+    return F.relu(y) if relu else y
 
 
 def _fold(conv, bn):
@@ -336,7 +338,7 @@ class YolactR50(nn.Module):
         pyramid = self.fpn(feats)
         pn = self.proto_net  # conv, relu, conv, relu, conv, relu, upsample, relu, conv, relu, conv (+ the final ReLU)
         p = conv_bias_act(pn[4], conv_bias_act(pn[2], conv_bias_act(pn[0], pyramid[0], True), True), True)
-        p = conv_bias_act(pn[10], conv_bias_act(pn[8], F.relu(pn[6](p)), True), True)
+        p = conv_bias_act(pn[10], conv_bias_act(pn[8], bilinear(p, scale_factor=2, relu=True), True), True)  # pn[6] (upsample) + pn[7] (ReLU) in one pass
         proto = p.permute(0, 2, 3, 1).contiguous()
         head = self.prediction_layers[0]
         locs, confs, coefs = zip(*(head(p) for p in pyramid))

@@ -355,6 +355,17 @@ int amos_mask_conv1x1_device(void *stream, const float *d_x, const float *d_w, c
 int amos_mask_bilinear_nhwc_device(void *stream, const float *d_x, float *d_y, int n, int in_h, int in_w, int out_h,
                                    int out_w, int channels, float scale_h, float scale_w);
 
+/* The same with a ReLU on the result when relu != 0 (the prototype network's upsample, yolact.py proto_net[6..7]). */
+int amos_mask_bilinear_nhwc_act_device(void *stream, const float *d_x, float *d_y, int n, int in_h, int in_w, int out_h,
+                                       int out_w, int channels, float scale_h, float scale_w, int relu);
+
+/* The suppression term of Fast NMS (layers/functions/detection.py:103-170 fast_nms, layers/box_utils.py jaccard): d_boxes holds
+ * n_lists lists of k boxes [x1, y1, x2, y2] sorted by descending score; d_out[list][j] = max over i < j of IoU(box i, box j), 0 for
+ * j == 0 -- what `jaccard(boxes, boxes).triu_(diagonal=1).max(dim=1)` yields, in jaccard's float32 arithmetic (bit-identical to
+ * PyTorch's elementwise kernels), without materialising the k x k matrices.  1 <= k <= 256. */
+int amos_mask_nms_column_max_device(void *stream, const float *d_boxes, float *d_out, int n_lists, int k);
+
+
 /* ---------------------------------------------------------------- SLIC superpixels (8f-2) ---- */
 
 /* ORB_SLAM2::center, include/cluster.h:21-30. */

@@ -392,3 +392,48 @@ def test_hip_bilinear_nhwc_equals_torch_interpolate(mask, gpu_lib):
         torch.cuda.synchronize()
         assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
         assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max())), (n, c, h, w, kw)
+
+
+@pytest.mark.gpu
+def test_nms_suppression_kernel_equals_the_torch_ops(mask, gpu_lib):
+    """amos_mask_nms_column_max_device against `jaccard(boxes, boxes).triu_(diagonal=1).max(dim=1)` as PyTorch computes it on the same
+    GPU: random boxes, heavily overlapping boxes (many IoUs around the 0.5 threshold), duplicates (IoU exactly 1), k = 1 and k = 200.
+    Bit-identical; then detect_batch end to end against the reference-order detect() (test_static_shape_batch_post... covers the CPU)."""
+    det = importlib.import_module("amos_slam_amd.mask.detect")
+    torch.manual_seed(11)
+    st = torch.cuda.current_stream().cuda_stream
+    for lists, k, spread in ((7, 200, 1.0), (160, 200, 0.05), (3, 1, 1.0), (5, 37, 0.2), (2, 256, 0.1)):
+        c = torch.rand(lists, k, 2, device="cuda") * spread + 0.3
+        wh = torch.rand(lists, k, 2, device="cuda") * 0.2 + 0.05
+        boxes = torch.cat((c - wh / 2, c + wh / 2), -1)
+        if k > 4:
+            boxes[:, 3] = boxes[:, 1]  # a duplicate: IoU 1 with a higher-scored box
+        want = det._pairwise_iou(boxes).triu_(diagonal=1).max(dim=1)[0]
+        got = torch.full((lists, k), float("nan"), device="cuda")
+        gpu_lib.mask_nms_column_max(st, boxes.contiguous().data_ptr(), got.data_ptr(), lists, k)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (lists, k, (got - want).abs().max().item())
+        assert got[:, 0].abs().max().item() == 0.0
+        via = det._suppression_term(boxes.view(1, lists, k, 4))
+        assert torch.equal(via.view(lists, k), want)
+    # a degenerate pair (two zero-area boxes at the same place): 0 / 0 = NaN wins the maximum, as in torch.max
+    boxes = torch.tensor([[[0.5, 0.5, 0.5, 0.5], [0.5, 0.5, 0.5, 0.5], [0.1, 0.1, 0.2, 0.2]]], device="cuda")
+    want = det._pairwise_iou(boxes).triu_(diagonal=1).max(dim=1)[0]
+    got = torch.zeros((1, 3), device="cuda")
+    gpu_lib.mask_nms_column_max(st, boxes.data_ptr(), got.data_ptr(), 1, 3)
+    torch.cuda.synchronize()
+    assert torch.isnan(want[0, 1]) and torch.isnan(got[0, 1]) and got[0, 0] == 0 and got[0, 2] == want[0, 2]
+    with pytest.raises(gpu_lib.AmosError):
+        gpu_lib.mask_nms_column_max(st, boxes.data_ptr(), got.data_ptr(), 1, 257)
+
+
+@pytest.mark.gpu
+def test_bilinear_with_relu_equals_relu_of_bilinear(mask, gpu_lib):
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    torch.manual_seed(12)
+    x = torch.randn(2, 256, 69, 69, device="cuda").contiguous(memory_format=torch.channels_last)
+    plain = net_mod.bilinear(x, scale_factor=2)
+    fused = net_mod.bilinear(x, scale_factor=2, relu=True)
+    assert fused.is_contiguous(memory_format=torch.channels_last) and torch.equal(fused, torch.relu(plain)) and bool((fused == 0).any())
+    cpu = net_mod.bilinear(x.cpu(), scale_factor=2, relu=True)
+    assert torch.allclose(cpu, fused.cpu(), rtol=1e-5, atol=1e-6)
