@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -468,6 +468,16 @@ def mask_bilinear_nhwc(stream_ptr, x_ptr, y_ptr, n, in_h, in_w, out_h, out_w, ch
     _check(lib().amos_mask_bilinear_nhwc_act_device(C.c_void_p(stream_ptr), C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_int(n), C.c_int(in_h), C.c_int(in_w),
                                                     C.c_int(out_h), C.c_int(out_w), C.c_int(channels), C.c_float(scale_h), C.c_float(scale_w), C.c_int(int(relu))),
            "amos_mask_bilinear_nhwc_act_device")
+
+
+def mask_class_scores(stream_ptr, conf_ptr, scores_ptr, batch, n_priors, n_classes_with_background, threshold):
+    _check(lib().amos_mask_class_scores_device(C.c_void_p(stream_ptr), C.c_void_p(conf_ptr), C.c_void_p(scores_ptr), C.c_int(batch), C.c_int(n_priors),
+                                               C.c_int(n_classes_with_background), C.c_float(threshold)), "amos_mask_class_scores_device")
+
+
+def mask_person_mask(stream_ptr, masks_ptr, flags_ptr, out_ptr, batch, n_det, mask_h, mask_w, out_h, out_w):
+    _check(lib().amos_mask_person_mask_device(C.c_void_p(stream_ptr), C.c_void_p(masks_ptr), C.c_void_p(flags_ptr), C.c_void_p(out_ptr), C.c_int(batch),
+                                              C.c_int(n_det), C.c_int(mask_h), C.c_int(mask_w), C.c_int(out_h), C.c_int(out_w)), "amos_mask_person_mask_device")
 
 
 def mask_nms_column_max(stream_ptr, boxes_ptr, out_ptr, n_lists, k):

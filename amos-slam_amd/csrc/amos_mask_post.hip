@@ -1,0 +1,112 @@
+// amos_mask_post.hip -- the two memory-bound ends of the mask network's post-processing (a15: layers/functions/detection.py Detect,
+// yolact_interface.py postprocess / prep_display as amos-slam_amd/mask/detect.py and post.py restate them) as single passes.
+//
+//   k_class_scores  conf [B][P][1 + C] (softmax output) -> scores [B][C][P]: the background column dropped, the classes transposed to
+//                   the layout top-k wants, and every prior whose best class score is <= the threshold set to -1 (detect_batch's
+//                   static-shape form of `conf_scores.max(0) > conf_thresh`).  PyTorch: a strided max (0.28 ms at 32 frames), a fill,
+//                   a where and a transposing copy (0.35 ms) over 200 MB each; here one read and one write.  Pure selection: exact.
+//   k_person_mask   cropped sigmoid masks [B][n][ph][pw] + per-detection flags -> uint8 [B][H][W]: bilinear upsample to the frame
+//                   (align_corners = False, PyTorch's source index and weights), > 0.5, count of the flagged detections, x 255 modulo
+//                   256 (the reference's `(m * 255).byte()`).  PyTorch: upsample to a [B][15][H][W] float tensor (590 MB at 32 frames),
+//                   compare, and, widen, sum; here the 36 MB of masks are read and the 10 MB result written, unflagged detections skipped.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/amos_frontend.h"
+#include "amos_common.h"
+
+namespace amos {
+
+// One work-group transposes a tile of 64 priors x all classes through LDS: coalesced reads along the class axis, coalesced writes
+// along the prior axis.  grid = (ceil(P / 64), B), block = 256.
+constexpr int kScoreTile = 64;
+__global__ __launch_bounds__(256) void k_class_scores(const float *__restrict__ conf, float *__restrict__ scores, int P, int C1, float thresh)
+{
+    extern __shared__ float tile[];  // [kScoreTile][C1 + 1]
+    __shared__ float best[kScoreTile];
+    const int b = blockIdx.y, p0 = blockIdx.x * kScoreTile, np = min(kScoreTile, P - p0), pitch = C1 + 1;
+    const float *src = conf + ((size_t)b * P + p0) * C1;
+    for (int e = threadIdx.x; e < np * C1; e += 256) {
+        const int r = e / C1, c = e - r * C1;
+        tile[r * pitch + c] = src[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < np) {
+        const float *row = tile + threadIdx.x * pitch;
+        float m = row[1];
+        bool nan = m != m;
+        for (int c = 2; c < C1; c++) {
+            const float v = row[c];
+            nan = nan || v != v;
+            m = v > m ? v : m;
+        }
+        best[threadIdx.x] = nan ? __builtin_nanf("") : m;  // torch.max propagates a NaN; NaN > thresh is false
+    }
+    __syncthreads();
+    const int C = C1 - 1;
+    for (int e = threadIdx.x; e < C * kScoreTile; e += 256) {
+        const int c = e / kScoreTile, r = e - c * kScoreTile;
+        if (r < np) scores[((size_t)b * C + c) * P + p0 + r] = best[r] > thresh ? tile[r * pitch + c + 1] : -1.f;
+    }
+}
+
+// grid = (ceil(W / 64), ceil(H / 4), B), block = (64, 4).
+__global__ __launch_bounds__(256) void k_person_mask(const float *__restrict__ masks, const uint8_t *__restrict__ flags, uint8_t *__restrict__ out, int n,
+                                                    int ph, int pw, int H, int W, float scaleH, float scaleW)
+{
+    const int ox = blockIdx.x * 64 + threadIdx.x, oy = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+    if (ox >= W || oy >= H) return;
+    float fy = __fsub_rn(__fmul_rn(scaleH, __fadd_rn((float)oy, 0.5f)), 0.5f), fx = __fsub_rn(__fmul_rn(scaleW, __fadd_rn((float)ox, 0.5f)), 0.5f);
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < ph - 1 ? 1 : 0), x1 = x0 + (x0 < pw - 1 ? 1 : 0);
+    const float ly = __fsub_rn(fy, (float)y0), lx = __fsub_rn(fx, (float)x0), hy = __fsub_rn(1.f, ly), hx = __fsub_rn(1.f, lx);
+    unsigned count = 0;
+    for (int i = 0; i < n; i++) {
+        if (!flags[b * n + i]) continue;  // uniform over the work-group
+        const float *m = masks + ((size_t)b * n + i) * ph * pw;
+        const float p = m[y0 * pw + x0], r = m[y0 * pw + x1], s = m[y1 * pw + x0], u = m[y1 * pw + x1];
+        const float v = __fadd_rn(__fmul_rn(hy, __fadd_rn(__fmul_rn(hx, p), __fmul_rn(lx, r))), __fmul_rn(ly, __fadd_rn(__fmul_rn(hx, s), __fmul_rn(lx, u))));
+        count += v > 0.5f ? 1u : 0u;
+    }
+    out[((size_t)b * H + oy) * W + ox] = (uint8_t)((count * 255u) & 0xffu);
+}
+
+}  // namespace amos
+
+using namespace amos;
+
+extern "C" {
+
+int amos_mask_class_scores_device(void *stream, const float *d_conf, float *d_scores, int batch, int n_priors, int n_classes_with_background, float threshold)
+{
+    if (!d_conf || !d_scores || batch < 0 || n_priors < 1 || n_classes_with_background < 2 || n_classes_with_background > 512 || batch > 65535) {
+        set_error("amos_mask_class_scores_device: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    if (batch == 0) return AMOS_OK;
+    const size_t lds = (size_t)kScoreTile * (n_classes_with_background + 1) * sizeof(float);
+    hipLaunchKernelGGL(k_class_scores, dim3((n_priors + kScoreTile - 1) / kScoreTile, batch), dim3(256), lds, (hipStream_t)stream, d_conf, d_scores, n_priors,
+                       n_classes_with_background, threshold);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_mask_person_mask_device(void *stream, const float *d_masks, const uint8_t *d_flags, uint8_t *d_out, int batch, int n_det, int mask_h, int mask_w,
+                                 int out_h, int out_w)
+{
+    if (!d_masks || !d_flags || !d_out || batch < 0 || n_det < 0 || mask_h < 1 || mask_w < 1 || out_h < 1 || out_w < 1 || batch > 65535 || out_h > 4 * 65535) {
+        set_error("amos_mask_person_mask_device: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    if (batch == 0) return AMOS_OK;
+    // PyTorch's area_pixel_compute_scale for a given output size: input / output in float32
+    const float sh = (float)mask_h / (float)out_h, sw = (float)mask_w / (float)out_w;
+    hipLaunchKernelGGL(k_person_mask, dim3((out_w + 63) / 64, (out_h + 3) / 4, batch), dim3(64, 4), 0, (hipStream_t)stream, d_masks, d_flags, d_out, n_det, mask_h,
+                       mask_w, out_h, out_w, sh, sw);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+}  // extern "C"

@@ -84,9 +84,15 @@ def detect_batch(pred):
     size = priors[None, :, 2:] * torch.exp(loc[..., 2:] * 0.2)
     x1y1 = centre - size / 2
     boxes = torch.cat((x1y1, x1y1 + size), -1)                       # [B, P, 4]
-    cls = conf.transpose(1, 2)[:, 1:, :]                             # [B, 80, P]
-    keep = cls.max(dim=1, keepdim=True)[0] > CONF_THRESH             # [B, 1, P]
-    cls = torch.where(keep, cls, torch.full_like(cls, -1.0))
+    if conf.is_cuda and conf.dtype == torch.float32 and conf.is_contiguous():
+        # one HIP pass (amos_mask_class_scores_device) instead of a strided max, a fill, a where and a transposing copy
+        from .. import mask_class_scores
+        cls = torch.empty((B, conf.shape[2] - 1, P), dtype=torch.float32, device=conf.device)
+        mask_class_scores(torch.cuda.current_stream(conf.device).cuda_stream, conf.data_ptr(), cls.data_ptr(), B, P, conf.shape[2], CONF_THRESH)
+    else:
+        cls = conf.transpose(1, 2)[:, 1:, :]                             # [B, 80, P]
+        keep = cls.max(dim=1, keepdim=True)[0] > CONF_THRESH             # [B, 1, P]
+        cls = torch.where(keep, cls, torch.full_like(cls, -1.0))
     k = min(NMS_TOP_K, P)
     scores, idx = cls.topk(k, dim=2)                                 # [B, 80, k], descending
     gather = idx.reshape(B, -1)

@@ -76,7 +76,15 @@ def person_mask_batch(det, w, h):
     rows = torch.arange(ph, device=masks.device, dtype=x1.dtype).view(1, 1, -1, 1)
     inside = (cols >= x1[..., None, None]) & (cols < x2[..., None, None]) & (rows >= y1[..., None, None]) & (rows < y2[..., None, None])
     masks = masks * inside.to(masks.dtype)
+    person = sel_valid & (sel_cls == PERSON_CLASS)
+    if masks.is_cuda and masks.dtype == torch.float32:
+        # upsample + threshold + count of the displayed persons + (x 255).byte() in one HIP pass (amos_mask_person_mask_device) instead
+        # of a [B, 15, h, w] float tensor and four passes over it
+        from .. import mask_person_mask
+        masks, flags = masks.contiguous(), person.to(torch.uint8).contiguous()
+        out = torch.empty((B, h, w), dtype=torch.uint8, device=masks.device)
+        mask_person_mask(torch.cuda.current_stream(masks.device).cuda_stream, masks.data_ptr(), flags.data_ptr(), out.data_ptr(), B, masks.shape[1], ph, pw, h, w)
+        return out, found
     masks = F.interpolate(masks, (h, w), mode="bilinear", align_corners=False) > 0.5
-    person = (sel_valid & (sel_cls == PERSON_CLASS))[..., None, None]
-    total = (masks & person).sum(dim=1)
+    total = (masks & person[..., None, None]).sum(dim=1)
     return ((total.to(torch.int64) * 255) & 0xFF).to(torch.uint8), found

@@ -365,6 +365,20 @@ int amos_mask_bilinear_nhwc_act_device(void *stream, const float *d_x, float *d_
  * PyTorch's elementwise kernels), without materialising the k x k matrices.  1 <= k <= 256. */
 int amos_mask_nms_column_max_device(void *stream, const float *d_boxes, float *d_out, int n_lists, int k);
 
+/* Class scores for Fast NMS in the static-shape batch form (layers/functions/detection.py:46-75 as mask/detect.py detect_batch
+ * restates it): d_conf [batch][n_priors][n_classes_with_background] (the network's softmax output) -> d_scores
+ * [batch][n_classes_with_background - 1][n_priors]: the background column dropped, the class axis first (the layout top-k
+ * reads), and -1 for every prior whose best non-background score is not > threshold.  Pure selection: exact. */
+int amos_mask_class_scores_device(void *stream, const float *d_conf, float *d_scores, int batch, int n_priors,
+                                  int n_classes_with_background, float threshold);
+
+/* The tail of yolact_interface.py postprocess + prep_display (:678-779, :806-832): d_masks [batch][n_det][mask_h][mask_w] are the
+ * cropped sigmoid masks, d_flags [batch][n_det] != 0 marks the detections that count (displayed persons); d_out [batch][out_h][out_w]
+ * = (number of flagged detections whose mask, upsampled bilinearly (align_corners = False) to the frame, is > 0.5) * 255 modulo 256,
+ * the reference's `(m * 255).byte()`.  Same source index and weights as PyTorch's upsample_bilinear2d. */
+int amos_mask_person_mask_device(void *stream, const float *d_masks, const uint8_t *d_flags, uint8_t *d_out, int batch, int n_det,
+                                 int mask_h, int mask_w, int out_h, int out_w);
+
 
 /* ---------------------------------------------------------------- SLIC superpixels (8f-2) ---- */
 

@@ -437,3 +437,49 @@ def test_bilinear_with_relu_equals_relu_of_bilinear(mask, gpu_lib):
     assert fused.is_contiguous(memory_format=torch.channels_last) and torch.equal(fused, torch.relu(plain)) and bool((fused == 0).any())
     cpu = net_mod.bilinear(x.cpu(), scale_factor=2, relu=True)
     assert torch.allclose(cpu, fused.cpu(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_class_scores_kernel_equals_the_torch_ops(mask, gpu_lib):
+    """amos_mask_class_scores_device against detect_batch's torch form (transpose, drop background, max over classes > 0.05, where):
+    exact, incl. a ragged last tile of priors and scores exactly at the threshold."""
+    torch.manual_seed(13)
+    st = torch.cuda.current_stream().cuda_stream
+    for B, P, C1 in ((3, 19248, 81), (2, 100, 81), (1, 65, 5)):
+        conf = torch.softmax(torch.randn(B, P, C1, device="cuda") * 3, -1)
+        conf[0, 3, 1:] = 0.05  # best class exactly at the threshold: not kept
+        conf[0, 4, 2] = 0.9
+        cls = conf.transpose(1, 2)[:, 1:, :]
+        keep = cls.max(dim=1, keepdim=True)[0] > 0.05
+        want = torch.where(keep, cls, torch.full_like(cls, -1.0)).contiguous()
+        got = torch.full((B, C1 - 1, P), float("nan"), device="cuda")
+        gpu_lib.mask_class_scores(st, conf.data_ptr(), got.data_ptr(), B, P, C1, 0.05)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and bool((got[0, :, 3] == -1).all()) and got[0, 1, 4] == conf[0, 4, 2]
+
+
+@pytest.mark.gpu
+def test_person_mask_kernel_equals_the_torch_ops(mask, gpu_lib):
+    """amos_mask_person_mask_device against F.interpolate(...) > 0.5, & flags, sum, (x 255).byte(): smooth random masks (values cross 0.5
+    along curves, as sigmoid masks do), 0 .. 15 flagged detections, more than one overlapping detection (255 * 2 wraps to 254).
+    PyTorch's upsample kernel may contract its multiply-adds differently: a pixel whose interpolated value is within an ulp of 0.5
+    may flip, hence the bar of 1e-6 of the pixels (none observed)."""
+    F = torch.nn.functional
+    torch.manual_seed(14)
+    st = torch.cuda.current_stream().cuda_stream
+    B, n, ph, pw, h, w = 4, 15, 138, 138, 480, 640
+    base = F.interpolate(torch.randn(B, n, 9, 9, device="cuda"), (ph, pw), mode="bicubic", align_corners=False)
+    masks = torch.sigmoid(base * 4).contiguous()
+    masks[:, :, :20] = 0  # cropped region
+    flags = (torch.rand(B, n, device="cuda") < 0.4)
+    flags[0] = False
+    flags[1] = True
+    want_b = F.interpolate(masks, (h, w), mode="bilinear", align_corners=False) > 0.5
+    total = (want_b & flags[..., None, None]).sum(dim=1)
+    want = ((total.to(torch.int64) * 255) & 0xFF).to(torch.uint8)
+    got = torch.full((B, h, w), 7, dtype=torch.uint8, device="cuda")
+    gpu_lib.mask_person_mask(st, masks.data_ptr(), flags.to(torch.uint8).contiguous().data_ptr(), got.data_ptr(), B, n, ph, pw, h, w)
+    torch.cuda.synchronize()
+    differing = int((got != want).sum())
+    assert differing <= 1e-6 * got.numel(), differing
+    assert int(got[0].max()) == 0 and int((got[1] == ((255 * 2) & 0xFF)).sum()) > 0
