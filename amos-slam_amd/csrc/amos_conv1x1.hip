@@ -118,17 +118,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             *reinterpret_cast<float4 *>(ws + 96 * kGemmPitch) = w3;                                   \
         }                                                                                             \
     }
-#define AMOS_GEMM_COMPUTE(buf, kk0, kk1)                                                                                                         \
-    _Pragma("unroll") for (int kk = kk0; kk < kk1; kk++) {                                                                                      \
-        float4 xa[TI], wb[2];                                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < TI; i++) xa[i] = *reinterpret_cast<const float4 *>(&Xs[buf][xoff + i * 32 * kGemmPitch + 8 * kk]); \
-        _Pragma("unroll") for (int j = 0; j < 2; j++) wb[j] = *reinterpret_cast<const float4 *>(&Ws[buf][woff + j * 32 * kGemmPitch + 8 * kk]);  \
-        _Pragma("unroll") for (int i = 0; i < TI; i++) _Pragma("unroll") for (int j = 0; j < 2; j++) {                                           \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].x, wb[j].x, acc[i][j], 0, 0, 0);                                              \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].y, wb[j].y, acc[i][j], 0, 0, 0);                                              \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].z, wb[j].z, acc[i][j], 0, 0, 0);                                              \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].w, wb[j].w, acc[i][j], 0, 0, 0);                                              \
-        }                                                                                                                                        \
+    // fragments: two register sets, so the LDS reads of k-step kk + 1 are in flight under the MFMAs of k-step kk
+    float4 fa0[TI], fb0[2], fa1[TI], fb1[2];
+#define AMOS_GEMM_LDFRAG(fa, fb, buf, kk)                                                                                                        \
+    {                                                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < TI; i++) fa[i] = *reinterpret_cast<const float4 *>(&Xs[buf][xoff + i * 32 * kGemmPitch + 8 * (kk)]); \
+        _Pragma("unroll") for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const float4 *>(&Ws[buf][woff + j * 32 * kGemmPitch + 8 * (kk)]);  \
+    }
+#define AMOS_GEMM_MFMAS(fa, fb)                                                                           \
+    _Pragma("unroll") for (int i = 0; i < TI; i++) _Pragma("unroll") for (int j = 0; j < 2; j++) {        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);           \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);           \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);           \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);           \
+    }
+// scheduling pattern of one phase: one memory instruction of the named kind behind each of the first `n` MFMAs, then the rest of the MFMAs
+#define AMOS_GEMM_INTERLEAVE(mask, n)                                                     \
+    _Pragma("unroll") for (int q = 0; q < (n); q++) {                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(mask, 1, 0);                                 \
+    }
+    constexpr int kFragReads = TI + 2, kMfmas = 8 * TI;
+    // One stage = four k-steps of 8.  The LDS reads of step kk + 1 go out under the MFMAs of step kk; tile s + 1 (in the staging
+    // registers since the stage before) is written to the other buffer under step 1, tile s + 2 is requested under step 2; the
+    // barrier sits between steps 2 and 3 -- by then this wave holds the fragments of step 3 in registers, so after the barrier
+    // nobody reads this stage's buffer any more and the next stage may overwrite it, and the first fragments of the next stage
+    // (other buffer, complete at the barrier) are read under the MFMAs of step 3: no LDS latency is exposed at the stage boundary.
+#define AMOS_GEMM_STAGE(s, buf, kStash, kFetch, kNext)                                    \
+    {                                                                                     \
+        AMOS_GEMM_LDFRAG(fa1, fb1, buf, 1);                                               \
+        AMOS_GEMM_MFMAS(fa0, fb0);                                                        \
+        AMOS_GEMM_INTERLEAVE(0x100, kFragReads);                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, kMfmas, 0);                           \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        AMOS_GEMM_LDFRAG(fa0, fb0, buf, 2);                                               \
+        if (kStash) AMOS_GEMM_STASH((buf) ^ 1);                                           \
+        AMOS_GEMM_MFMAS(fa1, fb1);                                                        \
+        AMOS_GEMM_INTERLEAVE(0x100, kFragReads);                                          \
+        AMOS_GEMM_INTERLEAVE(0x200, XP + WP);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, kMfmas, 0);                           \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        AMOS_GEMM_LDFRAG(fa1, fb1, buf, 3);                                               \
+        if (kFetch) AMOS_GEMM_FETCH((s) + 2);                                             \
+        AMOS_GEMM_MFMAS(fa0, fb0);                                                        \
+        AMOS_GEMM_INTERLEAVE(0x100, kFragReads);                                          \
+        AMOS_GEMM_INTERLEAVE(0x020, XP + WP);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, kMfmas, 0);                           \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        __syncthreads();                                                                  \
+        if (kNext) AMOS_GEMM_LDFRAG(fa0, fb0, (buf) ^ 1, 0);                              \
+        AMOS_GEMM_MFMAS(fa1, fb1);                                                        \
+        AMOS_GEMM_INTERLEAVE(0x100, kFragReads);                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, kMfmas, 0);                           \
+        __builtin_amdgcn_sched_barrier(0);                                                \
     }
     f32x16 acc[TI][2];
 #pragma unroll
@@ -139,31 +181,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     const int xoff = (wm * 32 * TI + (lane & 31)) * kGemmPitch + 4 * (lane >> 5);
     const int woff = (wn * 64 + (lane & 31)) * kGemmPitch + 4 * (lane >> 5);
-    // Staging schedule: the registers of tile s + 1 are written to the other LDS buffer in the MIDDLE of stage s (that buffer was
-    // last read in stage s - 1, which every wave left before the barrier that ended it) and re-loaded with tile s + 2 at once,
-    // so a global load has a whole stage of MFMAs to land and the stage ends with nothing but the barrier.
     const int stages = kcPerTap * a.kh * a.kw;
     AMOS_GEMM_FETCH(0);
     AMOS_GEMM_STASH(0);
     if (stages > 1) AMOS_GEMM_FETCH(1);
     __syncthreads();
-    for (int s = 0; s < stages; s++) {
+    AMOS_GEMM_LDFRAG(fa0, fb0, 0, 0);
+    int s = 0;
+    for (; s + 2 < stages; s++) {
         const int buf = s & 1;
-        __builtin_amdgcn_sched_barrier(0);
-        AMOS_GEMM_COMPUTE(buf, 0, kGemmBK / 16);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < stages) {
-            AMOS_GEMM_STASH(buf ^ 1);
-            if (s + 2 < stages) AMOS_GEMM_FETCH(s + 2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        AMOS_GEMM_COMPUTE(buf, kGemmBK / 16, kGemmBK / 8);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        AMOS_GEMM_STAGE(s, buf, true, true, true);
+    }
+    if (s + 1 < stages) {  // the last but one: nothing left to request
+        const int buf = s & 1;
+        AMOS_GEMM_STAGE(s, buf, true, false, true);
+        s++;
+    }
+    {
+        const int buf = s & 1;
+        AMOS_GEMM_STAGE(s, buf, false, false, false);
     }
 #undef AMOS_GEMM_FETCH
 #undef AMOS_GEMM_STASH
-#undef AMOS_GEMM_COMPUTE
+#undef AMOS_GEMM_LDFRAG
+#undef AMOS_GEMM_MFMAS
+#undef AMOS_GEMM_INTERLEAVE
+#undef AMOS_GEMM_STAGE
     // epilogue.  Accumulator register r of a 32 x 32 tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31: the tile goes
     // through LDS (row-major, BN floats per row; a half-wave writes 32 consecutive floats) so that every thread then handles
     // 16-byte pieces of output rows: bias, residual and ReLU on float4, one coalesced residual load and one store per piece.

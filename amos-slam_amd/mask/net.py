@@ -24,45 +24,49 @@ PRED_SCALES = (24, 48, 96, 192, 384)   # one scale per pyramid level
 ASPECT_RATIOS = (1.0, 0.5, 2.0)        # pred_aspect_ratios; anchors are squares (use_square_anchors)
 
 
-def _gemm_conv1x1(conv, x):
-    """Should this 1 x 1 convolution run on the project's fp32 MFMA GEMM (amos_mask_conv1x1_device: bias, residual and ReLU in its
-    epilogue) rather than MIOpen + the epilogue pass?  Measured per shape on MI355X (tools/conv1x1_probe.py): it wins
-    1.03 - 1.57 x wherever the input channels are <= 512 and the launch has >= 1024 work-groups (every such layer of a 32-frame
-    chunk); MIOpen's assembly kernels keep the K-heavy, small layers (0.76 - 0.99 x there).  AMOS_MASK_CONV1X1=0 / 1 forces one
-    side for experiments."""
-    if conv.kernel_size != (1, 1) or conv.padding != (0, 0) or conv.dilation != (1, 1) or conv.groups != 1 or conv.stride[0] != conv.stride[1]:
+def _gemm_conv(conv, x):
+    """Should this convolution run on the project's fp32 MFMA (implicit) GEMM (amos_mask_conv_device: bias, residual and ReLU in its
+    epilogue) rather than MIOpen + the epilogue pass?  Measured per shape on MI355X at 32 frames (tools/conv1x1_probe.py,
+    tools/conv_gemm_probe.py).  1 x 1: the GEMM wins 1.03 - 1.56 x on every layer whose launch has >= 600
+    work-groups of 128 x 128 outputs; MIOpen's assembly kernels keep the two small K = 2048 layers (0.83 / 0.91 x: 324 / 162 groups leave
+    CUs idle).  3 x 3: 1.02 - 1.04 x on the layers with >= 1024 work-groups, MIOpen ahead on the smaller ones (0.7 - 0.9 x).
+    AMOS_MASK_CONV1X1=0 / 1 and AMOS_MASK_CONV3X3=0 force a side (experiments, tests)."""
+    k = conv.kernel_size
+    if k[0] != k[1] or conv.padding[0] != conv.padding[1] or conv.dilation != (1, 1) or conv.groups != 1 or conv.stride[0] != conv.stride[1]:
         return False
-    from .. import mask_conv1x1_supported
-    if not mask_conv1x1_supported(conv.in_channels, conv.out_channels, conv.stride[0]):
+    from .. import mask_conv_supported
+    if not mask_conv_supported(conv.in_channels, conv.out_channels, k[0], k[1], conv.stride[0], conv.padding[0]):
         return False
+    s = conv.stride[0]
+    m = x.shape[0] * ((x.shape[2] + 2 * conv.padding[0] - k[0]) // s + 1) * ((x.shape[3] + 2 * conv.padding[1] - k[1]) // s + 1)
+    groups = ((m + 127) // 128) * (conv.out_channels // (128 if conv.out_channels % 128 == 0 else 64))
+    if k != (1, 1) or conv.padding != (0, 0):
+        return os.environ.get("AMOS_MASK_CONV3X3", "1") != "0" and groups >= 1024 and conv.weight.is_contiguous(memory_format=torch.channels_last)
     mode = os.environ.get("AMOS_MASK_CONV1X1", "auto")
     if mode in ("0", "1"):
         return mode == "1"
-    s = conv.stride[0]
-    m = x.shape[0] * ((x.shape[2] - 1) // s + 1) * ((x.shape[3] - 1) // s + 1)
-    groups = ((m + 127) // 128) * (conv.out_channels // (128 if conv.out_channels % 128 == 0 else 64))
-    return conv.in_channels <= 512 and groups >= 1024
+    return groups >= 600
 
 
 def conv_bias_act(conv, x, relu, residual=None):
     """conv -> + bias -> (+ residual) -> (ReLU).  On the GPU with float32 channels-last activations the bias, the residual
     and the ReLU are ONE in-place pass by a HIP kernel of this project (amos_mask_bias_act_device) behind MIOpen's
     convolution instead of PyTorch's three elementwise passes; the summation order is the same, so are the bits.  The large
-    1 x 1 convolutions go to this project's MFMA GEMM with that epilogue fused (_gemm_conv1x1; float32 rounding apart from MIOpen).
+    1 x 1 convolutions go to this project's MFMA GEMM with that epilogue fused (_gemm_conv; float32 rounding apart from MIOpen).
     Anywhere else (CPU tests, autocast) the plain torch ops run."""
     if x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and not torch.is_autocast_enabled():
         cl = torch.channels_last
-        if _gemm_conv1x1(conv, x) and x.is_contiguous(memory_format=cl) and conv.weight.dtype == torch.float32 and (
-                conv.weight.is_contiguous() or conv.weight.is_contiguous(memory_format=cl)) and (residual is None or (
+        if _gemm_conv(conv, x) and x.is_contiguous(memory_format=cl) and conv.weight.dtype == torch.float32 and (
+                conv.weight.is_contiguous(memory_format=cl) or (conv.kernel_size == (1, 1) and conv.weight.is_contiguous())) and (residual is None or (
                 residual.dtype == torch.float32 and residual.is_contiguous(memory_format=cl))):
-            from .. import mask_conv1x1
+            from .. import mask_conv
             b, _, h, w = x.shape
-            s = conv.stride[0]
-            y = torch.empty((b, conv.out_channels, (h - 1) // s + 1, (w - 1) // s + 1), device=x.device, dtype=torch.float32, memory_format=cl)
+            s, k, p = conv.stride[0], conv.kernel_size[0], conv.padding[0]
+            y = torch.empty((b, conv.out_channels, (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1), device=x.device, dtype=torch.float32, memory_format=cl)
             if residual is not None and residual.shape != y.shape:
                 raise ValueError("conv_bias_act: residual shape %s, output shape %s" % (tuple(residual.shape), tuple(y.shape)))
-            mask_conv1x1(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), conv.weight.data_ptr(), conv.bias.data_ptr(),
-                         residual.data_ptr() if residual is not None else None, y.data_ptr(), b, h, w, conv.in_channels, conv.out_channels, s, relu)
+            mask_conv(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), conv.weight.data_ptr(), conv.bias.data_ptr(),
+                      residual.data_ptr() if residual is not None else None, y.data_ptr(), b, h, w, conv.in_channels, conv.out_channels, k, k, s, p, relu)
             return y
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if y.dtype == torch.float32 and y.is_contiguous(memory_format=cl) and (residual is None or (

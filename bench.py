@@ -176,7 +176,7 @@ def dry_run(args):
 def count_network_flops(torch, engine, batch):
     """FLOPs (2 x multiply-accumulates) of ONE network forward per frame, counted from the shapes the convolutions
     actually see: torch.nn.functional.conv2d is wrapped for one forward (every convolution of the network goes through it,
-    nn.Conv2d modules and the fused-epilogue path alike; the GEMM path of the 1 x 1 layers is switched off for that forward)."""
+    nn.Conv2d modules and the fused-epilogue path alike; the project's GEMM path is switched off for that forward)."""
     import torch.nn.functional as F
     total = [0]
     real = F.conv2d
@@ -187,17 +187,19 @@ def count_network_flops(torch, engine, batch):
         return out
 
     F.conv2d = counting
-    keep = os.environ.get("AMOS_MASK_CONV1X1")
-    os.environ["AMOS_MASK_CONV1X1"] = "0"  # for this one forward the 1 x 1 layers too go through F.conv2d (they run on the project's GEMM otherwise)
+    keep = {k: os.environ.get(k) for k in ("AMOS_MASK_CONV1X1", "AMOS_MASK_CONV3X3")}
+    for k in keep:  # for this one forward every layer goes through F.conv2d (the large ones run on the project's GEMM otherwise)
+        os.environ[k] = "0"
     try:
         with torch.no_grad():
             engine._forward(torch.zeros((batch, 3, 550, 550), device=engine.device))
     finally:
         F.conv2d = real
-        if keep is None:
-            del os.environ["AMOS_MASK_CONV1X1"]
-        else:
-            os.environ["AMOS_MASK_CONV1X1"] = keep
+        for k, v in keep.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     return total[0] / batch
 
 

@@ -370,9 +370,15 @@ def test_mfma_conv1x1_against_float64(mask, gpu_lib, monkeypatch):
     # the rule of the automatic choice: large launches with <= 512 input channels
     big, small = torch.empty(32, 64, 138, 138, device="meta"), torch.empty(1, 64, 138, 138, device="meta")
     c = torch.nn.Conv2d(64, 256, 1)
-    assert net_mod._gemm_conv1x1(c, big) and not net_mod._gemm_conv1x1(c, small)
-    assert not net_mod._gemm_conv1x1(torch.nn.Conv2d(1024, 256, 1), torch.empty(32, 1024, 35, 35, device="meta"))
-    assert not net_mod._gemm_conv1x1(torch.nn.Conv2d(256, 256, 3, padding=1), big)
+    assert net_mod._gemm_conv(c, big) and not net_mod._gemm_conv(c, small)
+    assert net_mod._gemm_conv(torch.nn.Conv2d(1024, 256, 1), torch.empty(32, 1024, 35, 35, device="meta"))       # 614 work-groups
+    assert not net_mod._gemm_conv(torch.nn.Conv2d(2048, 512, 1), torch.empty(32, 2048, 18, 18, device="meta"))   # 324
+    c3 = torch.nn.Conv2d(64, 64, 3, padding=1).to(memory_format=cl)
+    assert net_mod._gemm_conv(c3, big) and not net_mod._gemm_conv(c3, small)
+    assert not net_mod._gemm_conv(torch.nn.Conv2d(256, 243, 3, padding=1).to(memory_format=cl), torch.empty(32, 256, 69, 69, device="meta"))  # 243 channels
+    monkeypatch.setenv("AMOS_MASK_CONV3X3", "0")
+    assert not net_mod._gemm_conv(c3, big)
+    monkeypatch.delenv("AMOS_MASK_CONV3X3")
     with pytest.raises(RuntimeError):
         gpu_lib.mask_conv1x1(st, 0, 0, None, None, 0, 1, 8, 8, 64, 64, 1, True)
 
