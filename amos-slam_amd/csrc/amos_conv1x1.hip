@@ -29,6 +29,8 @@ constexpr int kGemmPitch = kGemmBK + 4;     // floats between LDS rows
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ __attribute__((aligned(16))) const float g_conv_zeros[4] = {0.f, 0.f, 0.f, 0.f};  // what a tap outside the image reads
+
 struct ConvGemmArgs {
     const float *x, *w, *bias, *res;
     float *y;
@@ -80,17 +82,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     for (int j = 0; j < WP; j++) wsrc[j] = a.w + (size_t)(nt * BN + pr + 32 * j) * wRow + 4 * pc;
     static_assert(XP == 4 && (WP == 2 || WP == 4), "the staging registers below are named one by one");
     float4 x0, x1, x2, x3, w0, w1, w2 = {}, w3 = {};  // (arrays of these end up in scratch once the scheduling fences below are in place)
+    // kTaps: the tap / channel-block of the NEXT fetch, advanced after every fetch (stages are fetched in order); a row whose tap falls
+    // outside the image reads 16 bytes of zeros instead (a select on the ADDRESS: the load itself stays unconditional, so the stage
+    // remains one scheduling region)
+    int fKc = 0, fDy = 0, fDx = 0;
+    // (the select is made on integers and the result read through a global-address-space pointer: a select of two C++ pointers of
+    // different provenance becomes a FLAT load, which also counts as an LDS operation and would be waited for at the barrier)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) f32x4 *GlobalF4;
+    const uintptr_t zeroAddr = (uintptr_t)g_conv_zeros;
+#define AMOS_GEMM_TAPSRC(i) \
+    ((GlobalF4)(((unsigned)(iy0[i] + fDy) < (unsigned)a.inH && (unsigned)(ix0[i] + fDx) < (unsigned)a.inW) ? (uintptr_t)(xsrc[i] + tapOff) : zeroAddr))
 #define AMOS_GEMM_FETCH(stage)                                                                                               \
     {                                                                                                                        \
         const int k0 = (stage) * kGemmBK;                                                                                    \
         if (kTaps) {                                                                                                         \
-            const int tap = (stage) / kcPerTap, kc = (stage) - tap * kcPerTap, dy = tap / a.kw, dx = tap - dy * a.kw;        \
-            const ptrdiff_t off = (ptrdiff_t)(dy * a.inW + dx) * a.K + kc * kGemmBK;                                         \
-            const float4 zero = {0.f, 0.f, 0.f, 0.f};                                                                        \
-            x0 = ((unsigned)(iy0[0] + dy) < (unsigned)a.inH && (unsigned)(ix0[0] + dx) < (unsigned)a.inW) ? *reinterpret_cast<const float4 *>(xsrc[0] + off) : zero; \
-            x1 = ((unsigned)(iy0[1] + dy) < (unsigned)a.inH && (unsigned)(ix0[1] + dx) < (unsigned)a.inW) ? *reinterpret_cast<const float4 *>(xsrc[1] + off) : zero; \
-            x2 = ((unsigned)(iy0[2] + dy) < (unsigned)a.inH && (unsigned)(ix0[2] + dx) < (unsigned)a.inW) ? *reinterpret_cast<const float4 *>(xsrc[2] + off) : zero; \
-            x3 = ((unsigned)(iy0[3] + dy) < (unsigned)a.inH && (unsigned)(ix0[3] + dx) < (unsigned)a.inW) ? *reinterpret_cast<const float4 *>(xsrc[3] + off) : zero; \
+            const ptrdiff_t tapOff = (ptrdiff_t)(fDy * a.inW + fDx) * a.K + fKc * kGemmBK;                                   \
+            x0 = __builtin_bit_cast(float4, *AMOS_GEMM_TAPSRC(0));                                                               \
+            x1 = __builtin_bit_cast(float4, *AMOS_GEMM_TAPSRC(1));                                                               \
+            x2 = __builtin_bit_cast(float4, *AMOS_GEMM_TAPSRC(2));                                                               \
+            x3 = __builtin_bit_cast(float4, *AMOS_GEMM_TAPSRC(3));                                                               \
+            fKc++;                                                                                                           \
+            const bool tapDone = fKc == kcPerTap;                                                                            \
+            fKc = tapDone ? 0 : fKc;                                                                                         \
+            fDx += tapDone ? 1 : 0;                                                                                          \
+            const bool rowDone = fDx == a.kw;                                                                                \
+            fDx = rowDone ? 0 : fDx;                                                                                         \
+            fDy += rowDone ? 1 : 0;                                                                                          \
         } else {                                                                                                             \
             x0 = *reinterpret_cast<const float4 *>(xsrc[0] + k0);                                                            \
             x1 = *reinterpret_cast<const float4 *>(xsrc[1] + k0);                                                            \
@@ -202,6 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         AMOS_GEMM_STAGE(s, buf, false, false, false);
     }
 #undef AMOS_GEMM_FETCH
+#undef AMOS_GEMM_TAPSRC
 #undef AMOS_GEMM_STASH
 #undef AMOS_GEMM_LDFRAG
 #undef AMOS_GEMM_MFMAS
