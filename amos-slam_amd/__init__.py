@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -440,6 +440,12 @@ def flow_scene_flow(stream, d_depth_last, last_stride, d_depth_cur, cur_stride, 
     _check(lib().amos_flow_scene_flow_device(C.c_void_p(stream), C.c_void_p(d_depth_last), C.c_size_t(last_stride), C.c_void_p(d_depth_cur),
                                              C.c_size_t(cur_stride), C.c_void_p(d_match_pre), C.c_void_p(d_match_cur), C.c_int(n), C.byref(cam),
                                              C.c_void_p(d_out)), "amos_flow_scene_flow_device")
+
+
+def mask_bias_relu_maxpool(stream_ptr, x_ptr, bias_ptr, y_ptr, n, in_h, in_w, channels):
+    """amos_mask_bias_relu_maxpool_device: max_pool2d(relu(x + bias), 3, 2, 1) of an NHWC float32 tensor in one pass (device pointers)."""
+    _check(lib().amos_mask_bias_relu_maxpool_device(C.c_void_p(stream_ptr), C.c_void_p(x_ptr), C.c_void_p(bias_ptr), C.c_void_p(y_ptr), C.c_int(n), C.c_int(in_h),
+                                                    C.c_int(in_w), C.c_int(channels)), "amos_mask_bias_relu_maxpool_device")
 
 
 def mask_conv1x1_supported(cin, cout, stride):

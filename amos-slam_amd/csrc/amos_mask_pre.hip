@@ -119,6 +119,55 @@ __global__ __launch_bounds__(256) void k_bias_act(float *__restrict__ y, const f
     }
 }
 
+// ---- the stem's tail: bias + ReLU + max_pool2d(3, stride 2, padding 1) of the 7 x 7 convolution's raw output in one pass
+// (backbone.py ResNetBackbone.forward: conv1 -> bn1 (folded) -> relu -> maxpool).  relu(x + b) is monotone in x, and rounding is
+// monotone, so max over the window of relu(x_i + b) == relu(max_i(x_i) + b) bit for bit: the kernel takes the maximum of the raw
+// values (padding = -inf, as F.max_pool2d pads) and applies bias and ReLU once.  Replaces the in-place bias/ReLU pass over the
+// 275 x 275 x 64 tensor (read + write) and the pooling kernel's read of it with one read.
+// grid = (ceil(outW * C / 4 / 256), outH, N), block = 256; a thread makes four channels of one pooled pixel.
+__global__ __launch_bounds__(256) void k_bias_relu_maxpool(const float *__restrict__ x, const float *__restrict__ bias, float *__restrict__ y, int inH, int inW,
+                                                          int outH, int outW, int c4)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= outW * c4) return;
+    const int ox = t / c4, q = t - ox * c4, oy = blockIdx.y, n = blockIdx.z;
+    const float4 *src = reinterpret_cast<const float4 *>(x) + (size_t)n * inH * inW * c4;
+    const float ninf = -__builtin_inff();
+    float4 m = {ninf, ninf, ninf, ninf};
+    bool nan = false;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++) {
+        const int iy = 2 * oy + dy;
+        if ((unsigned)iy >= (unsigned)inH) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            const int ix = 2 * ox + dx;
+            if ((unsigned)ix >= (unsigned)inW) continue;
+            const float4 v = src[((size_t)iy * inW + ix) * c4 + q];
+            nan = nan || v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
+            m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y; m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+        }
+    }
+    const float4 b = reinterpret_cast<const float4 *>(bias)[q];
+    float4 r = {fmaxf(__fadd_rn(m.x, b.x), 0.f), fmaxf(__fadd_rn(m.y, b.y), 0.f), fmaxf(__fadd_rn(m.z, b.z), 0.f), fmaxf(__fadd_rn(m.w, b.w), 0.f)};
+    if (nan) {  // rare path: per component, a NaN in the window wins (as in max_pool2d of the relu'd tensor)
+        float *rp = &r.x;
+        for (int e = 0; e < 4; e++) {
+            bool cn = false;
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    const int iy = 2 * oy + dy, ix = 2 * ox + dx;
+                    if ((unsigned)iy < (unsigned)inH && (unsigned)ix < (unsigned)inW) {
+                        const float v = (&src[((size_t)iy * inW + ix) * c4 + q].x)[e];
+                        cn = cn || v != v;
+                    }
+                }
+            if (cn) rp[e] = __builtin_nanf("");
+        }
+    }
+    reinterpret_cast<float4 *>(y)[(((size_t)n * outH + oy) * outW + ox) * c4 + q] = r;
+}
+
 // ---- bilinear resize of an NHWC float tensor (F.interpolate(..., mode="bilinear", align_corners=False): the FPN's
 // top-down path and the prototype network's x2 step, yolact.py:318-329, config mask_proto_net).  PyTorch's channels-last
 // kernel for this took 13 % of the mask pass (5 ms per call at 32 frames); here a thread makes four channels of one
@@ -336,6 +385,20 @@ int amos_mask_bias_act_device(void *stream, float *d_y, const float *d_bias, con
     if (vec && pow2) hipLaunchKernelGGL((k_bias_act<true, true>), grid, block, 0, (hipStream_t)stream, d_y, d_bias, d_residual, n, channels, relu);
     else if (vec) hipLaunchKernelGGL((k_bias_act<true, false>), grid, block, 0, (hipStream_t)stream, d_y, d_bias, d_residual, n, channels, relu);
     else hipLaunchKernelGGL((k_bias_act<false, false>), grid, block, 0, (hipStream_t)stream, d_y, d_bias, d_residual, n, channels, relu);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+
+int amos_mask_bias_relu_maxpool_device(void *stream, const float *d_x, const float *d_bias, float *d_y, int n, int in_h, int in_w, int channels)
+{
+    if (!d_x || !d_bias || !d_y || n < 1 || in_h < 1 || in_w < 1 || channels < 4 || channels % 4 != 0 ||
+        ((uintptr_t)d_x | (uintptr_t)d_y | (uintptr_t)d_bias) % 16 != 0 || n > 65535 || in_h > 2 * 65535) {
+        set_error("amos_mask_bias_relu_maxpool_device: invalid argument (channels % 4 == 0, 16-byte aligned tensors)");
+        return AMOS_ERR_INVALID;
+    }
+    const int oh = (in_h + 2 - 3) / 2 + 1, ow = (in_w + 2 - 3) / 2 + 1, c4 = channels / 4;
+    hipLaunchKernelGGL(k_bias_relu_maxpool, dim3((ow * c4 + 255) / 256, oh, n), dim3(256), 0, (hipStream_t)stream, d_x, d_bias, d_y, in_h, in_w, oh, ow, c4);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }

@@ -183,8 +183,21 @@ class ResNet50Trunk(nn.Module):
                 block.fold_batch_norms()
 
     def forward(self, x):
-        x = conv_bias_act(self.conv1, x, True) if self.conv1.bias is not None else F.relu(self.bn1(self.conv1(x)))
-        x = F.max_pool2d(x, 3, stride=2, padding=1)
+        cl = torch.channels_last
+        if self.conv1.bias is not None and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
+            # raw convolution, then bias + ReLU + max-pool in one pass of a HIP kernel (bit-identical to the separate passes)
+            raw = F.conv2d(x, self.conv1.weight, None, self.conv1.stride, self.conv1.padding)
+            if raw.is_contiguous(memory_format=cl) and raw.shape[1] % 4 == 0:
+                from .. import mask_bias_relu_maxpool
+                b, c, h, w = raw.shape
+                y = torch.empty((b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device, memory_format=cl)
+                mask_bias_relu_maxpool(torch.cuda.current_stream(x.device).cuda_stream, raw.data_ptr(), self.conv1.bias.data_ptr(), y.data_ptr(), b, h, w, c)
+                x = y
+            else:
+                x = F.max_pool2d(F.relu(raw + self.conv1.bias.view(1, -1, 1, 1)), 3, stride=2, padding=1)
+        else:
+            x = conv_bias_act(self.conv1, x, True) if self.conv1.bias is not None else F.relu(self.bn1(self.conv1(x)))
+            x = F.max_pool2d(x, 3, stride=2, padding=1)
         outs = []
         for layer in self.layers:
             x = layer(x)

@@ -330,6 +330,12 @@ int amos_orb_detect_color_with_mask_pre_batch_device(amos_orb *h, amos_mask_pre 
 int amos_mask_bias_act_device(void *stream, float *d_y, const float *d_bias, const float *d_residual, size_t n,
                               int channels, int relu);
 
+/* The stem's tail (backbone.py ResNetBackbone.forward: bn1 folded -> relu -> maxpool): y = max_pool2d(relu(x + bias[c]), 3, stride 2,
+ * padding 1) of a channels-last float32 tensor x [n][in_h][in_w][channels] (a convolution's raw output) in ONE pass; y is
+ * [n][(in_h - 1) / 2 + 1][(in_w - 1) / 2 + 1][channels].  Bit-identical to the separate passes (max and the monotone bias + ReLU commute). */
+int amos_mask_bias_relu_maxpool_device(void *stream, const float *d_x, const float *d_bias, float *d_y, int n, int in_h, int in_w,
+                                       int channels);
+
 /* A convolution of the mask network (yolact.py / backbone.py as amos-slam_amd/mask/net.py restates them: the ResNet-50
  * bottlenecks, the FPN, the prototype network, the prediction heads) on channels-last float32 tensors as one fp32 MFMA
  * (implicit) GEMM with the epilogue of amos_mask_bias_act_device fused:

@@ -489,3 +489,24 @@ def test_person_mask_kernel_equals_the_torch_ops(mask, gpu_lib):
     differing = int((got != want).sum())
     assert differing <= 1e-6 * got.numel(), differing
     assert int(got[0].max()) == 0 and int((got[1] == ((255 * 2) & 0xFF)).sum()) > 0
+
+
+@pytest.mark.gpu
+def test_bias_relu_maxpool_kernel_equals_the_torch_ops(mask, gpu_lib):
+    """amos_mask_bias_relu_maxpool_device against F.max_pool2d(F.relu(x + bias), 3, 2, 1) on channels-last tensors: odd and even sizes
+    (the stem's 275 x 275 and others), negative maxima (ReLU clamps after the max), a NaN in one window.  Bit-identical."""
+    F = torch.nn.functional
+    torch.manual_seed(15)
+    st = torch.cuda.current_stream().cuda_stream
+    cl = torch.channels_last
+    for n, c, h, w in ((2, 64, 275, 275), (1, 8, 6, 9), (3, 4, 1, 1), (1, 64, 14, 15)):
+        x = (torch.randn(n, c, h, w, device="cuda") - 0.5).contiguous(memory_format=cl)
+        bias = torch.randn(c, device="cuda")
+        if h > 4:
+            x[0, 1, 3, 4] = float("nan")
+        want = F.max_pool2d(F.relu(x + bias.view(1, -1, 1, 1)), 3, stride=2, padding=1)
+        got = torch.full(want.shape, 7.0, device="cuda").contiguous(memory_format=cl)
+        gpu_lib.mask_bias_relu_maxpool(st, x.data_ptr(), bias.data_ptr(), got.data_ptr(), n, h, w, c)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape and torch.equal(torch.isnan(got), torch.isnan(want)), (n, c, h, w)
+        assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want)), (n, c, h, w, (torch.nan_to_num(got) - torch.nan_to_num(want)).abs().max().item())
