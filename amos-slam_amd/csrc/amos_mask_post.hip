@@ -1,4 +1,4 @@
-// amos_mask_post.hip -- the two memory-bound ends of the mask network's post-processing (a15: layers/functions/detection.py Detect,
+// amos_mask_post.hip -- the memory-bound ends of the mask network's post-processing (a15: layers/functions/detection.py Detect,
 // yolact_interface.py postprocess / prep_display as amos-slam_amd/mask/detect.py and post.py restate them) as single passes.
 //
 //   k_class_scores  conf [B][P][1 + C] (softmax output) -> scores [B][C][P]: the background column dropped, the classes transposed to
@@ -73,6 +73,55 @@ __global__ __launch_bounds__(256) void k_person_mask(const float *__restrict__ m
     out[((size_t)b * H + oy) * W + ox] = (uint8_t)((count * 255u) & 0xffu);
 }
 
+// The prediction head's outputs for one pyramid level (yolact.py PredictionModule.forward + Yolact.forward's cat / softmax, as mask/net.py
+// restates them): raw = the merged 3 x 3 convolution's output WITHOUT bias, channels-last [B][cells][cpad] with channels
+// [A x 4 box | A x (1 + C) class | A x D coefficient | padding]; this level's priors (cell-major, anchor-minor) start at prior p_off of
+// the concatenated outputs loc [B][P][4] = raw + bias, conf [B][P][1 + C] = softmax over the classes of (raw + bias), coef [B][P][D] =
+// tanh(raw + bias).  PyTorch: a bias pass, three strided reshape copies per level, three concatenations, a softmax and a tanh pass;
+// here each level's tensor is read once and the three outputs are written once, as contiguous runs (the priors of consecutive cells are
+// consecutive).  A work-group stages kHeadCells cells in LDS.  Softmax as PyTorch's: max, exp(x - max), sum, divide -- the sum is taken
+// sequentially here and by a butterfly there, so conf agrees to float32 rounding (1 - 2 ulp), loc and coef bit for bit.
+// grid = (ceil(cells / kHeadCells), B), block = 256.
+constexpr int kHeadCells = 16;
+__global__ __launch_bounds__(256) void k_head_outputs(const float *__restrict__ raw, const float *__restrict__ bias, float *__restrict__ loc, float *__restrict__ conf,
+                                                     float *__restrict__ coef, int cells, int cpad, int A, int C1, int D, int P, int pOff)
+{
+    extern __shared__ float sh[];  // [kHeadCells][cpad]
+    const int b = blockIdx.y, c0 = blockIdx.x * kHeadCells, nc = min(kHeadCells, cells - c0);
+    const int nLoc = A * 4, nConf = A * C1, nCoef = A * D;
+    const float *src = raw + ((size_t)b * cells + c0) * cpad;
+    for (int e = threadIdx.x * 4; e < nc * cpad; e += 256 * 4) {  // cpad % 4 == 0
+        float4 v = *reinterpret_cast<const float4 *>(src + e);
+        const float4 bb = *reinterpret_cast<const float4 *>(bias + e % cpad);
+        v.x = __fadd_rn(v.x, bb.x); v.y = __fadd_rn(v.y, bb.y); v.z = __fadd_rn(v.z, bb.z); v.w = __fadd_rn(v.w, bb.w);
+        *reinterpret_cast<float4 *>(sh + e) = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nc * A) {  // one thread per prior: softmax over its 1 + C class values, in place
+        const int cell = threadIdx.x / A, a = threadIdx.x - cell * A;
+        float *v = sh + cell * cpad + nLoc + a * C1;
+        float m = v[0];
+        for (int c = 1; c < C1; c++) m = fmaxf(m, v[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C1; c++) {
+            const float e = expf(__fsub_rn(v[c], m));
+            v[c] = e;
+            sum = __fadd_rn(sum, e);
+        }
+        for (int c = 0; c < C1; c++) v[c] = v[c] / sum;
+    }
+    for (int e = threadIdx.x; e < nc * nCoef; e += 256) {
+        const int cell = e / nCoef, k = e - cell * nCoef;
+        float *v = sh + cell * cpad + nLoc + nConf + k;
+        *v = tanhf(*v);
+    }
+    __syncthreads();
+    const size_t prior0 = (size_t)b * P + pOff + (size_t)c0 * A;  // first prior of this work-group
+    for (int e = threadIdx.x; e < nc * nLoc; e += 256) loc[prior0 * 4 + e] = sh[(e / nLoc) * cpad + e % nLoc];
+    for (int e = threadIdx.x; e < nc * nConf; e += 256) conf[prior0 * C1 + e] = sh[(e / nConf) * cpad + nLoc + e % nConf];
+    for (int e = threadIdx.x; e < nc * nCoef; e += 256) coef[prior0 * D + e] = sh[(e / nCoef) * cpad + nLoc + nConf + e % nCoef];
+}
+
 }  // namespace amos
 
 using namespace amos;
@@ -105,6 +154,25 @@ int amos_mask_person_mask_device(void *stream, const float *d_masks, const uint8
     const float sh = (float)mask_h / (float)out_h, sw = (float)mask_w / (float)out_w;
     hipLaunchKernelGGL(k_person_mask, dim3((out_w + 63) / 64, (out_h + 3) / 4, batch), dim3(64, 4), 0, (hipStream_t)stream, d_masks, d_flags, d_out, n_det, mask_h,
                        mask_w, out_h, out_w, sh, sw);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_mask_head_outputs_device(void *stream, const float *d_raw, const float *d_bias, float *d_loc, float *d_conf, float *d_coef, int batch, int cells,
+                                  int channels_padded, int anchors, int n_classes_with_background, int mask_dim, int n_priors_total, int prior_offset)
+{
+    const long long used = (long long)anchors * (4 + n_classes_with_background + mask_dim);
+    if (!d_raw || !d_bias || !d_loc || !d_conf || !d_coef || batch < 0 || cells < 1 || anchors < 1 || n_classes_with_background < 1 || mask_dim < 1 ||
+        channels_padded % 4 != 0 || used > channels_padded || channels_padded > 2048 || prior_offset < 0 ||
+        (long long)prior_offset + (long long)cells * anchors > n_priors_total || batch > 65535 || kHeadCells * anchors > 256 ||
+        ((uintptr_t)d_raw | (uintptr_t)d_bias) % 16 != 0) {
+        set_error("amos_mask_head_outputs_device: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    if (batch == 0) return AMOS_OK;
+    hipLaunchKernelGGL(k_head_outputs, dim3((cells + kHeadCells - 1) / kHeadCells, batch), dim3(256), (size_t)kHeadCells * channels_padded * sizeof(float),
+                       (hipStream_t)stream, d_raw, d_bias, d_loc, d_conf, d_coef, cells, channels_padded, anchors, n_classes_with_background, mask_dim,
+                       n_priors_total, prior_offset);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }

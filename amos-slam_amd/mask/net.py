@@ -263,6 +263,37 @@ class SharedHead(nn.Module):
             object.__setattr__(self, "merged", merged.requires_grad_(False))
         return self
 
+    def fused_outputs(self, pyramid, n_priors):
+        """All levels' outputs, concatenated, softmax / tanh applied: (loc [B, P, 4], conf [B, P, 81], coef [B, P, 32]), or None when the
+        fused path does not apply (no merged layer, not float32 channels-last on the GPU).  Per level: the upfeature convolution, the
+        merged output convolution WITHOUT its bias, then ONE HIP kernel (amos_mask_head_outputs_device) that adds the bias, takes the
+        softmax and the tanh and writes the level's priors into the three concatenated tensors -- instead of a bias pass, three
+        strided reshape copies per level, three concatenations, a softmax and a tanh pass."""
+        merged = getattr(self, "merged", None)
+        x0 = pyramid[0]
+        if merged is None or not x0.is_cuda or x0.dtype != torch.float32 or torch.is_autocast_enabled() or os.environ.get("AMOS_MASK_FUSED_HEAD", "1") == "0":
+            return None
+        from .. import mask_head_outputs
+        b, dev = x0.shape[0], x0.device
+        n_anchor = self.bbox_layer.out_channels // 4
+        loc = torch.empty((b, n_priors, 4), dtype=torch.float32, device=dev)
+        conf = torch.empty((b, n_priors, NUM_CLASSES), dtype=torch.float32, device=dev)
+        coef = torch.empty((b, n_priors, MASK_DIM), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        off = 0
+        for x in pyramid:
+            u = conv_bias_act(self.upfeature[0], x, True)
+            raw = F.conv2d(u, merged.weight, None, merged.stride, merged.padding)
+            if not raw.is_contiguous(memory_format=torch.channels_last):
+                raw = raw.contiguous(memory_format=torch.channels_last)
+            cells = raw.shape[2] * raw.shape[3]
+            mask_head_outputs(stream, raw.data_ptr(), merged.bias.data_ptr(), loc.data_ptr(), conf.data_ptr(), coef.data_ptr(), b, cells, raw.shape[1],
+                              n_anchor, NUM_CLASSES, MASK_DIM, n_priors, off)
+            off += cells * n_anchor
+        if off != n_priors:
+            raise ValueError("fused_outputs: %d priors written, %d expected" % (off, n_priors))
+        return loc, conf, coef
+
     def forward(self, x):
         b = x.shape[0]
         x = conv_bias_act(self.upfeature[0], x, True)
@@ -358,10 +389,15 @@ class YolactR50(nn.Module):
         p = conv_bias_act(pn[10], conv_bias_act(pn[8], bilinear(p, scale_factor=2, relu=True), True), True)  # pn[6] (upsample) + pn[7] (ReLU) in one pass
         proto = p.permute(0, 2, 3, 1).contiguous()
         head = self.prediction_layers[0]
-        locs, confs, coefs = zip(*(head(p) for p in pyramid))
         sizes = tuple(tuple(p.shape[2:]) for p in pyramid)
         key = (sizes, str(x.device))
         if key not in self._prior_cache:
             self._prior_cache[key] = build_priors(sizes, x.device)
+        priors = self._prior_cache[key]
+        fused = head.fused_outputs(pyramid, priors.shape[0])
+        if fused is not None:
+            loc, conf, coef = fused
+            return {"loc": loc, "conf": conf, "mask": coef, "priors": priors, "proto": proto}
+        locs, confs, coefs = zip(*(head(p) for p in pyramid))
         return {"loc": torch.cat(locs, 1), "conf": F.softmax(torch.cat(confs, 1), -1), "mask": torch.cat(coefs, 1),
-                "priors": self._prior_cache[key], "proto": proto}
+                "priors": priors, "proto": proto}

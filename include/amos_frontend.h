@@ -385,6 +385,15 @@ int amos_mask_class_scores_device(void *stream, const float *d_conf, float *d_sc
 int amos_mask_person_mask_device(void *stream, const float *d_masks, const uint8_t *d_flags, uint8_t *d_out, int batch, int n_det,
                                  int mask_h, int mask_w, int out_h, int out_w);
 
+/* The prediction head's outputs for one pyramid level (yolact.py PredictionModule.forward and the cat / softmax of Yolact.forward):
+ * d_raw [batch][cells][channels_padded] = the merged output convolution WITHOUT bias, channels [anchors x 4 | anchors x
+ * n_classes_with_background | anchors x mask_dim | padding]; the level's priors (cell-major, anchor-minor) start at prior_offset of
+ * d_loc [batch][n_priors_total][4] = raw + bias, d_conf [..][n_classes_with_background] = softmax(raw + bias), d_coef [..][mask_dim]
+ * = tanh(raw + bias).  loc and coef equal PyTorch's bit for bit, conf to float32 rounding (order of the softmax sum). */
+int amos_mask_head_outputs_device(void *stream, const float *d_raw, const float *d_bias, float *d_loc, float *d_conf, float *d_coef,
+                                  int batch, int cells, int channels_padded, int anchors, int n_classes_with_background, int mask_dim,
+                                  int n_priors_total, int prior_offset);
+
 
 /* ---------------------------------------------------------------- SLIC superpixels (8f-2) ---- */
 

@@ -510,3 +510,41 @@ def test_bias_relu_maxpool_kernel_equals_the_torch_ops(mask, gpu_lib):
         torch.cuda.synchronize()
         assert got.shape == want.shape and torch.equal(torch.isnan(got), torch.isnan(want)), (n, c, h, w)
         assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want)), (n, c, h, w, (torch.nan_to_num(got) - torch.nan_to_num(want)).abs().max().item())
+
+
+@pytest.mark.gpu
+def test_fused_head_outputs_equal_the_torch_ops(mask, gpu_lib, monkeypatch):
+    """The prediction head's fused output path (amos_mask_head_outputs_device: bias + reshape + concatenation + softmax / tanh in one
+    kernel per level) against the torch form on the same weights and pyramid: box regressions bit for bit, class scores to float32
+    rounding of the softmax sum, coefficients within 2 ulp (MIOpen may pick another solver for the two calls, hence allclose too)."""
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    torch.manual_seed(16)
+    cl = torch.channels_last
+    head = net_mod.SharedHead().cuda().eval().to(memory_format=cl)
+    head.merge_output_layers()
+    head.merged.to(memory_format=cl)
+    sizes = ((69, 69), (35, 35), (18, 18), (9, 9), (5, 5))
+    pyramid = [torch.randn(2, 256, h, w, device="cuda").contiguous(memory_format=cl) for h, w in sizes]
+    P = sum(h * w * 3 for h, w in sizes)
+    with torch.no_grad():
+        loc, conf, coef = head.fused_outputs(pyramid, P)
+        monkeypatch.setenv("AMOS_MASK_FUSED_HEAD", "0")
+        assert head.fused_outputs(pyramid, P) is None
+        locs, confs, coefs = zip(*(head(p) for p in pyramid))
+        want_loc, want_conf, want_coef = torch.cat(locs, 1), torch.softmax(torch.cat(confs, 1), -1), torch.cat(coefs, 1)
+    assert loc.shape == want_loc.shape == (2, P, 4) and conf.shape == (2, P, 81) and coef.shape == (2, P, 32)
+    assert torch.allclose(loc, want_loc, rtol=1e-5, atol=1e-6) and torch.allclose(coef, want_coef, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(conf, want_conf, rtol=1e-5, atol=1e-8) and torch.allclose(conf.sum(-1), torch.ones_like(conf[..., 0]), atol=1e-5)
+    # the kernel alone on one raw tensor: exact for box / coefficient channels
+    raw = torch.randn(2, 352, 7, 5, device="cuda").contiguous(memory_format=cl)
+    bias = torch.randn(352, device="cuda")
+    l2, c2, m2 = torch.zeros(2, 200, 4, device="cuda"), torch.zeros(2, 200, 81, device="cuda"), torch.zeros(2, 200, 32, device="cuda")
+    gpu_lib.mask_head_outputs(torch.cuda.current_stream().cuda_stream, raw.data_ptr(), bias.data_ptr(), l2.data_ptr(), c2.data_ptr(), m2.data_ptr(), 2, 35, 352, 3,
+                              81, 32, 200, 50)
+    torch.cuda.synchronize()
+    y = (raw + bias.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    assert torch.equal(l2[:, 50:155], y[..., :12].reshape(2, -1, 4)) and torch.equal(m2[:, 50:155], torch.tanh(y[..., 255:351].reshape(2, -1, 32)))
+    assert torch.allclose(c2[:, 50:155], torch.softmax(y[..., 12:255].reshape(2, -1, 81), -1), rtol=1e-6, atol=1e-9)
+    assert float(l2[:, :50].abs().max()) == 0 and float(c2[:, 155:].abs().max()) == 0  # nothing outside the level's priors
+    with pytest.raises(gpu_lib.AmosError):
+        gpu_lib.mask_head_outputs(0, raw.data_ptr(), bias.data_ptr(), l2.data_ptr(), c2.data_ptr(), m2.data_ptr(), 2, 35, 352, 3, 81, 32, 200, 150)
