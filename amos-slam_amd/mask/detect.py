@@ -1,5 +1,7 @@
 """Box decoding and Fast NMS (layers/box_utils.py:268-312, layers/functions/detection.py:27-170):
 top_k 200 per class, IoU 0.5, class-confidence threshold 0.05, at most 100 detections."""
+import os
+
 import torch
 
 NMS_TOP_K = 200
@@ -94,7 +96,16 @@ def detect_batch(pred):
         keep = cls.max(dim=1, keepdim=True)[0] > CONF_THRESH             # [B, 1, P]
         cls = torch.where(keep, cls, torch.full_like(cls, -1.0))
     k = min(NMS_TOP_K, P)
-    scores, idx = cls.topk(k, dim=2)                                 # [B, 80, k], descending
+    if cls.is_cuda and cls.dtype == torch.float32 and cls.is_contiguous() and k <= 256 and os.environ.get("AMOS_MASK_TOPK", "1") != "0":
+        # one HIP kernel, one work-group per (frame, class) row (amos_mask_topk_rows_device): the values torch.topk returns; equal
+        # values come lowest index first (torch leaves their order open)
+        from .. import mask_topk_rows
+        n_cls = cls.shape[1]
+        scores = torch.empty((B, n_cls, k), dtype=torch.float32, device=cls.device)
+        idx = torch.empty((B, n_cls, k), dtype=torch.int64, device=cls.device)
+        mask_topk_rows(torch.cuda.current_stream(cls.device).cuda_stream, cls.data_ptr(), scores.data_ptr(), idx.data_ptr(), B * n_cls, P, k)
+    else:
+        scores, idx = cls.topk(k, dim=2)                             # [B, 80, k], descending
     gather = idx.reshape(B, -1)
     cand_boxes = torch.gather(boxes, 1, gather[..., None].expand(-1, -1, 4)).view(B, -1, k, 4)
     cand_coefs = torch.gather(coef, 1, gather[..., None].expand(-1, -1, coef.shape[-1])).view(B, -1, k, coef.shape[-1])

@@ -394,6 +394,11 @@ int amos_mask_head_outputs_device(void *stream, const float *d_raw, const float 
                                   int batch, int cells, int channels_padded, int anchors, int n_classes_with_background, int mask_dim,
                                   int n_priors_total, int prior_offset);
 
+/* Row-wise top-k, sorted descending (the per-class `scores.topk(200)` of Fast NMS, layers/functions/detection.py:103-111): d_x
+ * [rows][n] -> d_values [rows][k], d_indices [rows][k] (int64, as torch.topk returns them).  Values equal torch.topk's; among equal
+ * values the lower index comes first (torch leaves that order unspecified).  1 <= k <= min(256, n). */
+int amos_mask_topk_rows_device(void *stream, const float *d_x, float *d_values, long long *d_indices, int rows, int n, int k);
+
 
 /* ---------------------------------------------------------------- SLIC superpixels (8f-2) ---- */
 

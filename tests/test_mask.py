@@ -548,3 +548,49 @@ def test_fused_head_outputs_equal_the_torch_ops(mask, gpu_lib, monkeypatch):
     assert float(l2[:, :50].abs().max()) == 0 and float(c2[:, 155:].abs().max()) == 0  # nothing outside the level's priors
     with pytest.raises(gpu_lib.AmosError):
         gpu_lib.mask_head_outputs(0, raw.data_ptr(), bias.data_ptr(), l2.data_ptr(), c2.data_ptr(), m2.data_ptr(), 2, 35, 352, 3, 81, 32, 200, 150)
+
+
+@pytest.mark.gpu
+def test_topk_rows_kernel_against_torch_topk(mask, gpu_lib):
+    """amos_mask_topk_rows_device against torch.topk(sorted=True): the values bit for bit; the indices point at those values, are unique
+    per row, and equal torch's wherever the row's top values are distinct.  Rows of distinct random values, rows that are mostly one
+    value (-1 for priors under the threshold) with a handful / exactly k / more than k real scores, ties across the k-th place (lowest
+    index first), negative values, k = 1, k = n, n not a multiple of 256."""
+    torch.manual_seed(17)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(x, k):
+        rows, n = x.shape
+        v = torch.full((rows, k), float("nan"), device="cuda")
+        i = torch.full((rows, k), -1, dtype=torch.int64, device="cuda")
+        gpu_lib.mask_topk_rows(st, x.data_ptr(), v.data_ptr(), i.data_ptr(), rows, n, k)
+        torch.cuda.synchronize()
+        return v, i
+
+    for rows, n, k in ((64, 19248, 200), (5, 1000, 200), (3, 257, 256), (4, 50, 1), (2, 37, 37)):
+        x = torch.randn(rows, n, device="cuda")
+        v, i = run(x, k)
+        wv, wi = x.topk(k, dim=1)
+        assert torch.equal(v, wv) and torch.equal(i, wi), (rows, n, k)
+    # the detector's rows: -1 everywhere except a few real scores
+    for real in (0, 7, 200, 1500):
+        x = torch.full((6, 19248), -1.0, device="cuda")
+        if real:
+            pos = torch.stack([torch.randperm(19248, device="cuda")[:real] for _ in range(6)])
+            x.scatter_(1, pos, torch.rand(6, real, device="cuda") * 0.9 + 0.05)
+        v, i = run(x, 200)
+        wv, _ = x.topk(200, dim=1)
+        assert torch.equal(v, wv), real
+        assert torch.equal(torch.gather(x, 1, i), v) and all(len(set(r.tolist())) == 200 for r in i.cpu()), real
+        if real < 200:  # the padding: the lowest indices among the -1 entries
+            tail = i[0, real:].cpu().tolist()
+            free = [j for j in range(19248) if x[0, j].item() == -1.0][:200 - real]
+            assert tail == free
+    # ties across the k-th place: lowest index first
+    x = torch.zeros(1, 600, device="cuda")
+    x[0, 100:110] = 2.0
+    x[0, 300:400] = 1.0
+    v, i = run(x, 60)
+    assert v[0].tolist() == [2.0] * 10 + [1.0] * 50 and i[0].tolist() == list(range(100, 110)) + list(range(300, 350))
+    with pytest.raises(gpu_lib.AmosError):
+        run(x, 257)
