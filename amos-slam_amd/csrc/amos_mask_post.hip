@@ -259,8 +259,8 @@ extern "C" {
 
 int amos_mask_class_scores_device(void *stream, const float *d_conf, float *d_scores, int batch, int n_priors, int n_classes_with_background, float threshold)
 {
-    if (!d_conf || !d_scores || batch < 0 || n_priors < 1 || n_classes_with_background < 2 || n_classes_with_background > 512 || batch > 65535) {
-        set_error("amos_mask_class_scores_device: invalid argument");
+    if (!d_conf || !d_scores || batch < 0 || n_priors < 1 || n_classes_with_background < 2 || n_classes_with_background > 200 || batch > 65535) {  // 64 x (classes + 1) floats of LDS
+        set_error("amos_mask_class_scores_device: invalid argument (2 <= classes incl. background <= 200)");
         return AMOS_ERR_INVALID;
     }
     if (batch == 0) return AMOS_OK;
@@ -292,7 +292,8 @@ int amos_mask_head_outputs_device(void *stream, const float *d_raw, const float 
 {
     const long long used = (long long)anchors * (4 + n_classes_with_background + mask_dim);
     if (!d_raw || !d_bias || !d_loc || !d_conf || !d_coef || batch < 0 || cells < 1 || anchors < 1 || n_classes_with_background < 1 || mask_dim < 1 ||
-        channels_padded % 4 != 0 || used > channels_padded || channels_padded > 2048 || prior_offset < 0 ||
+        channels_padded % 4 != 0 || used > channels_padded || channels_padded > 1000 || prior_offset < 0 ||  // 16 x channels floats of LDS
+       
         (long long)prior_offset + (long long)cells * anchors > n_priors_total || batch > 65535 || kHeadCells * anchors > 256 ||
         ((uintptr_t)d_raw | (uintptr_t)d_bias) % 16 != 0) {
         set_error("amos_mask_head_outputs_device: invalid argument");
