@@ -203,6 +203,40 @@ def count_network_flops(torch, engine, batch):
     return total[0] / batch
 
 
+def gemm_kernel_roofline(torch, amos, dev, frames):
+    """The dominant kernel of the mask pass against the fp32 MFMA peak, measured live: amos::k_conv_gemm on the network's largest layer
+    (proto_net[8]: 3 x 3, 256 -> 256 channels at 138 x 138, `frames` frames per launch) through the C ABI, after the timed region (the chip
+    is otherwise idle), HIP events on the stream the kernel is launched on.  FLOPs = 2 x output pixels x cout x 9 x cin."""
+    cl = torch.channels_last
+    cin = cout = 256
+    hw = 138
+    x = torch.randn(frames, cin, hw, hw, device=dev).contiguous(memory_format=cl)
+    w = (torch.randn(cout, cin, 3, 3, device=dev) / 48.0).contiguous(memory_format=cl)
+    b = torch.zeros(cout, device=dev)
+    y = torch.empty(frames, cout, hw, hw, device=dev).contiguous(memory_format=cl)
+    stream = torch.cuda.current_stream(dev)
+
+    def launch():
+        amos.mask_conv(stream.cuda_stream, x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, 3, 3, 1, 1, True)
+
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record(stream)
+    for _ in range(reps):
+        launch()
+    e1.record(stream)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * frames * hw * hw * cout * 9 * cin
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "amos::k_conv_gemm<2, 2, 2, true> (proto_net 3x3 256->256 at 138x138: the largest launch of the pass)", "bound": "mfma",
+            "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+            "flops_per_launch": int(flops), "frames_per_launch": frames, "avg_launch_ms": round(ms, 4),
+            "measured_in": "after the timed region, the kernel alone on the chip, HIP events on the launching stream (10 launches)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -506,6 +540,8 @@ def main():
                                     "note": "convolution FLOPs (2 x MAC, counted from the shapes of one forward) of all frames of a step / the step's wall "
                                             "time, i.e. a lower bound of the convolution kernels' own rate: the step also holds the pre / post-processing, "
                                             "the ORB kernels and the match.  lane_pass_ms = one lane's whole mask pass (events on its stream), lanes overlap."}
+            if args.mask_conv_dtype == "fp32":
+                out["roofline_mask"]["dominant_kernel"] = gemm_kernel_roofline(torch, pkg, torch.device(dev), chunk)
         if em:
             st = em["stage_ms"]
             alg = algorithmic_bytes(lw, lh, em["mean_kp"], W, H)

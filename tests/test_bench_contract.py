@@ -55,6 +55,10 @@ def test_default_run_is_the_baseline_metric_with_the_mask(gpu_lib):
     assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and m["peak"] == 157.3 and 0 < m["frac"] < 1
     assert 1.0e11 < m["flops_per_frame"] < 1.4e11  # YOLACT-R50 at 550 x 550: 59 G multiply-accumulates
     assert d["stage_ms_per_launch"]["mask_pass"] > 0
+    k = m["dominant_kernel"]  # the project's conv GEMM on the largest layer, live
+    assert "k_conv_gemm" in k["kernel"] and k["bound"] == "mfma" and k["peak"] == 157.3 and 0.3 < k["frac"] < 1.0
+    assert abs(k["achieved"] - k["flops_per_launch"] / (k["avg_launch_ms"] * 1e-3) / 1e12) / k["achieved"] < 0.01
+    assert k["flops_per_launch"] == 2 * k["frames_per_launch"] * 138 * 138 * 256 * 9 * 256
 
 
 @pytest.mark.gpu
