@@ -121,6 +121,50 @@ class MaskEngine:
             out[b0:b0 + masks.shape[0]] = masks
         return out
 
+    # ---- one HIP graph for network + detection + mask assembly at a fixed batch: the frame-by-frame caller (Tracking.cc:366 calls
+    # evalImage once per frame) is bound by the ~250 launches of a pass, not by their work (3.5 ms per frame eagerly, tools/mask_latency.py)
+    @torch.no_grad()
+    def capture_graph(self, batch=1):
+        """Capture `network input [batch, 3, 550, 550] -> masks [batch, 480, 640], found [batch]` (the static-shape batch path:
+        detect_batch + person_mask_batch, every kernel on the capturing stream) into a HIP graph and keep it for eval_net_input_graph.
+        MIOpen picks its solvers in the eager warm-up passes before the capture.  Returns self."""
+        if self.device.type != "cuda":
+            raise RuntimeError("capture_graph needs the GPU")
+        self._g_in = torch.zeros((batch, 3, 550, 550), dtype=torch.float32, device=self.device)
+
+        def body():
+            return person_mask_batch(detect_batch(self._forward(self._g_in)), 640, 480)
+
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._g_masks, self._g_found = body()
+        self._graph, self._g_batch = graph, batch
+        return self
+
+    @torch.no_grad()
+    def eval_net_input_graph(self, x):
+        """x: [batch, 3, 550, 550] float32 on the engine's device, batch as captured.  Replays the graph; returns (masks uint8
+        [batch, 480, 640], found bool [batch]) -- the same tensors every call (copy them to keep them)."""
+        if getattr(self, "_graph", None) is None or x.shape[0] != self._g_batch:
+            raise RuntimeError("eval_net_input_graph: call capture_graph(batch=%d) first" % x.shape[0])
+        self._g_in.copy_(x)
+        self._graph.replay()
+        return self._g_masks, self._g_found
+
+    @torch.no_grad()
+    def eval_bgr_graph(self, frames_u8):
+        """[batch, H, W, 3] uint8 BGR frames on the engine's device -> (masks, found) through the HIP pre-processing kernels and the
+        captured graph (the pre-processing runs eagerly: three kernels on its own stream)."""
+        frames = torch.as_tensor(frames_u8, dtype=torch.uint8, device=self.device)
+        return self.eval_net_input_graph(self._preprocess_hip(frames))
+
     @torch.no_grad()
     def eval_bgr_batch(self, frames_u8, chunk=16):
         """frames_u8: [B, H, W, 3] uint8 on the engine's device.  Returns [B, H, W] uint8 masks (zeros where

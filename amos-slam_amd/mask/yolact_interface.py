@@ -44,6 +44,17 @@ def yolact_eval_bgr_bytes(buf, height, width):
     """Entry point of the C++ `yolact` class of this project: the raw BGR frame as bytes; the
     reference's C++ marshalling (resize to 480x640, /255, CHW) runs on the GPU in mask/pre.py."""
     frame = np.frombuffer(buf, np.uint8).reshape(height, width, 3)
+    if os.environ.get("AMOS_MASK_GRAPH", "0") == "1" and model_interface.device.type == "cuda":
+        # frame-by-frame callers: network + detection + mask assembly replayed as ONE captured HIP graph (2.6 instead of 3.5 ms per
+        # frame on MI355X, tools/mask_latency.py; the static-shape batch path of detect.py / post.py, same masks)
+        import torch
+        if getattr(model_interface, "_graph", None) is None or model_interface._g_batch != 1:
+            model_interface.capture_graph(batch=1)
+        masks, found = model_interface.eval_bgr_graph(torch.from_numpy(frame.copy())[None].to(model_interface.device))
+        if not bool(found[0]):
+            raise IndexError("no detection above the score threshold")
+        out = np.ascontiguousarray(masks[0].cpu().numpy())
+        return out, out
     mask = model_interface.eval_bgr(frame.copy())
     if mask is None:
         raise IndexError("no detection above the score threshold")

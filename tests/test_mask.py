@@ -594,3 +594,22 @@ def test_topk_rows_kernel_against_torch_topk(mask, gpu_lib):
     assert v[0].tolist() == [2.0] * 10 + [1.0] * 50 and i[0].tolist() == list(range(100, 110)) + list(range(300, 350))
     with pytest.raises(gpu_lib.AmosError):
         run(x, 257)
+
+
+@pytest.mark.gpu
+def test_mask_pass_as_one_hip_graph_equals_the_eager_pass(mask, gpu_lib):
+    """MaskEngine.capture_graph / eval_bgr_graph: network + detection + mask assembly of a fixed batch replayed as one HIP graph give the
+    masks of the eager pass on different frames (two replays), and refuse another batch size."""
+    torch.manual_seed(18)
+    eng = mask.MaskEngine(device="cuda:0", seed=3).prepare()
+    rng = np.random.default_rng(5)
+    eng.capture_graph(batch=2)
+    for _ in range(2):
+        frames = torch.as_tensor(rng.integers(0, 256, (2, 480, 640, 3), dtype=np.uint8), device="cuda:0")
+        want = eng.eval_bgr_batch(frames, chunk=2)
+        masks, found = eng.eval_bgr_graph(frames)
+        torch.cuda.synchronize()
+        assert masks.shape == (2, 480, 640) and masks.dtype == torch.uint8 and found.shape == (2,)
+        assert torch.equal(torch.where(found[:, None, None], masks, torch.zeros_like(masks)), want)
+    with pytest.raises(RuntimeError):
+        eng.eval_bgr_graph(frames[:1])
