@@ -18,6 +18,7 @@
 // HBM once and from that XCD's L2 afterwards.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/amos_frontend.h"
 #include "amos_common.h"
@@ -292,7 +293,13 @@ int amos_mask_conv_device(void *stream, const float *d_x, const float *d_w, cons
     a.M = (int)M; a.N = cout; a.K = cin;
     a.outW = ow; a.outHW = oh * ow; a.inW = in_w; a.inH = in_h;
     a.stride = stride; a.relu = relu; a.kh = kh; a.kw = kw; a.pad = pad;
-    const bool wide = cout % 128 == 0, taps = kh * kw > 1 || pad > 0;
+    // 128 x 128 tiles unless they would leave the chip short of work: below 1 024 work-groups the 128 x 64 shape (twice as many,
+    // lower per-group efficiency) balances the 256 CUs better -- measured on the 35 x 35 and 18 x 18 layers (tools/conv1x1_probe.py with
+    // AMOS_GEMM_NARROW=1: 1024 -> 256 at 35 x 35 0.212 -> 0.187 ms, 2048 -> 512 at 18 x 18 0.259 -> 0.209 ms; the large layers lose 5 - 10 %).
+    const char *env = getenv("AMOS_GEMM_NARROW");  // "1" / "0" force a shape (experiments)
+    const long long wideGroups = ((M + 127) / 128) * (cout / 128);
+    const bool narrow = env && (env[0] == '0' || env[0] == '1') ? env[0] == '1' : wideGroups < 1024;
+    const bool wide = cout % 128 == 0 && !narrow, taps = kh * kw > 1 || pad > 0;
     const int BM = 128, BN = wide ? 128 : 64;
     a.mTiles = (int)((M + BM - 1) / BM);
     a.nTiles = cout / BN;

@@ -28,8 +28,8 @@ def _gemm_conv(conv, x):
     """Should this convolution run on the project's fp32 MFMA (implicit) GEMM (amos_mask_conv_device: bias, residual and ReLU in its
     epilogue) rather than MIOpen + the epilogue pass?  Measured per shape on MI355X at 32 frames (tools/conv1x1_probe.py,
     tools/conv_gemm_probe.py).  1 x 1: the GEMM wins 1.03 - 1.56 x on every layer whose launch has >= 600
-    work-groups of 128 x 128 outputs; MIOpen's assembly kernels keep the two small K = 2048 layers (0.83 / 0.91 x: 324 / 162 groups leave
-    CUs idle).  3 x 3: 1.02 - 1.04 x on the layers with >= 1024 work-groups, MIOpen ahead on the smaller ones (0.7 - 0.9 x).
+    work-groups (of 128 x 128 outputs, or of 128 x 64 where the library switches to those); MIOpen's assembly kernels keep the
+    2048 -> 256 lateral at 18 x 18 (0.88 x: 324 groups leave CUs idle).  3 x 3: 1.02 - 1.04 x on the layers with >= 1024 work-groups, MIOpen ahead on the smaller ones (0.7 - 0.9 x).
     AMOS_MASK_CONV1X1=0 / 1 and AMOS_MASK_CONV3X3=0 force a side (experiments, tests)."""
     k = conv.kernel_size
     if k[0] != k[1] or conv.padding[0] != conv.padding[1] or conv.dilation != (1, 1) or conv.groups != 1 or conv.stride[0] != conv.stride[1]:
@@ -40,6 +40,8 @@ def _gemm_conv(conv, x):
     s = conv.stride[0]
     m = x.shape[0] * ((x.shape[2] + 2 * conv.padding[0] - k[0]) // s + 1) * ((x.shape[3] + 2 * conv.padding[1] - k[1]) // s + 1)
     groups = ((m + 127) // 128) * (conv.out_channels // (128 if conv.out_channels % 128 == 0 else 64))
+    if groups < 1024 and (k, conv.padding) == ((1, 1), (0, 0)):
+        groups = ((m + 127) // 128) * (conv.out_channels // 64)  # the library then runs 128 x 64 tiles (amos_mask_conv_device)
     if k != (1, 1) or conv.padding != (0, 0):
         return os.environ.get("AMOS_MASK_CONV3X3", "1") != "0" and groups >= 1024 and conv.weight.is_contiguous(memory_format=torch.channels_last)
     mode = os.environ.get("AMOS_MASK_CONV1X1", "auto")

@@ -372,7 +372,8 @@ def test_mfma_conv1x1_against_float64(mask, gpu_lib, monkeypatch):
     c = torch.nn.Conv2d(64, 256, 1)
     assert net_mod._gemm_conv(c, big) and not net_mod._gemm_conv(c, small)
     assert net_mod._gemm_conv(torch.nn.Conv2d(1024, 256, 1), torch.empty(32, 1024, 35, 35, device="meta"))       # 614 work-groups
-    assert not net_mod._gemm_conv(torch.nn.Conv2d(2048, 512, 1), torch.empty(32, 2048, 18, 18, device="meta"))   # 324
+    assert net_mod._gemm_conv(torch.nn.Conv2d(2048, 512, 1), torch.empty(32, 2048, 18, 18, device="meta"))       # 324 wide = 648 narrow
+    assert not net_mod._gemm_conv(torch.nn.Conv2d(2048, 256, 1), torch.empty(32, 2048, 18, 18, device="meta"))   # 324 narrow
     c3 = torch.nn.Conv2d(64, 64, 3, padding=1).to(memory_format=cl)
     assert net_mod._gemm_conv(c3, big) and not net_mod._gemm_conv(c3, small)
     assert not net_mod._gemm_conv(torch.nn.Conv2d(256, 243, 3, padding=1).to(memory_format=cl), torch.empty(32, 256, 69, 69, device="meta"))  # 243 channels
