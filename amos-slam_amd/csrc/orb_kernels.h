@@ -1474,7 +1474,10 @@ __global__ __launch_bounds__(kDescKps * 16) void k_describe(const uint8_t *__res
     int dstIdx = i;
     for (int l = 0; l < (active ? level : 0); l++) dstIdx += cnt[l];
     active = active && dstIdx < g->kpCap;
-    amos_keypoint kp = lvKps[(size_t)frame * g->kpLevelTotal + (active ? slot : 0)];
+    // only the three fields the descriptor needs live through the kernel (the whole 28-byte record kept in registers ended up partly
+    // in scratch memory); lane 0 of the keypoint reads the record again when it writes it out
+    const amos_keypoint *kpSrc = lvKps + (size_t)frame * g->kpLevelTotal + (active ? slot : 0);
+    struct { float x, y, angle; } kp = {kpSrc->x, kpSrc->y, kpSrc->angle};
     if (!active) { kp.x = kp.y = (float)(kEdge + kDescR); kp.angle = 0.f; }
     const int stride = lg.stride;
     const uint8_t *corner = level_origin(blur, g, frame, active ? level : 0) + (ptrdiff_t)(__float2int_rn(kp.y) - kDescR) * stride +
@@ -1511,11 +1514,12 @@ __global__ __launch_bounds__(kDescKps * 16) void k_describe(const uint8_t *__res
     if (active) {
         reinterpret_cast<uint16_t *>(outDesc + ((size_t)frame * g->kpCap + dstIdx) * 32)[j] = (uint16_t)myword;
         if (j == 0) {
+            amos_keypoint o = *kpSrc;
             if (level != 0) {  // keypoint->pt *= scale, ORBextractor.cc:1804-1813
-                kp.x = __fmul_rn(kp.x, lg.scale);
-                kp.y = __fmul_rn(kp.y, lg.scale);
+                o.x = __fmul_rn(o.x, lg.scale);
+                o.y = __fmul_rn(o.y, lg.scale);
             }
-            outKps[(size_t)frame * g->kpCap + dstIdx] = kp;
+            outKps[(size_t)frame * g->kpCap + dstIdx] = o;
         }
     }
 }
