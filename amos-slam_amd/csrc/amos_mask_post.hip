@@ -97,30 +97,62 @@ __global__ __launch_bounds__(256) void k_head_outputs(const float *__restrict__ 
         *reinterpret_cast<float4 *>(sh + e) = v;
     }
     __syncthreads();
-    if ((int)threadIdx.x < nc * A) {  // one thread per prior: softmax over its 1 + C class values, in place
+    // softmax over each prior's 1 + C class values, in place.  The maximum and the sum are taken by ONE thread per prior (sequential
+    // order: the same bits whatever the work-group shape); the exponentials and the divisions by all threads.  The element loops walk
+    // (cell, offset) pairs incrementally: an integer division per element cost more than the arithmetic it indexed.
+    __shared__ float sMax[256], sSum[256];
+#define AMOS_HEAD_FOREACH(n, body)                                                             \
+    {                                                                                          \
+        const int stepCell = 256 / (n), stepR = 256 % (n);                                     \
+        int cell = (int)threadIdx.x / (n), r = (int)threadIdx.x - cell * (n);                  \
+        for (int e = threadIdx.x; e < nc * (n); e += 256) {                                    \
+            body;                                                                              \
+            cell += stepCell;                                                                  \
+            r += stepR;                                                                        \
+            if (r >= (n)) { r -= (n); cell++; }                                                \
+        }                                                                                      \
+    }
+    if ((int)threadIdx.x < nc * A) {
         const int cell = threadIdx.x / A, a = threadIdx.x - cell * A;
-        float *v = sh + cell * cpad + nLoc + a * C1;
+        const float *v = sh + cell * cpad + nLoc + a * C1;
         float m = v[0];
         for (int c = 1; c < C1; c++) m = fmaxf(m, v[c]);
-        float sum = 0.f;
-        for (int c = 0; c < C1; c++) {
-            const float e = expf(__fsub_rn(v[c], m));
-            v[c] = e;
-            sum = __fadd_rn(sum, e);
-        }
-        for (int c = 0; c < C1; c++) v[c] = v[c] / sum;
+        sMax[threadIdx.x] = m;
     }
-    for (int e = threadIdx.x; e < nc * nCoef; e += 256) {
-        const int cell = e / nCoef, k = e - cell * nCoef;
-        float *v = sh + cell * cpad + nLoc + nConf + k;
+    __syncthreads();
+    const float invC1 = 1.f / (float)C1;
+    AMOS_HEAD_FOREACH(nConf, {
+        float *v = sh + cell * cpad + nLoc + r;
+        int a = (int)((float)r * invC1);  // r / C1 for r < A * C1 <= a few hundred: the float quotient is off by at most one
+        a -= a * C1 > r ? 1 : 0;
+        a += (a + 1) * C1 <= r ? 1 : 0;
+        *v = expf(__fsub_rn(*v, sMax[cell * A + a]));
+    })
+    AMOS_HEAD_FOREACH(nCoef, {
+        float *v = sh + cell * cpad + nLoc + nConf + r;
         *v = tanhf(*v);
+    })
+    __syncthreads();
+    if ((int)threadIdx.x < nc * A) {
+        const int cell = threadIdx.x / A, a = threadIdx.x - cell * A;
+        const float *v = sh + cell * cpad + nLoc + a * C1;
+        float sum = 0.f;
+        for (int c = 0; c < C1; c++) sum = __fadd_rn(sum, v[c]);
+        sSum[threadIdx.x] = sum;
     }
     __syncthreads();
     const size_t prior0 = (size_t)b * P + pOff + (size_t)c0 * A;  // first prior of this work-group
-    for (int e = threadIdx.x; e < nc * nLoc; e += 256) loc[prior0 * 4 + e] = sh[(e / nLoc) * cpad + e % nLoc];
-    for (int e = threadIdx.x; e < nc * nConf; e += 256) conf[prior0 * C1 + e] = sh[(e / nConf) * cpad + nLoc + e % nConf];
-    for (int e = threadIdx.x; e < nc * nCoef; e += 256) coef[prior0 * D + e] = sh[(e / nCoef) * cpad + nLoc + nConf + e % nCoef];
+    AMOS_HEAD_FOREACH(nLoc, loc[prior0 * 4 + e] = sh[cell * cpad + r])
+    AMOS_HEAD_FOREACH(nConf, {
+        int a = (int)((float)r * invC1);
+        a -= a * C1 > r ? 1 : 0;
+        a += (a + 1) * C1 <= r ? 1 : 0;
+        conf[prior0 * C1 + e] = sh[cell * cpad + nLoc + r] / sSum[cell * A + a];
+    })
+    AMOS_HEAD_FOREACH(nCoef, coef[prior0 * D + e] = sh[cell * cpad + nLoc + nConf + r])
+#undef AMOS_HEAD_FOREACH
 }
+
 
 // Row-wise top-k, sorted descending (the `scores.topk(200)` per class of Fast NMS, layers/functions/detection.py:103-111 as
 // detect_batch restates it): one work-group per row maps the values to order-preserving integer keys, finds the k-th largest key
