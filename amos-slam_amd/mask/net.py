@@ -30,7 +30,7 @@ def _gemm_conv(conv, x):
     tools/conv_gemm_probe.py).  1 x 1: the GEMM wins 1.03 - 1.56 x on every layer whose launch has >= 600
     work-groups (of 128 x 128 outputs, or of 128 x 64 where the library switches to those); MIOpen's assembly kernels keep the
     2048 -> 256 lateral at 18 x 18 (0.88 x: 324 groups leave CUs idle).  3 x 3: 1.02 - 1.04 x on the layers with >= 1024 work-groups, MIOpen ahead on the smaller ones (0.7 - 0.9 x).
-    AMOS_MASK_CONV1X1=0 / 1 and AMOS_MASK_CONV3X3=0 force a side (experiments, tests)."""
+    AMOS_MASK_CONV1X1=0 / 1 and AMOS_MASK_CONV3X3=0 / 2 force a side (experiments, tests)."""
     k = conv.kernel_size
     if k[0] != k[1] or conv.padding[0] != conv.padding[1] or conv.dilation != (1, 1) or conv.groups != 1 or conv.stride[0] != conv.stride[1]:
         return False
@@ -43,7 +43,8 @@ def _gemm_conv(conv, x):
     if groups < 1024 and (k, conv.padding) == ((1, 1), (0, 0)):
         groups = ((m + 127) // 128) * (conv.out_channels // 64)  # the library then runs 128 x 64 tiles (amos_mask_conv_device)
     if k != (1, 1) or conv.padding != (0, 0):
-        return os.environ.get("AMOS_MASK_CONV3X3", "1") != "0" and groups >= 1024 and conv.weight.is_contiguous(memory_format=torch.channels_last)
+        mode3 = os.environ.get("AMOS_MASK_CONV3X3", "1")  # "0" never, "1" by the rule, "2" wherever the kernel applies (tests)
+        return mode3 != "0" and (groups >= 1024 or mode3 == "2") and conv.weight.is_contiguous(memory_format=torch.channels_last)
     mode = os.environ.get("AMOS_MASK_CONV1X1", "auto")
     if mode in ("0", "1"):
         return mode == "1"

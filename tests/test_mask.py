@@ -202,6 +202,25 @@ def test_network_with_folded_batch_norms_vs_reference_gpu(mask, gpu_lib):
 
 
 @pytest.mark.gpu
+def test_network_on_the_project_gemm_vs_reference_gpu(mask, gpu_lib, monkeypatch):
+    """The golden tensors again with EVERY convolution the project's MFMA GEMM can take forced onto it (at one frame the automatic
+    rule leaves them to MIOpen): same tolerances, same person-mask IoU bar."""
+    monkeypatch.setenv("AMOS_MASK_CONV1X1", "1")
+    monkeypatch.setenv("AMOS_MASK_CONV3X3", "2")
+    calls = []
+    real = gpu_lib.mask_conv
+
+    def counting(*a):
+        calls.append(a[9:15])  # cin, cout, kh, kw, stride, pad
+        return real(*a)
+
+    monkeypatch.setattr(gpu_lib, "mask_conv", counting)
+    assert _run(mask, "cuda", 5e-3, 5e-3, fold=True) >= 1 - 1e-3
+    kinds = {(c[2], c[4]) for c in calls}
+    assert len(calls) >= 60 and {(1, 1), (1, 2), (3, 1), (3, 2)} <= kinds, (len(calls), kinds)  # 1x1 and 3x3, strides 1 and 2
+
+
+@pytest.mark.gpu
 def test_engine_end_to_end_gpu(mask, gpu_lib):
     eng = _engine(mask, "cuda:0")
     m = eng.eval_bgr(_frame())
