@@ -117,7 +117,7 @@ class MaskEngine:
         out = torch.zeros((B, height, width), dtype=torch.uint8, device=self.device)
         for b0 in range(0, B, chunk):
             pred = self._forward(x[b0:b0 + chunk])
-            masks, _found = person_mask_batch(detect_batch(pred), 640, 480)
+            masks, _found = person_mask_batch(detect_batch(pred), width, height)
             out[b0:b0 + masks.shape[0]] = masks
         return out
 

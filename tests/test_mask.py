@@ -9,8 +9,12 @@ import numpy as np
 import pytest
 import torch
 
+import mask_cases
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G = np.load(os.path.join(ROOT, "tests", "golden", "yolact_seed0.npz"))
+GOLD = {c: np.load(os.path.join(ROOT, "tests", "golden", f"yolact_{c}.npz")) for c in mask_cases.CASES}
+CASES = list(mask_cases.CASES)   # six (frame, weight seed) cases: a checkerboard, the reference's two sample inputs, a synthetic scene; seeds 0 / 1 / 3
+G = GOLD["seed0"]
 SUB = int(G["sub"][0])
 
 
@@ -19,32 +23,35 @@ def mask(pkg):
     return importlib.import_module("amos_slam_amd.mask")
 
 
-def _frame():
-    rng = np.random.default_rng(int(G["frame_seed"][0]))
-    yy, xx = np.mgrid[0:480, 0:640]
-    return (rng.integers(0, 60, (480, 640, 3)) + 90 * ((xx // 80 + yy // 60) % 2)[..., None] + np.array([10, 40, 70])).astype(np.uint8)
+def _frame(case="seed0"):
+    import zlib
+    f = mask_cases.frame(case)
+    assert zlib.crc32(f.tobytes()) == int(GOLD[case]["frame_crc"][0]), "the case's frame is not the one the fixture was made from"
+    return f
 
 
-def _engine(mask, device):
-    eng = mask.MaskEngine(device=device, seed=0)
-    with torch.no_grad():  # same bias tweak as the fixture generator
-        head = eng.net.prediction_layers[0].conf_layer.bias
-        b = head.detach().cpu().view(3, 81).clone()
-        b[:, 1] += 5.0
-        b[1, 3] += 5.5
-        head.copy_(b.view(-1).to(head.device))
+def _engine(mask, device, case="seed0"):
+    eng = mask.MaskEngine(device=device, seed=mask_cases.weight_seed(case))
+    mask_cases.bias_class_head(eng.net, case)   # same bias tweak as the fixture generator
     return eng
+
+
+def _iou(got, want):
+    """Intersection over union of two boolean masks; two empty masks agree (the cars-only case)."""
+    union = int((got | want).sum())
+    return 1.0 if union == 0 else int((got & want).sum()) / union
 
 
 def _sub(t):
     return t.detach().float().cpu().reshape(-1)[::SUB].numpy()
 
 
-def _run(mask, device, rtol, atol, fold=False):
-    eng = _engine(mask, device)
+def _run(mask, device, rtol, atol, fold=False, case="seed0"):
+    G = GOLD[case]
+    eng = _engine(mask, device, case)
     if fold:
         eng.prepare()
-    frame = torch.from_numpy(_frame()).to(device)
+    frame = torch.from_numpy(_frame(case)).to(device)
     chw = mask.cxx_marshalling(frame)
     img = mask.resize_f32_cv(chw.permute(1, 2, 0) * 255, 640, 480)
     batch = mask.fast_base_transform(img)
@@ -76,7 +83,7 @@ def _run(mask, device, rtol, atol, fold=False):
     person = mask.person_mask(det, 640, 480).cpu().numpy()
     want = np.unpackbits(G["person_mask_bits"])[:480 * 640].reshape(480, 640).astype(bool)
     got = person > 0
-    iou = (got & want).sum() / max((got | want).sum(), 1)
+    iou = _iou(got, want)
     assert iou >= 1 - 1e-3, iou
     assert set(np.unique(person)) <= set(G["person_mask_values"].tolist()) | {0}
     return iou
@@ -116,13 +123,15 @@ def test_fast_nms_tie_and_threshold_rules(mask):
     assert c.tolist() == [1, 0, 0, 1] and [round(v, 2) for v in s.tolist()] == [0.95, 0.9, 0.7, 0.1]
 
 
-def test_network_vs_reference_cpu(mask):
-    assert _run(mask, "cpu", 2e-4, 2e-5) >= 1 - 1e-3
+@pytest.mark.parametrize("case", CASES)
+def test_network_vs_reference_cpu(mask, case):
+    assert _run(mask, "cpu", 2e-4, 2e-5, case=case) >= 1 - 1e-3
 
 
-def test_network_with_folded_batch_norms_vs_reference_cpu(mask):
+@pytest.mark.parametrize("case", CASES)
+def test_network_with_folded_batch_norms_vs_reference_cpu(mask, case):
     """MaskEngine.prepare(): the inference form bench.py and the C++ class run."""
-    assert _run(mask, "cpu", 2e-4, 2e-5, fold=True) >= 1 - 1e-3
+    assert _run(mask, "cpu", 2e-4, 2e-5, fold=True, case=case) >= 1 - 1e-3
 
 
 def test_folding_batch_norms_with_nontrivial_statistics(mask):
@@ -192,17 +201,20 @@ def test_no_detection_returns_none(mask):
 
 
 @pytest.mark.gpu
-def test_network_vs_reference_gpu(mask, gpu_lib):
-    assert _run(mask, "cuda:0", 5e-3, 5e-3) >= 1 - 1e-3
+@pytest.mark.parametrize("case", CASES)
+def test_network_vs_reference_gpu(mask, gpu_lib, case):
+    assert _run(mask, "cuda:0", 5e-3, 5e-3, case=case) >= 1 - 1e-3
 
 
 @pytest.mark.gpu
-def test_network_with_folded_batch_norms_vs_reference_gpu(mask, gpu_lib):
-    assert _run(mask, "cuda:0", 5e-3, 5e-3, fold=True) >= 1 - 1e-3
+@pytest.mark.parametrize("case", CASES)
+def test_network_with_folded_batch_norms_vs_reference_gpu(mask, gpu_lib, case):
+    assert _run(mask, "cuda:0", 5e-3, 5e-3, fold=True, case=case) >= 1 - 1e-3
 
 
 @pytest.mark.gpu
-def test_network_on_the_project_gemm_vs_reference_gpu(mask, gpu_lib, monkeypatch):
+@pytest.mark.parametrize("case", CASES)
+def test_network_on_the_project_gemm_vs_reference_gpu(mask, gpu_lib, monkeypatch, case):
     """The golden tensors again with EVERY convolution the project's MFMA GEMM can take forced onto it (at one frame the automatic
     rule leaves them to MIOpen): same tolerances, same person-mask IoU bar."""
     monkeypatch.setenv("AMOS_MASK_CONV1X1", "1")
@@ -215,19 +227,20 @@ def test_network_on_the_project_gemm_vs_reference_gpu(mask, gpu_lib, monkeypatch
         return real(*a)
 
     monkeypatch.setattr(gpu_lib, "mask_conv", counting)
-    assert _run(mask, "cuda", 5e-3, 5e-3, fold=True) >= 1 - 1e-3
+    assert _run(mask, "cuda", 5e-3, 5e-3, fold=True, case=case) >= 1 - 1e-3
     kinds = {(c[2], c[4]) for c in calls}
     assert len(calls) >= 60 and {(1, 1), (1, 2), (3, 1), (3, 2)} <= kinds, (len(calls), kinds)  # 1x1 and 3x3, strides 1 and 2
 
 
 @pytest.mark.gpu
-def test_engine_end_to_end_gpu(mask, gpu_lib):
-    eng = _engine(mask, "cuda:0")
-    m = eng.eval_bgr(_frame())
+@pytest.mark.parametrize("case", CASES)
+def test_engine_end_to_end_gpu(mask, gpu_lib, case):
+    eng = _engine(mask, "cuda:0", case)
+    m = eng.eval_bgr(_frame(case))
     assert m.shape == (480, 640) and m.dtype == torch.uint8
-    want = np.unpackbits(G["person_mask_bits"])[:480 * 640].reshape(480, 640).astype(bool)
+    want = np.unpackbits(GOLD[case]["person_mask_bits"])[:480 * 640].reshape(480, 640).astype(bool)
     got = m.cpu().numpy() > 0
-    assert (got & want).sum() / max((got | want).sum(), 1) >= 1 - 1e-3
+    assert _iou(got, want) >= 1 - 1e-3
 
 
 @pytest.mark.gpu

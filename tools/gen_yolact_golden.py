@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/yolact_*.npz by running the REFERENCE's own Python network code
+"""Writes tests/golden/yolact_<case>.npz (cases: tests/mask_cases.py) by running the REFERENCE's own Python network code
 (/root/reference/src/python: backbone.py, yolact.py, layers/) on CPU with seeded random weights.
 
 Only runnable in the build container (the reference never travels to the GPU box); the fixtures
@@ -14,6 +14,7 @@ import importlib.util
 import os
 import sys
 import types
+import zlib
 
 import numpy as np
 import torch
@@ -21,7 +22,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/src/python"
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as entry  # noqa: E402
+import mask_cases as cases  # noqa: E402
 
 entry.load_package()
 mask = importlib.import_module("amos_slam_amd.mask")
@@ -67,17 +70,14 @@ def sub(t):
     return t.detach().reshape(-1)[::SUB].numpy().copy()
 
 
-def biased_engine():
-    eng = mask.MaskEngine(device="cpu", seed=0)
-    with torch.no_grad():  # random weights never reach the 0.05 class threshold: bias two classes up
-        b = eng.net.prediction_layers[0].conf_layer.bias.view(3, 81)
-        b[:, 1] += 5.0   # person on every anchor
-        b[1, 3] += 5.5   # car on the second anchor
+def biased_engine(case):
+    eng = mask.MaskEngine(device="cpu", seed=cases.weight_seed(case))
+    cases.bias_class_head(eng.net, case)
     return eng
 
 
-def main():
-    eng = biased_engine()
+def run_case(case):
+    eng = biased_engine(case)
     ref = ref_yolact.Yolact()
     mine_sd = eng.net.state_dict()
     ref_sd = ref.state_dict()
@@ -88,9 +88,7 @@ def main():
     ref.detect.use_fast_nms = True
     ref.detect.use_cross_class_nms = False
 
-    rng = np.random.default_rng(42)
-    yy, xx = np.mgrid[0:480, 0:640]
-    frame = (rng.integers(0, 60, (480, 640, 3)) + 90 * ((xx // 80 + yy // 60) % 2)[..., None] + np.array([10, 40, 70])).astype(np.uint8)
+    frame = cases.frame(case)
     chw = mask.cxx_marshalling(torch.from_numpy(frame))
     img = mask.resize_f32_cv(chw.permute(1, 2, 0) * 255, 640, 480)
     batch = mask.fast_base_transform(img)
@@ -115,15 +113,20 @@ def main():
         person_u8 = (person * 255).byte().numpy()
     assert det_copy["score"].numel() > 20
     np.savez_compressed(
-        os.path.join(ROOT, "tests", "golden", "yolact_seed0.npz"),
-        keys=np.array(sorted(ref_sd.keys())), frame_seed=np.array([42]), sub=np.array([SUB]),
+        os.path.join(ROOT, "tests", "golden", f"yolact_{case}.npz"),
+        keys=np.array(sorted(ref_sd.keys())), sub=np.array([SUB]), frame_crc=np.array([zlib.crc32(frame.tobytes())]),
         batch=sub(batch), c3=sub(outs[1]), c5=sub(outs[3]), p3=sub(fpn_outs[0]), p7=sub(fpn_outs[4]),
         det_box=det_copy["box"].numpy(), det_class=det_copy["class"].numpy(), det_score=det_copy["score"].numpy(),
         det_mask=det_copy["mask"].numpy(), proto=sub(det_copy["proto"]),
         post_classes=classes.numpy(), post_scores=scores.numpy(), post_mask_area=masks.sum((1, 2)).numpy(),
         person_mask_bits=np.packbits(person_u8 > 0), person_mask_values=np.unique(person_u8))
-    print("detections", det_copy["score"].numel(), "after 0.15:", len(scores), "person px:", int((person_u8 > 0).sum()),
-          "values", np.unique(person_u8))
+    print(case, "detections", det_copy["score"].numel(), "after 0.15:", len(scores), "classes", sorted(set(classes.tolist())),
+          "person px:", int((person_u8 > 0).sum()), "values", np.unique(person_u8))
+
+
+def main():
+    for case in (sys.argv[1:] or list(cases.CASES)):
+        run_case(case)
 
 
 if __name__ == "__main__":
