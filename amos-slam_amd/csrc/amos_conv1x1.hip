@@ -18,6 +18,7 @@
 // HBM once and from that XCD's L2 afterwards.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "../../include/amos_frontend.h"
@@ -268,7 +269,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
 using namespace amos;
 
+// 128 x 128 tiles unless they would leave the chip short of work: below 1 024 work-groups the 128 x 64 shape (twice as many,
+// lower per-group efficiency) balances the 256 CUs better -- measured on the 35 x 35 and 18 x 18 layers (tools/conv1x1_probe.py with
+// the narrow shape forced: 1024 -> 256 at 35 x 35 0.212 -> 0.187 ms, 2048 -> 512 at 18 x 18 0.259 -> 0.209 ms; the large layers lose 5 - 10 %).
+// amos_mask_conv_tile_mode forces a shape (tests, experiments); AMOS_GEMM_NARROW=0 / 1 in the environment is its initial value, read once.
+static int g_gemm_tile_mode = -2;  // -2: environment not read yet; -1 automatic; 0 wide; 1 narrow
+
+static int gemm_tile_mode()
+{
+    if (g_gemm_tile_mode == -2) {
+        const char *env = getenv("AMOS_GEMM_NARROW");
+        g_gemm_tile_mode = env && (env[0] == '0' || env[0] == '1') ? env[0] - '0' : -1;
+    }
+    return g_gemm_tile_mode;
+}
+
+static bool gemm_wide_tiles(long long M, int cout)
+{
+    const int mode = gemm_tile_mode();
+    const long long wideGroups = ((M + 127) / 128) * (cout / 128);
+    const bool narrow = mode >= 0 ? mode == 1 : wideGroups < 1024;
+    return cout % 128 == 0 && !narrow;
+}
+
 extern "C" {
+
+int amos_mask_conv_tile_mode(int mode)
+{
+    const int before = gemm_tile_mode();
+    if (mode >= -1 && mode <= 1) g_gemm_tile_mode = mode;
+    return before;
+}
+
+// the kernel amos_mask_conv_device launches for this shape, as rocprofv3 names it
+int amos_mask_conv_kernel_name(int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride, int pad, char *name, int name_len)
+{
+    if (!name || name_len < 48 || batch < 1 || amos_mask_conv_supported(cin, cout, kh, kw, stride, pad) != AMOS_OK) {
+        set_error("amos_mask_conv_kernel_name: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    const int oh = (in_h + 2 * pad - kh) / stride + 1, ow = (in_w + 2 * pad - kw) / stride + 1;
+    const bool wide = gemm_wide_tiles((long long)batch * oh * ow, cout), taps = kh * kw > 1 || pad > 0;
+    snprintf(name, (size_t)name_len, "amos::k_conv_gemm<%s, %s>", wide ? "2, 2, 2" : "4, 1, 1", taps ? "true" : "false");
+    return AMOS_OK;
+}
 
 // 0 = this shape is served by amos_mask_conv_device, otherwise AMOS_ERR_INVALID (the caller keeps its library convolution)
 int amos_mask_conv_supported(int cin, int cout, int kh, int kw, int stride, int pad)
@@ -293,13 +337,7 @@ int amos_mask_conv_device(void *stream, const float *d_x, const float *d_w, cons
     a.M = (int)M; a.N = cout; a.K = cin;
     a.outW = ow; a.outHW = oh * ow; a.inW = in_w; a.inH = in_h;
     a.stride = stride; a.relu = relu; a.kh = kh; a.kw = kw; a.pad = pad;
-    // 128 x 128 tiles unless they would leave the chip short of work: below 1 024 work-groups the 128 x 64 shape (twice as many,
-    // lower per-group efficiency) balances the 256 CUs better -- measured on the 35 x 35 and 18 x 18 layers (tools/conv1x1_probe.py with
-    // AMOS_GEMM_NARROW=1: 1024 -> 256 at 35 x 35 0.212 -> 0.187 ms, 2048 -> 512 at 18 x 18 0.259 -> 0.209 ms; the large layers lose 5 - 10 %).
-    const char *env = getenv("AMOS_GEMM_NARROW");  // "1" / "0" force a shape (experiments)
-    const long long wideGroups = ((M + 127) / 128) * (cout / 128);
-    const bool narrow = env && (env[0] == '0' || env[0] == '1') ? env[0] == '1' : wideGroups < 1024;
-    const bool wide = cout % 128 == 0 && !narrow, taps = kh * kw > 1 || pad > 0;
+    const bool wide = gemm_wide_tiles(M, cout), taps = kh * kw > 1 || pad > 0;
     const int BM = 128, BN = wide ? 128 : 64;
     a.mTiles = (int)((M + BM - 1) / BM);
     a.nTiles = cout / BN;

@@ -273,7 +273,12 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
     g.kpCap = kpOff;
     g.blurItems = blurOff;
     // whole 16-byte pieces; + 8: the last 8-pixel group reads one dword past tw + 6.  One of the two strides k_fast_cells is compiled for.
-    g.fastTileStrideDw = ((maxTw + 7 + 8 + 15) >> 4) * 4 <= 16 ? 16 : 20;
+    const int fastStrideNeeded = ((maxTw + 7 + 8 + 15) >> 4) * 4;
+    if (fastStrideNeeded > 20) {  // a cell wider than the LDS tile rows k_fast_cells exists for: fail here rather than overrun the tile
+        set_error("build_geometry: FAST cell of %d pixels needs %d dwords per tile row, k_fast_cells is compiled for 16 and 20", maxTw, fastStrideNeeded);
+        return AMOS_ERR_INVALID;
+    }
+    g.fastTileStrideDw = fastStrideNeeded <= 16 ? 16 : 20;
     g.fastTileRows = maxTh + 6;
     g.fastMapRows = maxTh + 2;
     g.fastKeptCap = ((maxTw + 1) / 2) * ((maxTh + 1) / 2);

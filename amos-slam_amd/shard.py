@@ -13,10 +13,17 @@ def rank_info():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend, device=None):
-    """Joins the process group when WORLD_SIZE > 1; returns (rank, world)."""
+def launched():
+    """True under a launcher (torch.distributed.run exports RANK, WORLD_SIZE and the rendezvous address, also for one rank)."""
+    return all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+
+
+def init(backend, device=None, force=False):
+    """Joins the process group when WORLD_SIZE > 1, and also at world size 1 when a launcher started this process (or
+    force=True): a one-rank RCCL group runs the same barrier / all_reduce / all_gather code as the N-rank job.
+    Returns (rank, world)."""
     rank, world, _ = rank_info()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force or launched()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         kwargs = {"device_id": device} if (device is not None and backend == "nccl") else {}

@@ -76,9 +76,19 @@ def algorithmic_bytes(level_w, level_h, n_kp, width, height):
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline
-def _oracle_stream_run(ob, synth, cfg, stream, n, barrier=None):
+def _source_frames(synth, cfg, source, n):
+    """n gray frames of a frame source: ("synth", stream) or ("tum", root, sequence, associations, first frame)."""
+    if source[0] == "tum":
+        import importlib
+        tum = importlib.import_module("amos_slam_amd.tum")
+        seq = tum.load_sequence(source[1], source[2], n, associations=source[3], start=source[4])
+        return [tum.bgr_to_gray(f) for f in seq["bgr"]]
+    return [synth.frame(source[1], k, cfg["height"], cfg["width"]) for k in range(n)]
+
+
+def _oracle_stream_run(ob, synth, cfg, source, n, barrier=None):
     orc = ob.Oracle(n_features=cfg["n_features"], n_levels=cfg["n_levels"])
-    frames = [synth.frame(stream, k, cfg["height"], cfg["width"]) for k in range(n + 1)]
+    frames = _source_frames(synth, cfg, source, n + 1)
     if barrier is not None:
         barrier.wait()
     t0 = time.perf_counter()
@@ -90,17 +100,18 @@ def _oracle_stream_run(ob, synth, cfg, stream, n, barrier=None):
     return time.perf_counter() - t0
 
 
-def cpu_baseline_one_thread(synth, cfg, n_sample):
+def cpu_baseline_one_thread(synth, cfg, n_sample, source=("synth", 0)):
     """The oracle (CPU restatement of src/ORBextractor.cc + ORBmatcher.cc, 1 thread) on a bounded
     sample of the same workload.  Checker only: it is never the thing shipped or measured as GPU."""
     import oracle_binding as ob
-    dt = _oracle_stream_run(ob, synth, cfg, 0, n_sample)
+    dt = _oracle_stream_run(ob, synth, cfg, source, n_sample)
+    what = "the same synthetic stream" if source[0] == "synth" else f"the same TUM sequence ({source[2]})"
     return {"value": round(n_sample / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n_sample} frames of the same synthetic stream: oracle extract + N x N best-2 match, 1 thread"}
+            "sample": f"{n_sample} frames of {what}: oracle extract + N x N best-2 match, 1 thread"}
 
 
-def _cpu_worker(root, cfg, stream, n, barrier, q):
-    """One worker process of the all-cores CPU baseline: frames of its own synthetic stream."""
+def _cpu_worker(root, cfg, source, n, barrier, q):
+    """One worker process of the all-cores CPU baseline: frames of its own synthetic stream (or its own stretch of the sequence)."""
     sys.path.insert(0, root)
     sys.path.insert(0, os.path.join(root, "tests"))
     import importlib
@@ -108,25 +119,61 @@ def _cpu_worker(root, cfg, stream, n, barrier, q):
     entry.load_package()
     synth = importlib.import_module("amos_slam_amd.synth")
     import oracle_binding as ob
-    q.put(_oracle_stream_run(ob, synth, cfg, stream, n, barrier))
+    q.put(_oracle_stream_run(ob, synth, cfg, source, n, barrier))
 
 
-def cpu_baseline_all_cores(cfg, workers, n_per_worker):
+def granted_cores():
+    """(cores this process may run on, cgroup CPU quota in cores or None): the affinity mask, and cpu.max of cgroup v2 /
+    cfs_quota_us of v1 when a quota is set (a quota below the mask means that many cores' worth of time, whatever the mask shows)."""
+    granted = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return granted, quota
+
+
+def all_cores_worker_count():
+    """Worker processes of the all-cores CPU baseline: every granted core (north_star: "all host cores stated"), held back only by a
+    cgroup quota (more runnable processes than quota just take turns) and by memory (~0.25 GiB per worker: interpreter, numpy, frames)."""
+    granted, quota = granted_cores()
+    workers = granted if quota is None else max(1, min(granted, int(quota + 0.5)))
+    try:
+        avail_kb = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:"))
+        workers = max(1, min(workers, int(avail_kb / (256 * 1024) * 0.5)))
+    except Exception:
+        pass
+    return workers
+
+
+def cpu_baseline_all_cores(cfg, workers, n_per_worker, tum_source=None):
     """The same oracle on `workers` processes, one frame stream per process, started together (the reference
     extractor is single-threaded per frame, so all cores = one frame per core)."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     barrier, q = ctx.Barrier(workers), ctx.Queue()
     small = {k: cfg[k] for k in ("n_features", "n_levels", "height", "width")}
-    procs = [ctx.Process(target=_cpu_worker, args=(ROOT, small, 100 + w, n_per_worker, barrier, q)) for w in range(workers)]
+    sources = [(("synth", 100 + w) if tum_source is None else tum_source[:4] + (tum_source[4] + w * n_per_worker,)) for w in range(workers)]
+    procs = [ctx.Process(target=_cpu_worker, args=(ROOT, small, sources[w], n_per_worker, barrier, q)) for w in range(workers)]
     for p in procs:
         p.start()
-    times = [q.get(timeout=600) for _ in procs]
+    times = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     wall = max(times)  # all workers leave the barrier together: the slowest one is the wall time
+    what = f"{workers} synthetic streams" if tum_source is None else f"consecutive stretches of the TUM sequence {tum_source[2]}"
     return {"value": round(workers * n_per_worker / wall, 2), "unit": "frames/s", "cores": workers, "kind": "port",
-            "sample": f"{workers} processes x {n_per_worker} frames of {workers} synthetic streams, started together; "
+            "per_process_frames_per_s": [round(min(n_per_worker / t for t in times), 2), round(max(n_per_worker / t for t in times), 2)],
+            "sample": f"{workers} processes x {n_per_worker} frames of {what}, started together; "
                       f"oracle extract + N x N best-2 match per frame"}
 
 
@@ -231,10 +278,15 @@ def gemm_kernel_roofline(torch, amos, dev, frames):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * frames * hw * hw * cout * 9 * cin
     tf = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "amos::k_conv_gemm<2, 2, 2, true> (proto_net 3x3 256->256 at 138x138: the largest launch of the pass)", "bound": "mfma",
+    name = amos.mask_conv_kernel_name(frames, hw, hw, cin, cout, 3, 3, 1, 1)  # the tile shape depends on the launch size
+    return {"kernel": name + " (proto_net 3x3 256->256 at 138x138: the largest launch of the pass)", "bound": "mfma",
             "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
             "flops_per_launch": int(flops), "frames_per_launch": frames, "avg_launch_ms": round(ms, 4),
             "measured_in": "after the timed region, the kernel alone on the chip, HIP events on the launching stream (10 launches)"}
+
+
+def use_mask_cfg(args):
+    return bool(CONFIGS[args.config].get("mask"))
 
 
 def main():
@@ -248,7 +300,11 @@ def main():
     ap.add_argument("--leg-steps", type=int, default=100, help="timed steps of the mask-off extract+match sub-leg of a c3 run (0 = skip the leg)")
     ap.add_argument("--leg-batch", type=int, default=512, help="frames per step of that sub-leg (4 lanes)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the 1-thread CPU baseline sample (0 = skip the CPU baseline)")
-    ap.add_argument("--cpu-cores", type=int, default=-1, help="processes of the all-cores CPU baseline (default: min(granted cores, 16); 0 = skip)")
+    ap.add_argument("--cpu-cores", type=int, default=-1, help="processes of the all-cores CPU baseline (default: every granted core, bounded by a cgroup quota and memory; 0 = skip)")
+    ap.add_argument("--tum-root", default=os.environ.get("AMOS_TUM_ROOT", ""), help="directory holding TUM RGB-D sequences (default $AMOS_TUM_ROOT): the 640x480 "
+                    "configs then run on real frames (BASELINE north_star: fr3/walking_xyz) instead of the synthetic stream")
+    ap.add_argument("--tum-sequence", default="", help="sequence(s), comma separated; rank r takes entry r modulo the list (default: fr3_walking_halfsphere for c3, fr3_walking_xyz for c2)")
+    ap.add_argument("--tum-associations", default="", help="associations file (`t rgb t depth` per line, rgbd_tum.cc:182-210); default: associations.txt inside the sequence")
     ap.add_argument("--mask-conv-dtype", choices=["fp32", "fp16", "bf16"], default="fp32",
                     help="precision of the mask network's convolutions (c3 only; fp32 is the parity configuration)")
     ap.add_argument("--mask-chunk", type=int, default=0, help="frames per network forward (default: frames per lane)")
@@ -304,7 +360,22 @@ def main():
 
     # frames of this rank's stream, resident in HBM before any timed region
     n_frames_dev = max(B, legB)
-    frames_np = synth.frames(shard.stream_for_rank(rank), 0, n_frames_dev, H, W)  # one stream per GPU
+    tum_source, d_bgr, data_label = None, None, "synthetic"
+    if args.tum_root and (W, H) == (640, 480):
+        # real frames: rank r takes its own sequence (configs[3]: one sequence per GPU) or, with one sequence, its own stretch of it
+        tum = importlib.import_module("amos_slam_amd.tum")
+        names = [n for n in (args.tum_sequence or ("fr3_walking_halfsphere" if use_mask_cfg(args) else "fr3_walking_xyz")).split(",") if n]
+        seq_name = names[rank % len(names)]
+        first = (rank // len(names)) * n_frames_dev
+        seq = tum.load_sequence(args.tum_root, seq_name, n_frames_dev, associations=args.tum_associations or None, start=first)
+        if seq["bgr"].shape[1:3] != (H, W):
+            raise SystemExit(f"TUM frames are {seq['bgr'].shape[2]}x{seq['bgr'].shape[1]}, the config wants {W}x{H}")
+        frames_np = tum.bgr_to_gray(seq["bgr"])  # what Tracking.cc:308-321 hands the extractor (the gray-input leg)
+        d_bgr = torch.from_numpy(seq["bgr"]).to(dev)  # the colour-input leg reads these (one read: gray pyramid + network input)
+        tum_source = ("tum", args.tum_root, seq_name, args.tum_associations or None, first)
+        data_label = "tum:" + seq["name"] + (" (wrapped: %d frames in the sequence)" % seq["frames_in_sequence"] if seq["wrapped"] else "")
+    else:
+        frames_np = synth.frames(shard.stream_for_rank(rank), 0, n_frames_dev, H, W)  # one stream per GPU
     d_frames = torch.from_numpy(frames_np).to(dev)
 
     # Lanes: extractor + matcher handle with their own HIP streams; kernels of one lane (e.g. the memory-bound
@@ -346,6 +417,7 @@ def main():
         for li in range(nl):
             ln = lanes[li]
             ln.frames = d_frames[li * bl:(li + 1) * bl]
+            ln.bgr_src = d_bgr[li * bl:(li + 1) * bl] if d_bgr is not None else None
             ln.pairs_q = torch.arange(bl, dtype=torch.int32, device=dev)
             ln.pairs_t = (ln.pairs_q - 1) % bl  # frame k against frame k-1 (the lane's first frame against its last)
             ln.bgr = None
@@ -357,7 +429,8 @@ def main():
         if masked:
             for ln in active:
                 if ln.bgr is None:
-                    ln.bgr = ln.frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()  # the colour frames (gray replicated), in HBM
+                    # the colour frames in HBM: the sequence's own BGR frames, or the synthetic gray stream replicated to three channels
+                    ln.bgr = ln.bgr_src.contiguous() if ln.bgr_src is not None else ln.frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
                     ln.pre = pkg.MaskPreprocessor(W, H, bl, device=local_rank, stream=ln.ext.stream)
                     ln.net_in = torch.empty((bl, 3, 550, 550), dtype=torch.float32, device=dev)
 
@@ -514,18 +587,22 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8" if not use_mask else "u8 (ORB, gate, matcher) + %s (mask network)" % args.mask_conv_dtype,
-            "data": "synthetic",
+            "data": data_label,
             "config": {"workload": cfg["label"], "frames_per_step_per_gpu": B, "lanes_per_gpu": S, "frames_per_launch": Bl, "width": W, "height": H,
                        "n_features": cfg["n_features"], "n_levels": cfg["n_levels"], "ini_th_fast": 20, "min_th_fast": 7,
                        "mean_keypoints_per_frame": round(mean_kp, 1), "match": "frame k vs k-1, N x N best-2",
                        "frames": "resident in HBM before the timed region (offline replay: %.0f MB/s of frames, no host link in the figure)" % (fps / world * W * H / 1e6),
-                       "synthetic_stream_seed": "stream = rank, frame k seeded 1000*rank+k (amos-slam_amd/synth.py)",
+                       "synthetic_stream_seed": ("stream = rank, frame k seeded 1000*rank+k (amos-slam_amd/synth.py)" if tum_source is None
+                                                 else "n/a: frames of " + data_label + " from frame %d on" % tum_source[4]),
                        "parallelism": f"frames sharded {world} ways, one process per GPU, no data-path collective"},
             "stage_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
             "digest_per_rank": {"layout": "per frame of the rank's first lane: keypoints, CRC32 of descriptor bytes, matches <= TH_LOW", "rows": digest_all},
         }
         if checked is not None:
             out["oracle_checked_frames"] = checked
+        import torch.distributed as dist
+        if dist.is_initialized():  # under a launcher, also with one rank: the collectives above ran through this group
+            out["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
         if use_mask:
             out["config"]["mask"] = {"network": "YOLACT-R50-FPN 550x550, %s, batch-norm folded, NHWC, random weights (no checkpoint offline)" % args.mask_conv_dtype,
                                      "frames_per_forward": chunk}
@@ -598,16 +675,17 @@ def main():
             out["gated_match"] = gated
         n_cpu = args.cpu_frames if args.cpu_frames >= 0 else (100 if W == 640 else 12)
         if world == 1 and n_cpu > 0:
-            granted = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            cores = args.cpu_cores if args.cpu_cores >= 0 else min(granted, 16)
-            one = cpu_baseline_one_thread(synth, cfg, n_cpu)
+            granted, quota = granted_cores()
+            cores = args.cpu_cores if args.cpu_cores >= 0 else all_cores_worker_count()
+            one = cpu_baseline_one_thread(synth, cfg, n_cpu, tum_source or ("synth", 0))
             if cores > 1:
-                out["cpu_baseline"] = cpu_baseline_all_cores(cfg, cores, 24 if W == 640 else 3)
+                out["cpu_baseline"] = cpu_baseline_all_cores(cfg, cores, 48 if W == 640 else 4, tum_source)
                 out["cpu_baseline"]["single_thread"] = one
             else:
                 out["cpu_baseline"] = one
             out["cpu_baseline"]["host_cores_visible"] = os.cpu_count()
             out["cpu_baseline"]["host_cores_granted"] = granted
+            out["cpu_baseline"]["cgroup_cpu_quota_cores"] = quota
             out["cpu_baseline"]["workload"] = "ORB extract + N x N best-2 match (the reference's CPU path, src/ORBextractor.cc + ORBmatcher.cc; its mask network runs on a GPU in the reference too)"
         print(json.dumps(out), flush=True)
 

@@ -351,6 +351,13 @@ int amos_mask_conv_supported(int cin, int cout, int kh, int kw, int stride, int 
 int amos_mask_conv_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual,
                           float *d_y, int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride, int pad,
                           int relu);
+/* Work-group tile of amos_mask_conv_device: -1 = automatic (128 x 128 outputs unless that leaves fewer than 1 024 work-groups or
+ * cout % 128 != 0, then 128 x 64), 0 = 128 x 128 wherever cout allows, 1 = always 128 x 64.  Returns the mode in force before
+ * the call; any other argument only queries.  The environment's AMOS_GEMM_NARROW (0 / 1) is the initial mode, read once.
+ * amos_mask_conv_kernel_name writes the name of the kernel the call with these arguments launches (as a profiler shows it). */
+int amos_mask_conv_tile_mode(int mode);
+int amos_mask_conv_kernel_name(int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride, int pad, char *name,
+                               int name_len);
 int amos_mask_conv1x1_supported(int cin, int cout, int stride);
 int amos_mask_conv1x1_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual,
                              float *d_y, int batch, int in_h, int in_w, int cin, int cout, int stride, int relu);

@@ -358,15 +358,21 @@ def test_mfma_conv1x1_against_float64(mask, gpu_lib, monkeypatch):
         for wfmt in (torch.contiguous_format, cl):
             wt = wgt.contiguous(memory_format=wfmt)
             for use_bias, use_res, relu in ((True, True, True), (True, False, True), (False, True, False), (False, False, False), (True, False, False)):
-                y = torch.full((b, cout, oh, ow), float("nan"), device="cuda").contiguous(memory_format=cl)
-                gpu_lib.mask_conv1x1(st, x.data_ptr(), wt.data_ptr(), bias.data_ptr() if use_bias else None, res.data_ptr() if use_res else None,
-                                     y.data_ptr(), b, h, w, cin, cout, stride, relu)
-                torch.cuda.synchronize()
-                want = exact + (bias.double().view(1, -1, 1, 1) if use_bias else 0) + (res.double() if use_res else 0)
-                if relu:
-                    want = want.relu()
-                err = (y.double() - want).abs()
-                assert torch.isfinite(y).all() and bool((err <= bound).all()), (cin, cout, stride, use_bias, use_res, relu, err.max().item())
+                # both work-group shapes: the automatic rule gives these small launches 128 x 64 tiles, the batched path's 128 x 128
+                # kernels (k_conv_gemm<2, 2, 2, *>) run when forced (cout % 128 == 0 only; elsewhere mode 0 changes nothing)
+                for tile_mode in (0, 1):
+                    gpu_lib.mask_conv_tile_mode(tile_mode)
+                    assert ("<2, 2, 2, false>" in gpu_lib.mask_conv_kernel_name(b, h, w, cin, cout, 1, 1, stride, 0)) == (tile_mode == 0 and cout % 128 == 0)
+                    y = torch.full((b, cout, oh, ow), float("nan"), device="cuda").contiguous(memory_format=cl)
+                    gpu_lib.mask_conv1x1(st, x.data_ptr(), wt.data_ptr(), bias.data_ptr() if use_bias else None, res.data_ptr() if use_res else None,
+                                         y.data_ptr(), b, h, w, cin, cout, stride, relu)
+                    torch.cuda.synchronize()
+                    gpu_lib.mask_conv_tile_mode(-1)
+                    want = exact + (bias.double().view(1, -1, 1, 1) if use_bias else 0) + (res.double() if use_res else 0)
+                    if relu:
+                        want = want.relu()
+                    err = (y.double() - want).abs()
+                    assert torch.isfinite(y).all() and bool((err <= bound).all()), (cin, cout, stride, use_bias, use_res, relu, tile_mode, err.max().item())
         conv = torch.nn.Conv2d(cin, cout, 1, stride=stride, bias=True).cuda().to(memory_format=cl)
         with torch.no_grad():
             conv.weight.copy_(wgt)
@@ -389,15 +395,28 @@ def test_mfma_conv1x1_against_float64(mask, gpu_lib, monkeypatch):
         bound = 1e-5 * F.conv2d(x.double().abs(), wgt.double().abs(), None, stride, pad) + 1e-6
         res = torch.randn(exact.shape, device="cuda").contiguous(memory_format=cl)
         for use_res, relu in ((False, True), (True, False)):
-            y = torch.full(exact.shape, float("nan"), device="cuda").contiguous(memory_format=cl)
-            gpu_lib.mask_conv(st, x.data_ptr(), wgt.data_ptr(), bias.data_ptr(), res.data_ptr() if use_res else None, y.data_ptr(), b, h, w, cin, cout, k, k,
-                              stride, pad, relu)
-            torch.cuda.synchronize()
-            want = exact + (res.double() if use_res else 0)
-            if relu:
-                want = want.relu()
-            err = (y.double() - want).abs()
-            assert torch.isfinite(y).all() and bool((err <= bound).all()), (cin, cout, k, stride, pad, use_res, relu, err.max().item())
+            for tile_mode in (0, 1):  # 128 x 128 (k_conv_gemm<2, 2, 2, true>, the batched path's kernel) and 128 x 64 work-groups
+                gpu_lib.mask_conv_tile_mode(tile_mode)
+                assert ("<2, 2, 2, true>" in gpu_lib.mask_conv_kernel_name(b, h, w, cin, cout, k, k, stride, pad)) == (tile_mode == 0 and cout % 128 == 0 and (k > 1 or pad > 0))
+                y = torch.full(exact.shape, float("nan"), device="cuda").contiguous(memory_format=cl)
+                gpu_lib.mask_conv(st, x.data_ptr(), wgt.data_ptr(), bias.data_ptr(), res.data_ptr() if use_res else None, y.data_ptr(), b, h, w, cin, cout, k, k,
+                                  stride, pad, relu)
+                torch.cuda.synchronize()
+                gpu_lib.mask_conv_tile_mode(-1)
+                want = exact + (res.double() if use_res else 0)
+                if relu:
+                    want = want.relu()
+                err = (y.double() - want).abs()
+                assert torch.isfinite(y).all() and bool((err <= bound).all()), (cin, cout, k, stride, pad, use_res, relu, tile_mode, err.max().item())
+    # one launch large enough for the automatic rule to pick the 128 x 128 kernel by itself (>= 1 024 wide work-groups)
+    x = torch.randn(4, 64, 138, 138, device="cuda").contiguous(memory_format=cl)
+    wgt = (torch.randn(256, 64, 3, 3, device="cuda") / 24.0).contiguous(memory_format=cl)
+    assert "<2, 2, 2, true>" in gpu_lib.mask_conv_kernel_name(4, 138, 138, 64, 256, 3, 3, 1, 1)
+    y = torch.full((4, 256, 138, 138), float("nan"), device="cuda").contiguous(memory_format=cl)
+    gpu_lib.mask_conv(st, x.data_ptr(), wgt.data_ptr(), None, None, y.data_ptr(), 4, 138, 138, 64, 256, 3, 3, 1, 1, False)
+    exact = F.conv2d(x.double(), wgt.double(), None, 1, 1)
+    bound = 1e-5 * F.conv2d(x.double().abs(), wgt.double().abs(), None, 1, 1) + 1e-6
+    assert bool(((y.double() - exact).abs() <= bound).all())
     monkeypatch.delenv("AMOS_MASK_CONV1X1")
     # the rule of the automatic choice: large launches with <= 512 input channels
     big, small = torch.empty(32, 64, 138, 138, device="meta"), torch.empty(1, 64, 138, 138, device="meta")
