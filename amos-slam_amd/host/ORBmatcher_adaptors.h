@@ -429,10 +429,17 @@ public:
         const FeatureGrid grid(amos_adapt::view_of(*pKF));
         std::vector<int> vnBestIdx;
         Fuse(grid, q, pKF->mvScaleFactors, pKF->mvInvLevelSigma2, th, vnBestIdx);
+        // The reference filters, searches and writes back point by point (:1038-1172); here all searches come first.  The search of a
+        // point reads only the keyframe's features, which the write-backs do not touch, so the order matters through two tests alone:
+        // a point made bad by an earlier Replace of this call, or added to this keyframe by an earlier AddObservation (the same
+        // point twice in vpMapPoints), is skipped by the reference's filter (:1046, :1052) when its turn comes -- re-tested here.
+        // (A Replace also recomputes the surviving point's descriptor; the survivor is then in this keyframe, i.e. filtered, so the
+        // descriptor copied before the searches is never one the reference would have searched with after the change.)
         int nFused = 0;
         for (size_t i = 0; i < q.size(); i++) {  // :1146-1172, in the reference's order
             const int bestIdx = vnBestIdx[i];
             if (bestIdx < 0) continue;
+            if (src[i]->isBad() || src[i]->IsInKeyFrame(pKF)) continue;
             MapPointT *pMP = src[i], *pMPinKF = pKF->GetMapPoint(bestIdx);
             if (pMPinKF) {
                 if (!pMPinKF->isBad()) {
@@ -462,9 +469,10 @@ public:
         std::vector<int> vnBestIdx;
         Fuse(grid, q, pKF->mvScaleFactors, th, vnBestIdx);
         int nFused = 0;
-        for (size_t i = 0; i < q.size(); i++) {  // :1291-1308
+        for (size_t i = 0; i < q.size(); i++) {  // :1291-1308 (spAlreadyFound is taken once on entry, :1196, so only isBad can change under way)
             const int bestIdx = vnBestIdx[i];
             if (bestIdx < 0) continue;
+            if (src[i]->isBad()) continue;
             MapPointT *pMP = src[i], *pMPinKF = pKF->GetMapPoint(bestIdx);
             if (pMPinKF) {
                 if (!pMPinKF->isBad()) vpReplacePoint[at[i]] = pMPinKF;

@@ -384,6 +384,327 @@ int amos_host_ref_search_local_points(const amos_test_camera *cam, int n, const 
     AMOS_HOST_CATCH
 }
 
+// ---- the other eight reference signatures on a small stand-in "map": a table of map points, keyframes / frames whose features point
+// into it, DBoW2-style feature vectors.  Map points are reported back as indices into the table (-1 = NULL).
+
+struct amos_test_points {
+    int32_t n;
+    const float *world, *normal;   // n x 3
+    const uint8_t *desc;           // n x 32
+    const int32_t *obs;            // Observations()
+    const uint8_t *bad;
+    const float *min_dist, *max_dist;  // mfMinDistance / mfMaxDistance (GetMin/MaxDistanceInvariance scale them by 0.8 / 1.2)
+};
+
+struct amos_test_kf {
+    amos_test_camera cam;          // cam.Tcw: the pose (a Frame's mTcw, a KeyFrame's Tcw; Ow = -Rcw^T tcw as KeyFrame::SetPose computes it)
+    int32_t n;
+    const amos_keypoint *keys, *keys_un;
+    const uint8_t *desc;
+    const float *u_right;          // NULL: monocular (mvuRight all -1)
+    const int32_t *point_of;       // n: index into the point table or -1 (mvpMapPoints)
+    int32_t n_nodes;               // mFeatVec
+    const uint32_t *node_ids;
+    const int32_t *node_off, *node_idx;
+};
+
+}  // extern "C"
+
+namespace
+{
+using namespace amos_standins;
+
+std::vector<MapPoint> make_points(const amos_test_points *t)
+{
+    std::vector<MapPoint> pts(t->n);
+    for (int i = 0; i < t->n; i++) {
+        MapPoint &p = pts[i];
+        for (int k = 0; k < 3; k++) {
+            p.mWorldPos.at<float>(k, 0) = t->world[3 * i + k];
+            p.mNormal.at<float>(k, 0) = t->normal ? t->normal[3 * i + k] : 0.f;
+        }
+        std::memcpy(p.mDescriptor.data, t->desc + 32 * (size_t)i, 32);
+        p.mnObs = t->obs ? t->obs[i] : 1;
+        p.mbBad = t->bad && t->bad[i];
+        p.mfMinDistance = t->min_dist ? t->min_dist[i] : 0.f;
+        p.mfMaxDistance = t->max_dist ? t->max_dist[i] : 1e9f;
+    }
+    return pts;
+}
+
+template <class F>
+void fill_base(F &f, const amos_test_kf *k)
+{
+    const int n = k->n;
+    f.N = n;
+    f.mvKeys.resize(n);
+    f.mvKeysUn.resize(n);
+    if (n) {
+        std::memcpy(f.mvKeys.data(), k->keys, sizeof(amos_keypoint) * n);
+        std::memcpy(f.mvKeysUn.data(), k->keys_un, sizeof(amos_keypoint) * n);
+    }
+    f.mDescriptors = cv::Mat(std::max(n, 1), 32, CV_8U);
+    if (n) std::memcpy(f.mDescriptors.data, k->desc, (size_t)32 * n);
+    if (k->u_right) f.mvuRight.assign(k->u_right, k->u_right + n);
+    else f.mvuRight.assign(n, -1.f);
+    const amos_test_camera &c = k->cam;
+    f.fx = c.fx; f.fy = c.fy; f.cx = c.cx; f.cy = c.cy; f.mb = c.mb; f.mbf = c.mbf;
+    f.mnMinX = c.min_x; f.mnMaxX = c.max_x; f.mnMinY = c.min_y; f.mnMaxY = c.max_y;
+    f.mnScaleLevels = c.n_levels;
+    f.mvScaleFactors.assign(c.scale_factors, c.scale_factors + c.n_levels);
+    f.mvLevelSigma2.resize(c.n_levels);
+    f.mvInvLevelSigma2.resize(c.n_levels);
+    for (int l = 0; l < c.n_levels; l++) {  // ORBextractor.cc:522-533
+        f.mvLevelSigma2[l] = c.scale_factors[l] * c.scale_factors[l];
+        f.mvInvLevelSigma2[l] = 1.0f / f.mvLevelSigma2[l];
+    }
+    f.mfLogScaleFactor = c.n_levels > 1 ? std::log(c.scale_factors[1]) : 1.f;
+    for (int j = 0; j < k->n_nodes; j++) {
+        std::vector<unsigned int> &v = f.mFeatVec[k->node_ids[j]];
+        for (int e = k->node_off[j]; e < k->node_off[j + 1]; e++) v.push_back((unsigned int)k->node_idx[e]);
+    }
+    f.mvpMapPoints.assign(n, static_cast<MapPoint *>(NULL));
+}
+
+void fill_keyframe(KeyFrame &kf, const amos_test_kf *k, std::vector<MapPoint> &pts)
+{
+    fill_base(kf, k);
+    kf.Tcw = cv::Mat(4, 4, CV_32F);
+    std::memcpy(kf.Tcw.data, k->cam.Tcw, sizeof(float) * 16);
+    const amos_adapt::V3 ow = amos_adapt::centre(amos_adapt::pose_of(kf.Tcw));  // KeyFrame::SetPose: Ow = -Rwc * tcw (one gemm)
+    kf.Ow = cv::Mat(3, 1, CV_32F);
+    kf.Ow.at<float>(0, 0) = ow.x; kf.Ow.at<float>(1, 0) = ow.y; kf.Ow.at<float>(2, 0) = ow.z;
+    for (int i = 0; i < k->n; i++)
+        if (k->point_of && k->point_of[i] >= 0) {
+            MapPoint *p = &pts[k->point_of[i]];
+            kf.mvpMapPoints[i] = p;
+            if (!p->mObservations.count(&kf)) p->mObservations[&kf] = i;  // the point table's `obs` is Observations(); this is who observes
+        }
+}
+
+void fill_frame2(Frame &f, const amos_test_kf *k, std::vector<MapPoint> &pts)
+{
+    fill_base(f, k);
+    f.mvbOutlier.assign(k->n, false);
+    f.mTcw = cv::Mat(4, 4, CV_32F);
+    std::memcpy(f.mTcw.data, k->cam.Tcw, sizeof(float) * 16);
+    for (int i = 0; i < k->n; i++)
+        if (k->point_of && k->point_of[i] >= 0) f.mvpMapPoints[i] = &pts[k->point_of[i]];
+}
+
+inline int32_t index_of(const MapPoint *p, const std::vector<MapPoint> &pts) { return p ? (int32_t)(p - pts.data()) : -1; }
+}  // namespace
+
+extern "C" {
+
+// MapPoint::PredictScale of the stand-in (MapPoint.cc: ceil(log(max / dist) / log scale factor), clamped), for the tests' own pre-filter
+int amos_host_standin_predict_scale(float max_dist, float cur_dist, float log_scale_factor, int n_levels)
+{
+    MapPoint p;
+    p.mfMaxDistance = max_dist;
+    FrameBase f;
+    f.mfLogScaleFactor = log_scale_factor;
+    f.mnScaleLevels = n_levels;
+    return p.PredictScale(cur_dist, &f);
+}
+
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist), ORBmatcher.cc:1731.
+// cur->point_of = the occupants of CurrentFrame.mvpMapPoints on entry; cur_points[i2] = CurrentFrame.mvpMapPoints[i2] on return.
+int amos_host_ref_search_reloc(const amos_test_kf *cur, const amos_test_kf *kf, const amos_test_points *points, const uint8_t *already_found,
+                               float th, int orb_dist, float nnratio, int check_orientation, int32_t *cur_points)
+{
+    AMOS_HOST_TRY
+    std::vector<MapPoint> pts = make_points(points);
+    Frame Cur;
+    KeyFrame KF;
+    fill_frame2(Cur, cur, pts);
+    fill_keyframe(KF, kf, pts);
+    std::set<MapPoint *> found;
+    for (int i = 0; i < points->n; i++)
+        if (already_found && already_found[i]) found.insert(&pts[i]);
+    RefMatcher matcher(nnratio, check_orientation != 0);
+    const int n = matcher.SearchByProjection(Cur, &KF, found, th, orb_dist);
+    for (int i = 0; i < cur->n; i++) cur_points[i] = index_of(Cur.mvpMapPoints[i], pts);
+    return n;
+    AMOS_HOST_CATCH
+}
+
+// ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th), :388.
+// vp: indices into the point table; matched: in / out, n_kf entries (point index or -1).
+int amos_host_ref_search_kf_scw(const amos_test_kf *kf, const amos_test_points *points, const float *Scw, const int32_t *vp, int n_vp, int32_t *matched,
+                                int th, float nnratio)
+{
+    AMOS_HOST_TRY
+    std::vector<MapPoint> pts = make_points(points);
+    KeyFrame KF;
+    fill_keyframe(KF, kf, pts);
+    cv::Mat S(4, 4, CV_32F);
+    std::memcpy(S.data, Scw, sizeof(float) * 16);
+    std::vector<MapPoint *> vpPoints(n_vp), vpMatched(kf->n, static_cast<MapPoint *>(NULL));
+    for (int i = 0; i < n_vp; i++) vpPoints[i] = &pts[vp[i]];
+    for (int i = 0; i < kf->n; i++)
+        if (matched[i] >= 0) vpMatched[i] = &pts[matched[i]];
+    RefMatcher matcher(nnratio, true);
+    const int n = matcher.SearchByProjection(&KF, S, vpPoints, vpMatched, th);
+    for (int i = 0; i < kf->n; i++) matched[i] = index_of(vpMatched[i], pts);
+    return n;
+    AMOS_HOST_CATCH
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), :230.  matches: F.N entries.
+int amos_host_ref_search_bow_kf_frame(const amos_test_kf *kf, const amos_test_kf *frame, const amos_test_points *points, float nnratio,
+                                      int check_orientation, int32_t *matches)
+{
+    AMOS_HOST_TRY
+    std::vector<MapPoint> pts = make_points(points);
+    KeyFrame KF;
+    Frame F;
+    fill_keyframe(KF, kf, pts);
+    fill_frame2(F, frame, pts);
+    std::vector<MapPoint *> vpMapPointMatches(3, &pts[0]);  // the function re-creates it with F.N NULLs (:234)
+    RefMatcher matcher(nnratio, check_orientation != 0);
+    const int n = matcher.SearchByBoW(&KF, F, vpMapPointMatches);
+    if ((int)vpMapPointMatches.size() != frame->n) return -104;
+    for (int i = 0; i < frame->n; i++) matches[i] = index_of(vpMapPointMatches[i], pts);
+    return n;
+    AMOS_HOST_CATCH
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12), :656.  matches12: pKF1->N entries.
+int amos_host_ref_search_bow_kf_kf(const amos_test_kf *kf1, const amos_test_kf *kf2, const amos_test_points *points, float nnratio,
+                                   int check_orientation, int32_t *matches12)
+{
+    AMOS_HOST_TRY
+    std::vector<MapPoint> pts = make_points(points);
+    KeyFrame K1, K2;
+    fill_keyframe(K1, kf1, pts);
+    fill_keyframe(K2, kf2, pts);
+    std::vector<MapPoint *> vpMatches12;
+    RefMatcher matcher(nnratio, check_orientation != 0);
+    const int n = matcher.SearchByBoW(&K1, &K2, vpMatches12);
+    if ((int)vpMatches12.size() != kf1->n) return -104;
+    for (int i = 0; i < kf1->n; i++) matches12[i] = index_of(vpMatches12[i], pts);
+    return n;
+    AMOS_HOST_CATCH
+}
+
+// ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize), :515
+int amos_host_ref_search_initialization(const amos_test_kf *f1, const amos_test_kf *f2, float *prev_matched, int32_t *matches12, int window_size,
+                                        float nnratio, int check_orientation)
+{
+    AMOS_HOST_TRY
+    std::vector<MapPoint> none;
+    Frame F1, F2;
+    fill_frame2(F1, f1, none);
+    fill_frame2(F2, f2, none);
+    std::vector<cv::Point2f> prev(f1->n);
+    for (int i = 0; i < f1->n; i++) prev[i] = cv::Point2f(prev_matched[2 * i], prev_matched[2 * i + 1]);
+    std::vector<int> m12;
+    RefMatcher matcher(nnratio, check_orientation != 0);
+    const int n = matcher.SearchForInitialization(F1, F2, prev, m12, window_size);
+    for (int i = 0; i < f1->n; i++) {
+        matches12[i] = m12[i];
+        prev_matched[2 * i] = prev[i].x;
+        prev_matched[2 * i + 1] = prev[i].y;
+    }
+    return n;
+    AMOS_HOST_CATCH
+}
+
+// ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t,size_t>> &vMatchedPairs, bOnlyStereo), :810
+int amos_host_ref_search_triangulation(const amos_test_kf *kf1, const amos_test_kf *kf2, const amos_test_points *points, const float *F12,
+                                       int only_stereo, float nnratio, int check_orientation, int32_t *pairs, int cap)
+{
+    AMOS_HOST_TRY
+    std::vector<MapPoint> pts = make_points(points);
+    KeyFrame K1, K2;
+    fill_keyframe(K1, kf1, pts);
+    fill_keyframe(K2, kf2, pts);
+    cv::Mat F(3, 3, CV_32F);
+    std::memcpy(F.data, F12, sizeof(float) * 9);
+    std::vector<std::pair<size_t, size_t> > vMatchedPairs;
+    RefMatcher matcher(nnratio, check_orientation != 0);
+    const int n = matcher.SearchForTriangulation(&K1, &K2, F, vMatchedPairs, only_stereo != 0);
+    if ((int)vMatchedPairs.size() > cap) return -3;
+    for (size_t i = 0; i < vMatchedPairs.size(); i++) {
+        pairs[2 * i] = (int32_t)vMatchedPairs[i].first;
+        pairs[2 * i + 1] = (int32_t)vMatchedPairs[i].second;
+    }
+    return n;
+    AMOS_HOST_CATCH
+}
+
+// ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12,
+// const cv::Mat &t12, const float th), :1314.  matches12: in / out, pKF1->N entries (point index or -1).
+int amos_host_ref_search_sim3(const amos_test_kf *kf1, const amos_test_kf *kf2, const amos_test_points *points, int32_t *matches12, float s12,
+                              const float *R12, const float *t12, float th, float nnratio)
+{
+    AMOS_HOST_TRY
+    std::vector<MapPoint> pts = make_points(points);
+    KeyFrame K1, K2;
+    fill_keyframe(K1, kf1, pts);
+    fill_keyframe(K2, kf2, pts);
+    cv::Mat R(3, 3, CV_32F), t(3, 1, CV_32F);
+    std::memcpy(R.data, R12, sizeof(float) * 9);
+    std::memcpy(t.data, t12, sizeof(float) * 3);
+    std::vector<MapPoint *> vpMatches12(kf1->n, static_cast<MapPoint *>(NULL));
+    for (int i = 0; i < kf1->n; i++)
+        if (matches12[i] >= 0) vpMatches12[i] = &pts[matches12[i]];
+    RefMatcher matcher(nnratio, true);
+    const int n = matcher.SearchBySim3(&K1, &K2, vpMatches12, s12, R, t, th);
+    for (int i = 0; i < kf1->n; i++) matches12[i] = index_of(vpMatches12[i], pts);
+    return n;
+    AMOS_HOST_CATCH
+}
+
+// ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th), :1020.  vp: point indices, -1 = a NULL entry.
+// Out: the keyframe's map points afterwards, and per table entry replaced_by (mpReplaced or -1), Observations() and isBad().
+int amos_host_ref_fuse(const amos_test_kf *kf, const amos_test_points *points, const int32_t *vp, int n_vp, float th, float nnratio,
+                       int32_t *kf_points, int32_t *replaced_by, int32_t *obs_after, uint8_t *bad_after)
+{
+    AMOS_HOST_TRY
+    std::vector<MapPoint> pts = make_points(points);
+    KeyFrame KF;
+    fill_keyframe(KF, kf, pts);
+    std::vector<MapPoint *> vpMapPoints(n_vp);
+    for (int i = 0; i < n_vp; i++) vpMapPoints[i] = vp[i] >= 0 ? &pts[vp[i]] : static_cast<MapPoint *>(NULL);
+    RefMatcher matcher(nnratio, true);
+    const int n = matcher.Fuse(&KF, vpMapPoints, th);
+    for (int i = 0; i < kf->n; i++) kf_points[i] = index_of(KF.mvpMapPoints[i], pts);
+    for (int i = 0; i < points->n; i++) {
+        replaced_by[i] = index_of(pts[i].mpReplaced, pts);
+        obs_after[i] = pts[i].Observations();
+        bad_after[i] = pts[i].isBad();
+    }
+    return n;
+    AMOS_HOST_CATCH
+}
+
+// ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th, vector<MapPoint*> &vpReplacePoint), :1179.
+// replace_point: in / out, n_vp entries (point index or -1).
+int amos_host_ref_fuse_scw(const amos_test_kf *kf, const amos_test_points *points, const float *Scw, const int32_t *vp, int n_vp, float th, float nnratio,
+                           int32_t *replace_point, int32_t *kf_points, int32_t *obs_after)
+{
+    AMOS_HOST_TRY
+    std::vector<MapPoint> pts = make_points(points);
+    KeyFrame KF;
+    fill_keyframe(KF, kf, pts);
+    cv::Mat S(4, 4, CV_32F);
+    std::memcpy(S.data, Scw, sizeof(float) * 16);
+    std::vector<MapPoint *> vpPoints(n_vp), vpReplace(n_vp, static_cast<MapPoint *>(NULL));
+    for (int i = 0; i < n_vp; i++) {
+        vpPoints[i] = &pts[vp[i]];
+        if (replace_point[i] >= 0) vpReplace[i] = &pts[replace_point[i]];
+    }
+    RefMatcher matcher(nnratio, true);
+    const int n = matcher.Fuse(&KF, S, vpPoints, th, vpReplace);
+    for (int i = 0; i < n_vp; i++) replace_point[i] = index_of(vpReplace[i], pts);
+    for (int i = 0; i < kf->n; i++) kf_points[i] = index_of(KF.mvpMapPoints[i], pts);
+    for (int i = 0; i < points->n; i++) obs_after[i] = pts[i].Observations();
+    return n;
+    AMOS_HOST_CATCH
+}
+
 int amos_host_yolact_eval(const char *py_file, const char *weights, const uint8_t *bgr, int w, int h, uint8_t *mask_out, int *mask_w,
                           int *mask_h)
 {

@@ -43,8 +43,8 @@ public:
     }
     bool IsInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) != 0; }
     int GetIndexInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) ? (int)mObservations[pKF] : -1; }
-    void AddObservation(KeyFrame *pKF, size_t idx) { if (!mObservations.count(pKF)) { mObservations[pKF] = idx; mnObs++; } }
-    void Replace(MapPoint *pMP) { mbBad = true; mpReplaced = pMP; }
+    inline void AddObservation(KeyFrame *pKF, size_t idx);  // MapPoint.cc: a stereo observation counts twice
+    inline void Replace(MapPoint *pMP);                     // MapPoint.cc:244-310: observations move to pMP, the keyframes are updated
 
     bool mbTrackInView;
     int mnTrackScaleLevel;
@@ -91,6 +91,8 @@ public:
         return s;
     }
     void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }
+    void EraseMapPointMatch(const size_t &idx) { mvpMapPoints[idx] = static_cast<MapPoint *>(NULL); }
+    void ReplaceMapPointMatch(const size_t &idx, MapPoint *pMP) { mvpMapPoints[idx] = pMP; }
     bool IsInImage(const float &x, const float &y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
     cv::Mat GetRotation() { return cv::Mat(Tcw, cv::Rect(0, 0, 3, 3)).clone(); }
     cv::Mat GetTranslation() { return cv::Mat(Tcw, cv::Rect(3, 0, 1, 3)).clone(); }
@@ -98,4 +100,29 @@ public:
     std::vector<MapPoint *> mvpMapPoints;
     cv::Mat Tcw, Ow;
 };
+
+inline void MapPoint::AddObservation(KeyFrame *pKF, size_t idx)
+{
+    if (mObservations.count(pKF)) return;
+    mObservations[pKF] = idx;
+    mnObs += (idx < pKF->mvuRight.size() && pKF->mvuRight[idx] >= 0) ? 2 : 1;
+}
+
+inline void MapPoint::Replace(MapPoint *pMP)
+{
+    if (pMP == this) return;
+    const std::map<KeyFrame *, size_t> obs = mObservations;
+    mObservations.clear();
+    mbBad = true;
+    mpReplaced = pMP;
+    for (std::map<KeyFrame *, size_t>::const_iterator mit = obs.begin(); mit != obs.end(); ++mit) {
+        KeyFrame *pKF = mit->first;
+        if (!pMP->IsInKeyFrame(pKF)) {
+            pKF->ReplaceMapPointMatch(mit->second, pMP);
+            pMP->AddObservation(pKF, mit->second);
+        } else {
+            pKF->EraseMapPointMatch(mit->second);
+        }
+    }
+}
 }  // namespace AMOS_STANDIN_NS
