@@ -498,12 +498,12 @@ inline int32_t index_of(const MapPoint *p, const std::vector<MapPoint> &pts) { r
 extern "C" {
 
 // MapPoint::PredictScale of the stand-in (MapPoint.cc: ceil(log(max / dist) / log scale factor), clamped), for the tests' own pre-filter
-int amos_host_standin_predict_scale(float max_dist, float cur_dist, float log_scale_factor, int n_levels)
+int amos_host_standin_predict_scale(float max_dist, float cur_dist, float scale_factor, int n_levels)
 {
     MapPoint p;
     p.mfMaxDistance = max_dist;
     FrameBase f;
-    f.mfLogScaleFactor = log_scale_factor;
+    f.mfLogScaleFactor = n_levels > 1 ? std::log(scale_factor) : 1.f;  // as fill_base derives it from scale_factors[1]
     f.mnScaleLevels = n_levels;
     return p.PredictScale(cur_dist, &f);
 }

@@ -326,3 +326,120 @@ def ref_search_local_points(cam, keys_un, desc, u_right, points, in_view, bad, t
     r = _chk(host().amos_host_ref_search_local_points(C.byref(cam), C.c_int(len(k)), _p(k), _p(d), _p(ur), _p(pts), _p(iv), _p(bd), C.c_int(len(pts)),
                                                       C.c_float(th), C.c_float(nnratio), _p(match)))
     return r, match[:len(k)]
+
+
+# ---- the stand-in "map" for the other eight reference signatures (host_capi.cc: amos_test_points / amos_test_kf)
+
+class TestPoints(C.Structure):
+    _fields_ = [("n", C.c_int32), ("world", C.c_void_p), ("normal", C.c_void_p), ("desc", C.c_void_p), ("obs", C.c_void_p), ("bad", C.c_void_p),
+                ("min_dist", C.c_void_p), ("max_dist", C.c_void_p)]
+
+
+class TestKF(C.Structure):
+    _fields_ = [("cam", TestCamera), ("n", C.c_int32), ("keys", C.c_void_p), ("keys_un", C.c_void_p), ("desc", C.c_void_p), ("u_right", C.c_void_p),
+                ("point_of", C.c_void_p), ("n_nodes", C.c_int32), ("node_ids", C.c_void_p), ("node_off", C.c_void_p), ("node_idx", C.c_void_p)]
+
+
+def test_points(world, normal, desc, obs, bad, min_dist, max_dist):
+    keep = (np.ascontiguousarray(world, np.float32), np.ascontiguousarray(normal, np.float32), np.ascontiguousarray(desc, np.uint8),
+            np.ascontiguousarray(obs, np.int32), np.ascontiguousarray(bad, np.uint8), np.ascontiguousarray(min_dist, np.float32),
+            np.ascontiguousarray(max_dist, np.float32))
+    return TestPoints(len(keep[0]), *[a.ctypes.data for a in keep]), keep
+
+
+def test_kf(cam, keys, desc, u_right=None, point_of=None, nodes=None, keys_un=None):
+    """A stand-in Frame / KeyFrame: camera (pose inside), features, per-feature map point index, feature vector {node: [features]}."""
+    k = np.ascontiguousarray(keys, KP)
+    ku = k if keys_un is None else np.ascontiguousarray(keys_un, KP)
+    d = np.ascontiguousarray(desc, np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    po = None if point_of is None else np.ascontiguousarray(point_of, np.int32)
+    nodes = nodes or {}
+    ids = np.array(sorted(nodes), np.uint32)
+    off = np.zeros(len(ids) + 1, np.int32)
+    idx = []
+    for j, nid in enumerate(ids):
+        idx.extend(nodes[int(nid)])
+        off[j + 1] = len(idx)
+    idx = np.array(idx if idx else [0], np.int32)
+    s = TestKF(cam, len(k), k.ctypes.data, ku.ctypes.data, d.ctypes.data, ur.ctypes.data if ur is not None else None,
+               po.ctypes.data if po is not None else None, len(ids), ids.ctypes.data, off.ctypes.data, idx.ctypes.data)
+    return s, (k, ku, d, ur, po, ids, off, idx)
+
+
+def standin_predict_scale(max_dist, cur_dist, scale_factor, n_levels):
+    """MapPoint::PredictScale of the stand-in for arrays of (mfMaxDistance, current distance); scale_factor = mvScaleFactors[1]."""
+    host().amos_host_standin_predict_scale.restype = C.c_int
+    return [int(host().amos_host_standin_predict_scale(C.c_float(float(m)), C.c_float(float(c)), C.c_float(float(scale_factor)), C.c_int(n_levels)))
+            for m, c in zip(np.atleast_1d(max_dist), np.atleast_1d(cur_dist))]
+
+
+def ref_search_reloc(cur, kf, pts, already_found, th, orb_dist, nnratio=0.9, check_ori=True):
+    out = np.zeros(max(cur.n, 1), np.int32)
+    af = np.ascontiguousarray(already_found, np.uint8)
+    r = _chk(host().amos_host_ref_search_reloc(C.byref(cur), C.byref(kf), C.byref(pts), _p(af), C.c_float(th), C.c_int(orb_dist), C.c_float(nnratio),
+                                              C.c_int(int(check_ori)), _p(out)))
+    return r, out[:cur.n]
+
+
+def ref_search_kf_scw(kf, pts, scw, vp, matched, th, nnratio=0.75):
+    m = np.ascontiguousarray(matched, np.int32).copy()
+    vp = np.ascontiguousarray(vp, np.int32)
+    s = np.ascontiguousarray(scw, np.float32).reshape(16)
+    r = _chk(host().amos_host_ref_search_kf_scw(C.byref(kf), C.byref(pts), _p(s), _p(vp), C.c_int(len(vp)), _p(m), C.c_int(th), C.c_float(nnratio)))
+    return r, m
+
+
+def ref_search_bow_kf_frame(kf, frame, pts, nnratio=0.7, check_ori=True):
+    m = np.zeros(max(frame.n, 1), np.int32)
+    r = _chk(host().amos_host_ref_search_bow_kf_frame(C.byref(kf), C.byref(frame), C.byref(pts), C.c_float(nnratio), C.c_int(int(check_ori)), _p(m)))
+    return r, m[:frame.n]
+
+
+def ref_search_bow_kf_kf(kf1, kf2, pts, nnratio=0.75, check_ori=True):
+    m = np.zeros(max(kf1.n, 1), np.int32)
+    r = _chk(host().amos_host_ref_search_bow_kf_kf(C.byref(kf1), C.byref(kf2), C.byref(pts), C.c_float(nnratio), C.c_int(int(check_ori)), _p(m)))
+    return r, m[:kf1.n]
+
+
+def ref_search_initialization(f1, f2, prev_matched, window, nnratio=0.9, check_ori=True):
+    prev = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.zeros(max(f1.n, 1), np.int32)
+    r = _chk(host().amos_host_ref_search_initialization(C.byref(f1), C.byref(f2), _p(prev), _p(m12), C.c_int(window), C.c_float(nnratio),
+                                                       C.c_int(int(check_ori))))
+    return r, m12[:f1.n], prev
+
+
+def ref_search_triangulation(kf1, kf2, pts, f12, only_stereo, nnratio=0.6, check_ori=True):
+    f = np.ascontiguousarray(f12, np.float32).reshape(9)
+    pairs = np.zeros((max(kf1.n, 1), 2), np.int32)
+    r = _chk(host().amos_host_ref_search_triangulation(C.byref(kf1), C.byref(kf2), C.byref(pts), _p(f), C.c_int(int(only_stereo)), C.c_float(nnratio),
+                                                      C.c_int(int(check_ori)), _p(pairs), C.c_int(len(pairs))))
+    return r, pairs[:max(r, 0)].copy()
+
+
+def ref_search_sim3(kf1, kf2, pts, matches12, s12, r12, t12, th, nnratio=0.75):
+    m = np.ascontiguousarray(matches12, np.int32).copy()
+    R, t = np.ascontiguousarray(r12, np.float32).reshape(9), np.ascontiguousarray(t12, np.float32).reshape(3)
+    r = _chk(host().amos_host_ref_search_sim3(C.byref(kf1), C.byref(kf2), C.byref(pts), _p(m), C.c_float(s12), _p(R), _p(t), C.c_float(th),
+                                             C.c_float(nnratio)))
+    return r, m
+
+
+def ref_fuse(kf, pts, vp, th, nnratio=0.6):
+    vp = np.ascontiguousarray(vp, np.int32)
+    kf_points = np.zeros(max(kf.n, 1), np.int32)
+    replaced, obs, bad = np.zeros(pts.n, np.int32), np.zeros(pts.n, np.int32), np.zeros(pts.n, np.uint8)
+    r = _chk(host().amos_host_ref_fuse(C.byref(kf), C.byref(pts), _p(vp), C.c_int(len(vp)), C.c_float(th), C.c_float(nnratio), _p(kf_points), _p(replaced),
+                                      _p(obs), _p(bad)))
+    return r, kf_points[:kf.n], replaced, obs, bad
+
+
+def ref_fuse_scw(kf, pts, scw, vp, th, replace_point, nnratio=0.6):
+    vp = np.ascontiguousarray(vp, np.int32)
+    rp = np.ascontiguousarray(replace_point, np.int32).copy()
+    s = np.ascontiguousarray(scw, np.float32).reshape(16)
+    kf_points, obs = np.zeros(max(kf.n, 1), np.int32), np.zeros(pts.n, np.int32)
+    r = _chk(host().amos_host_ref_fuse_scw(C.byref(kf), C.byref(pts), _p(s), _p(vp), C.c_int(len(vp)), C.c_float(th), C.c_float(nnratio), _p(rp),
+                                          _p(kf_points), _p(obs)))
+    return r, rp, kf_points[:kf.n], obs
