@@ -121,10 +121,13 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
     typedef const __attribute__((address_space(1))) void *GlobalPtr;
 
     f32x4 raw[8];
-#define AMOS_WINO_FETCH(s, buf)                                                                                                      \
+#define AMOS_WINO_FETCH_U(s, buf)                                                                                                    \
     {                                                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; j++)                                                                                \
             __builtin_amdgcn_global_load_lds((GlobalPtr)(usrc + (size_t)(s) * kWinoStageU + j * 256), (LdsPtr)(AMOS_WINO_U(buf) + (wave * 4 + j) * 256), 16, 0, 0); \
+    }
+#define AMOS_WINO_FETCH_X(s)                                                                                                         \
+    {                                                                                                                                \
         _Pragma("unroll") for (int i = 0; i < 8; i++)                                                                                \
             raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[i], (s) * (kWinoK * 4), 0));         \
     }
@@ -150,35 +153,88 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[p][i][j][r] = 0.f;
     const int foff = wino_swz(lane & 31, lane >> 5);  // this lane's 4 floats inside a 32-row block
-
-    AMOS_WINO_FETCH(0, 0);
-    AMOS_WINO_STASH(0);
-    __syncthreads();
-    for (int s = 0; s < a.stages; s++) {
-        const int buf = s & 1;
-        if (s + 1 < a.stages) AMOS_WINO_FETCH(s + 1, buf ^ 1);
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int pos = wave * 2 + p;
-            f32x4 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++) fa[i] = *reinterpret_cast<const f32x4 *>(AMOS_WINO_V(buf) + (pos * kWinoTiles + i * 32) * kWinoK + foff);
-#pragma unroll
-            for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const f32x4 *>(AMOS_WINO_U(buf) + (pos * kWinoCout + j * 32) * kWinoK + foff);
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[p][i][j], 0, 0, 0);
-                    acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[p][i][j], 0, 0, 0);
-                    acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[p][i][j], 0, 0, 0);
-                    acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[p][i][j], 0, 0, 0);
-                }
-        }
-        if (s + 1 < a.stages) AMOS_WINO_STASH(buf ^ 1);
-        __syncthreads();
+    // fragments: one register set per position of the pair, so the LDS reads of one position are in flight under the MFMAs of the other
+    f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
+#define AMOS_WINO_LDFRAG(fa, fb, buf, p)                                                                                              \
+    {                                                                                                                                 \
+        const int pos = wave * 2 + (p);                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; i++) fa[i] = *reinterpret_cast<const f32x4 *>(AMOS_WINO_V(buf) + (pos * kWinoTiles + i * 32) * kWinoK + foff); \
+        _Pragma("unroll") for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const f32x4 *>(AMOS_WINO_U(buf) + (pos * kWinoCout + j * 32) * kWinoK + foff);  \
     }
-#undef AMOS_WINO_FETCH
+#define AMOS_WINO_MFMAS(fa, fb, p)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; i++) _Pragma("unroll") for (int j = 0; j < 2; j++) {           \
+        acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[p][i][j], 0, 0, 0);       \
+        acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[p][i][j], 0, 0, 0);       \
+        acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[p][i][j], 0, 0, 0);       \
+        acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[p][i][j], 0, 0, 0);       \
+    }
+// one instruction of the named kind behind each of the next `n` MFMAs
+#define AMOS_WINO_INTERLEAVE(mask, n, each)                                               \
+    _Pragma("unroll") for (int q = 0; q < (n); q++) {                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(mask, each, 0);                              \
+    }
+    // One stage = two halves of 16 MFMAs.  First half: position 0 of the pair multiplies (its fragments were read in the second half
+    // of the stage before), position 1's fragments are read, the next stage's V tile is made from the pixels requested a whole stage
+    // earlier and written to the other buffer, and the pixels of the stage after that are requested (HBM latency is about three
+    // quarters of a stage); then the barrier: the other buffer is complete (this wave's U pieces of it have landed: vmcnt leaves only
+    // the eight pixel loads just issued in flight) and nobody reads this stage's buffer any more, since every wave holds position 1's
+    // fragments.  Second half: position 1 multiplies, the next stage's position-0 fragments are read from the other buffer, and the
+    // U tile of the stage after that is requested by LDS-DMA into the buffer this stage just released.  No LDS latency and no global
+    // latency sits between two MFMAs.  (A raw s_barrier: __syncthreads() would drain the pixel loads as well.)
+#define AMOS_WINO_STAGE(s, buf, kNext, kNext2)                                            \
+    {                                                                                     \
+        AMOS_WINO_LDFRAG(fa1, fb1, buf, 1);                                               \
+        if (kNext) AMOS_WINO_STASH((buf) ^ 1);                                            \
+        if (kNext2) AMOS_WINO_FETCH_X((s) + 2);                                           \
+        AMOS_WINO_MFMAS(fa0, fb0, 0);                                                     \
+        AMOS_WINO_INTERLEAVE(0x100, 4, 1);                                                \
+        if (kNext) {                                                                      \
+            AMOS_WINO_INTERLEAVE(0x002, 6, 6);                                            \
+            AMOS_WINO_INTERLEAVE(0x200, 4, 1);                                            \
+        }                                                                                 \
+        if (kNext2) AMOS_WINO_INTERLEAVE(0x020, 2, 4);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                               \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (kNext2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (kNext) AMOS_WINO_LDFRAG(fa0, fb0, (buf) ^ 1, 0);                              \
+        if (kNext2) AMOS_WINO_FETCH_U((s) + 2, buf);                                      \
+        AMOS_WINO_MFMAS(fa1, fb1, 1);                                                     \
+        AMOS_WINO_INTERLEAVE(0x100, 4, 1);                                                \
+        if (kNext2) AMOS_WINO_INTERLEAVE(0x020, 4, 1);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                               \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    }
+
+    AMOS_WINO_FETCH_U(0, 0);
+    AMOS_WINO_FETCH_X(0);
+    AMOS_WINO_STASH(0);
+    if (a.stages > 1) AMOS_WINO_FETCH_X(1);
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (with one stage only: the eight loads above do not exist and this waits for everything)
+    AMOS_WINO_LDFRAG(fa0, fb0, 0, 0);
+    if (a.stages > 1) AMOS_WINO_FETCH_U(1, 1);
+    int s = 0;
+    for (; s + 2 < a.stages; s++) {
+        const int buf = s & 1;
+        AMOS_WINO_STAGE(s, buf, true, true);
+    }
+    if (s + 1 < a.stages) {  // the last but one: nothing left to request
+        const int buf = s & 1;
+        AMOS_WINO_STAGE(s, buf, true, false);
+        s++;
+    }
+    {
+        const int buf = s & 1;
+        AMOS_WINO_STAGE(s, buf, false, false);
+    }
+#undef AMOS_WINO_LDFRAG
+#undef AMOS_WINO_MFMAS
+#undef AMOS_WINO_INTERLEAVE
+#undef AMOS_WINO_STAGE
+#undef AMOS_WINO_FETCH_U
+#undef AMOS_WINO_FETCH_X
 #undef AMOS_WINO_U
 #undef AMOS_WINO_V
 #undef AMOS_WINO_STASH

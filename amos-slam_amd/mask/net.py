@@ -51,6 +51,51 @@ def _gemm_conv(conv, x):
     return groups >= 600
 
 
+def _winograd_conv(conv, x):
+    """Should this convolution run as Winograd F(2 x 2, 3 x 3) on the fp32 MFMA units (amos_mask_winograd_conv_device)?  3 x 3, stride 1,
+    pad 1, cin % 8 == 0, cout % 64 == 0, and a launch of at least 256 work-groups of 64 tiles x 64 channels (one per CU).  Measured
+    on MI355X at 32 frames (tools/winograd_probe.py): 1.29 - 1.53 x the direct implicit GEMM on every such layer of the network.
+    AMOS_MASK_WINOGRAD=0 never, 1 by this rule (default), 2 wherever the kernel applies (tests)."""
+    mode = os.environ.get("AMOS_MASK_WINOGRAD", "1")
+    if mode == "0" or conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.padding != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1:
+        return False
+    from .. import mask_winograd_supported
+    if not mask_winograd_supported(conv.in_channels, conv.out_channels) or x.numel() * 4 >= 2 ** 31 - 4096:
+        return False
+    tiles = x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)
+    return mode == "2" or ((tiles + 63) // 64) * (conv.out_channels // 64) >= 256
+
+
+def _winograd_weight(conv):
+    """The layer's transformed weight G g G^T (16 x cin x cout floats in the kernel's staging layout), made on first use and kept on the
+    module; remade when the weight tensor changes (another storage or an in-place update)."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    cached = getattr(conv, "_amos_winograd", None)
+    if cached is None or cached[0] != key:
+        from .. import mask_winograd_weights
+        wl = w.detach().contiguous(memory_format=torch.channels_last)  # [cout][3][3][cin] in memory
+        u = torch.empty(16 * conv.in_channels * conv.out_channels, dtype=torch.float32, device=w.device)
+        mask_winograd_weights(torch.cuda.current_stream(w.device).cuda_stream, wl.data_ptr(), u.data_ptr(), conv.in_channels, conv.out_channels)
+        cached = (key, u)
+        object.__setattr__(conv, "_amos_winograd", cached)
+    return cached[1]
+
+
+def conv_raw(conv, x):
+    """The convolution alone (no bias): Winograd / implicit GEMM of this project where they apply, else the library."""
+    cl = torch.channels_last
+    if x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and x.is_contiguous(memory_format=cl) and conv.weight.dtype == torch.float32:
+        if _winograd_conv(conv, x):
+            from .. import mask_winograd_conv
+            b, _, h, w = x.shape
+            y = torch.empty((b, conv.out_channels, h, w), device=x.device, dtype=torch.float32, memory_format=cl)
+            mask_winograd_conv(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), _winograd_weight(conv).data_ptr(), None, None, y.data_ptr(),
+                               b, h, w, conv.in_channels, conv.out_channels, False)
+            return y
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
 def conv_bias_act(conv, x, relu, residual=None):
     """conv -> + bias -> (+ residual) -> (ReLU).  On the GPU with float32 channels-last activations the bias, the residual
     and the ReLU are ONE in-place pass by a HIP kernel of this project (amos_mask_bias_act_device) behind MIOpen's
@@ -59,6 +104,16 @@ def conv_bias_act(conv, x, relu, residual=None):
     Anywhere else (CPU tests, autocast) the plain torch ops run."""
     if x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and not torch.is_autocast_enabled():
         cl = torch.channels_last
+        if _winograd_conv(conv, x) and x.is_contiguous(memory_format=cl) and conv.weight.dtype == torch.float32 and (residual is None or (
+                residual.dtype == torch.float32 and residual.is_contiguous(memory_format=cl))):
+            from .. import mask_winograd_conv
+            b, _, h, w = x.shape
+            y = torch.empty((b, conv.out_channels, h, w), device=x.device, dtype=torch.float32, memory_format=cl)
+            if residual is not None and residual.shape != y.shape:
+                raise ValueError("conv_bias_act: residual shape %s, output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+            mask_winograd_conv(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), _winograd_weight(conv).data_ptr(), conv.bias.data_ptr(),
+                               residual.data_ptr() if residual is not None else None, y.data_ptr(), b, h, w, conv.in_channels, conv.out_channels, relu)
+            return y
         if _gemm_conv(conv, x) and x.is_contiguous(memory_format=cl) and conv.weight.dtype == torch.float32 and (
                 conv.weight.is_contiguous(memory_format=cl) or (conv.kernel_size == (1, 1) and conv.weight.is_contiguous())) and (residual is None or (
                 residual.dtype == torch.float32 and residual.is_contiguous(memory_format=cl))):
@@ -247,7 +302,7 @@ class SharedHead(nn.Module):
 
     def merge_output_layers(self):
         """Inference form: the three output convolutions read the same tensor, so they run as ONE 3 x 3 convolution with
-        12 + 243 + 96 (+ 1 zero filter: 352 = a multiple of 4 for the vector epilogue) output channels -- one pass over the
+        12 + 243 + 96 (+ 33 zero filters: 384 = a multiple of 64 for this project's convolution kernels) output channels -- one pass over the
         upfeature tensor and one launch instead of three, with better output-channel tiles than 12 or 243 give (measured
         on MI355X, 32 frames at 69 x 69: 2.09 ms against 0.40 + 1.63 + 0.78).  Same sums per channel; MIOpen may pick
         another solver for the wider layer, hence float32 rounding.  Built from the loaded weights: call after
@@ -255,7 +310,7 @@ class SharedHead(nn.Module):
         if getattr(self, "merged", None) is None:
             layers = (self.bbox_layer, self.conf_layer, self.mask_layer)
             n = sum(l.out_channels for l in layers)
-            pad = (-n) % 4
+            pad = (-n) % 64  # 351 -> 384: a multiple of 64, which the project's Winograd / GEMM kernels take (zero filters: 9 % more work than 352)
             merged = nn.Conv2d(FPN_FEATURES, n + pad, 3, padding=1).to(device=self.bbox_layer.weight.device, dtype=self.bbox_layer.weight.dtype)
             with torch.no_grad():
                 merged.weight.zero_()
@@ -286,7 +341,7 @@ class SharedHead(nn.Module):
         off = 0
         for x in pyramid:
             u = conv_bias_act(self.upfeature[0], x, True)
-            raw = F.conv2d(u, merged.weight, None, merged.stride, merged.padding)
+            raw = conv_raw(merged, u)
             if not raw.is_contiguous(memory_format=torch.channels_last):
                 raw = raw.contiguous(memory_format=torch.channels_last)
             cells = raw.shape[2] * raw.shape[3]
@@ -302,7 +357,7 @@ class SharedHead(nn.Module):
         x = conv_bias_act(self.upfeature[0], x, True)
         merged = getattr(self, "merged", None)
         if merged is not None:
-            y = conv_bias_act(merged, x, False).permute(0, 2, 3, 1)  # [b, h, w, 352]: channels last in memory, so this is a view
+            y = conv_bias_act(merged, x, False).permute(0, 2, 3, 1)  # [b, h, w, 384]: channels last in memory, so this is a view
             n0, n1, n2 = self.bbox_layer.out_channels, self.conf_layer.out_channels, self.mask_layer.out_channels
             loc = y[..., :n0].reshape(b, -1, 4)
             conf = y[..., n0:n0 + n1].reshape(b, -1, NUM_CLASSES)

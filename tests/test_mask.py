@@ -234,6 +234,22 @@ def test_network_on_the_project_gemm_vs_reference_gpu(mask, gpu_lib, monkeypatch
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
+def test_network_with_winograd_everywhere_vs_reference_gpu(mask, gpu_lib, monkeypatch, case):
+    """The golden tensors and the person-mask IoU with EVERY stride-1 3 x 3 convolution of the network forced onto the Winograd kernel (the
+    rule leaves the small launches of one frame to the other paths): same tolerances, same IoU bar."""
+    monkeypatch.setenv("AMOS_MASK_WINOGRAD", "2")
+    calls = []
+    real = gpu_lib.mask_winograd_conv
+    monkeypatch.setattr(gpu_lib, "mask_winograd_conv", lambda *a: (calls.append(a[7:11]), real(*a))[1])
+    assert _run(mask, "cuda", 5e-3, 5e-3, fold=True, case=case) >= 1 - 1e-3
+    # one forward: 13 bottleneck conv2 with stride 1, 3 FPN prediction layers, 4 protonet layers, 5 levels x (upfeature + merged head
+    # output); _run also calls the backbone and the FPN once more on their own
+    assert len(calls) == (13 + 3 + 4 + 10) + 13 + 3, len(calls)
+    assert {c[2:] for c in calls} >= {(64, 64), (128, 128), (256, 256), (512, 512), (256, 384)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
 def test_engine_end_to_end_gpu(mask, gpu_lib, case):
     eng = _engine(mask, "cuda:0", case)
     m = eng.eval_bgr(_frame(case))
@@ -433,6 +449,88 @@ def test_mfma_conv1x1_against_float64(mask, gpu_lib, monkeypatch):
     monkeypatch.delenv("AMOS_MASK_CONV3X3")
     with pytest.raises(RuntimeError):
         gpu_lib.mask_conv1x1(st, 0, 0, None, None, 0, 1, 8, 8, 64, 64, 1, True)
+
+
+@pytest.mark.gpu
+def test_winograd_conv3x3_against_float64(mask, gpu_lib):
+    """amos_mask_winograd_conv_device (Winograd F(2 x 2, 3 x 3) on the fp32 MFMA units: input transform, 16 GEMMs, output transform, bias +
+    residual + ReLU in one kernel) against a float64 convolution, to the bound the direct kernels are held to (1e-5 of the sum of
+    |terms|): odd and even image sizes (half-empty last tiles), images smaller than a tile block, tile blocks spanning frames, channel
+    counts from one stage (8) to many, every epilogue combination; and the transformed weight against G g G^T in float64."""
+    F = torch.nn.functional
+    cl = torch.channels_last
+    torch.manual_seed(11)
+    st = torch.cuda.current_stream().cuda_stream
+    assert gpu_lib.mask_winograd_supported(8, 64) and gpu_lib.mask_winograd_supported(256, 384)
+    assert not gpu_lib.mask_winograd_supported(4, 64) and not gpu_lib.mask_winograd_supported(64, 32) and not gpu_lib.mask_winograd_supported(64, 352)
+    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device="cuda")
+    worst = 0.0
+    for b, cin, cout, h, w in ((1, 8, 64, 6, 6), (2, 64, 64, 21, 17), (1, 32, 128, 9, 9), (3, 256, 64, 5, 5), (3, 16, 192, 12, 7), (2, 24, 64, 1, 1),
+                               (1, 64, 128, 2, 37), (5, 40, 64, 7, 3), (2, 128, 256, 35, 35), (1, 256, 384, 69, 69)):
+        x = torch.randn(b, cin, h, w, device="cuda").contiguous(memory_format=cl)
+        wgt = (torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5).contiguous(memory_format=cl)
+        bias = torch.randn(cout, device="cuda")
+        res = torch.randn(b, cout, h, w, device="cuda").contiguous(memory_format=cl)
+        u = torch.full((16 * cin * cout,), float("nan"), device="cuda")
+        gpu_lib.mask_winograd_weights(st, wgt.data_ptr(), u.data_ptr(), cin, cout)
+        # the transformed weight: image [cout tile][stage][position][64 rows][8, halves swapped when (row >> 3) & 1]
+        U = G @ wgt.double() @ G.T                                                                      # [cout][cin][4][4]
+        img = u.view(cout // 64, cin // 8, 16, 64, 2, 4)
+        swap = ((torch.arange(64, device="cuda") >> 3) & 1).bool()
+        img = torch.where(swap.view(1, 1, 1, 64, 1, 1), img.flip(4), img).reshape(cout // 64, cin // 8, 16, 64, 8)
+        want_img = U.view(cout // 64, 64, cin // 8, 8, 16).permute(0, 2, 4, 1, 3)
+        assert bool(((img.double() - want_img).abs() <= 6e-8 * want_img.abs() + 1e-30).all()), (cin, cout)   # one rounding of a double sum
+        exact = F.conv2d(x.double(), wgt.double(), None, 1, 1)
+        bound = 1e-5 * F.conv2d(x.double().abs(), wgt.double().abs(), None, 1, 1) + 1e-6
+        for use_bias, use_res, relu in ((True, True, True), (True, False, True), (False, True, False), (False, False, False), (True, False, False)):
+            y = torch.full((b, cout, h, w), float("nan"), device="cuda").contiguous(memory_format=cl)
+            gpu_lib.mask_winograd_conv(st, x.data_ptr(), u.data_ptr(), bias.data_ptr() if use_bias else None, res.data_ptr() if use_res else None, y.data_ptr(),
+                                       b, h, w, cin, cout, relu)
+            torch.cuda.synchronize()
+            want = exact + (bias.double().view(1, -1, 1, 1) if use_bias else 0) + (res.double() if use_res else 0)
+            if relu:
+                want = want.relu()
+            err = (y.double() - want).abs()
+            assert torch.isfinite(y).all() and bool((err <= bound).all()), (b, cin, cout, h, w, use_bias, use_res, relu, err.max().item())
+            worst = max(worst, float((err / bound).max()))
+    assert worst < 0.2   # measured 0.02: the transforms cost less rounding than the 9-tap sums save
+    with pytest.raises(RuntimeError):
+        gpu_lib.mask_winograd_conv(st, 0, 0, None, None, 0, 1, 8, 8, 64, 64, True)
+    # through the network's dispatch: the rule, both forced sides, the cached transformed weight following an in-place weight update
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    conv = torch.nn.Conv2d(64, 128, 3, padding=1).cuda().to(memory_format=cl)
+    big, small = torch.empty(32, 64, 69, 69, device="meta"), torch.empty(1, 64, 35, 35, device="meta")
+    assert net_mod._winograd_conv(conv, big) and not net_mod._winograd_conv(conv, small)
+    assert not net_mod._winograd_conv(torch.nn.Conv2d(64, 128, 3, padding=1, stride=2), big) and not net_mod._winograd_conv(torch.nn.Conv2d(64, 100, 3, padding=1), big)
+
+
+@pytest.mark.gpu
+def test_winograd_dispatch_and_weight_cache(mask, gpu_lib, monkeypatch):
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    F = torch.nn.functional
+    cl = torch.channels_last
+    torch.manual_seed(12)
+    conv = torch.nn.Conv2d(64, 128, 3, padding=1).cuda().to(memory_format=cl)
+    x = torch.randn(2, 64, 23, 31, device="cuda").contiguous(memory_format=cl)
+    res = torch.randn(2, 128, 23, 31, device="cuda").contiguous(memory_format=cl)
+    calls = []
+    real = gpu_lib.mask_winograd_conv
+    monkeypatch.setattr(gpu_lib, "mask_winograd_conv", lambda *a: (calls.append(a[7:11]), real(*a))[1])
+    with torch.no_grad():
+        for round_ in range(2):
+            want = (F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), 1, 1) + res.double()).relu()
+            bound = 1e-5 * F.conv2d(x.double().abs(), conv.weight.double().abs(), None, 1, 1) + 1e-6
+            outs = {}
+            for side in ("0", "2"):
+                monkeypatch.setenv("AMOS_MASK_WINOGRAD", side)
+                outs[side] = net_mod.conv_bias_act(conv, x, True, residual=res)
+            assert len(calls) == 2 * round_ + 1   # only the forced side called the kernel (conv_raw below adds one more per round)
+            for side, y in outs.items():
+                assert y.is_contiguous(memory_format=cl) and bool(((y.double() - want).abs() <= bound).all()), side
+            raw = net_mod.conv_raw(conv, x)     # the convolution alone (what the fused prediction head uses)
+            assert bool(((raw.double() - F.conv2d(x.double(), conv.weight.double(), None, 1, 1)).abs() <= bound).all())
+            conv.weight.mul_(0.5)               # an in-place update must refresh the cached transformed weight
+    assert len(calls) == 4
 
 
 @pytest.mark.gpu
