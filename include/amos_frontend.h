@@ -364,10 +364,10 @@ int amos_mask_conv1x1_supported(int cin, int cout, int stride);
  * and the bottlenecks' conv2 of yolact.py / backbone.py: 70 % of the network's multiply-accumulates) as Winograd F(2 x 2, 3 x 3) on the
  * fp32 MFMA units: 2.25 x fewer multiplies, float32 in and float32 accumulate; the result differs from the direct form by float32
  * rounding of the transforms (tests/test_mask.py holds both to the same bound against a float64 convolution).
- *   amos_mask_winograd_supported(cin, cout): AMOS_OK when cin % 8 == 0 and cout % 64 == 0.
+ *   amos_mask_winograd_supported(cin, cout): AMOS_OK when cin % 16 == 0, cin >= 32 and cout % 64 == 0.
  *   amos_mask_winograd_weight_floats(cin, cout): size of the transformed weight in floats (16 * cin * cout; 0 if unsupported).
  *   amos_mask_winograd_weights_device: d_w [cout][3][3][cin] (a channels-last Conv2d weight) -> d_u = G g G^T of every filter, laid
- *     out as the kernel stages it; once per layer.
+ *     out in the order the kernel's MFMA fragments are read; once per layer.
  *   amos_mask_winograd_conv_device: y = act(conv3x3(x, w) + bias (+ residual)); x [batch][h][w][cin] (below 2 GiB), y and residual
  *     [batch][h][w][cout], all 16-byte aligned; bias and residual may be NULL.  Asynchronous on `stream`. */
 int amos_mask_winograd_supported(int cin, int cout);

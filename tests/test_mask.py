@@ -456,29 +456,28 @@ def test_winograd_conv3x3_against_float64(mask, gpu_lib):
     """amos_mask_winograd_conv_device (Winograd F(2 x 2, 3 x 3) on the fp32 MFMA units: input transform, 16 GEMMs, output transform, bias +
     residual + ReLU in one kernel) against a float64 convolution, to the bound the direct kernels are held to (1e-5 of the sum of
     |terms|): odd and even image sizes (half-empty last tiles), images smaller than a tile block, tile blocks spanning frames, channel
-    counts from one stage (8) to many, every epilogue combination; and the transformed weight against G g G^T in float64."""
+    counts from four stages (32) to many, a tile run of 64 one-tile segments (70 frames of 2 x 2), every epilogue combination; and the transformed weight against G g G^T in float64."""
     F = torch.nn.functional
     cl = torch.channels_last
     torch.manual_seed(11)
     st = torch.cuda.current_stream().cuda_stream
-    assert gpu_lib.mask_winograd_supported(8, 64) and gpu_lib.mask_winograd_supported(256, 384)
-    assert not gpu_lib.mask_winograd_supported(4, 64) and not gpu_lib.mask_winograd_supported(64, 32) and not gpu_lib.mask_winograd_supported(64, 352)
+    assert gpu_lib.mask_winograd_supported(32, 64) and gpu_lib.mask_winograd_supported(256, 384)
+    assert not gpu_lib.mask_winograd_supported(16, 64) and not gpu_lib.mask_winograd_supported(40, 64) and not gpu_lib.mask_winograd_supported(64, 32)
+    assert not gpu_lib.mask_winograd_supported(64, 352)
     G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device="cuda")
     worst = 0.0
-    for b, cin, cout, h, w in ((1, 8, 64, 6, 6), (2, 64, 64, 21, 17), (1, 32, 128, 9, 9), (3, 256, 64, 5, 5), (3, 16, 192, 12, 7), (2, 24, 64, 1, 1),
-                               (1, 64, 128, 2, 37), (5, 40, 64, 7, 3), (2, 128, 256, 35, 35), (1, 256, 384, 69, 69)):
+    for b, cin, cout, h, w in ((1, 32, 64, 6, 6), (2, 64, 64, 21, 17), (1, 32, 128, 9, 9), (3, 256, 64, 5, 5), (3, 48, 192, 12, 7), (2, 32, 64, 1, 1),
+                               (1, 64, 128, 2, 37), (5, 80, 64, 7, 3), (70, 32, 64, 2, 2), (2, 128, 256, 35, 35), (1, 256, 384, 69, 69)):
         x = torch.randn(b, cin, h, w, device="cuda").contiguous(memory_format=cl)
         wgt = (torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5).contiguous(memory_format=cl)
         bias = torch.randn(cout, device="cuda")
         res = torch.randn(b, cout, h, w, device="cuda").contiguous(memory_format=cl)
         u = torch.full((16 * cin * cout,), float("nan"), device="cuda")
         gpu_lib.mask_winograd_weights(st, wgt.data_ptr(), u.data_ptr(), cin, cout)
-        # the transformed weight: image [cout tile][stage][position][64 rows][8, halves swapped when (row >> 3) & 1]
+        # the transformed weight in MFMA fragment order: [cout tile][stage][position][32-channel block][k half][32 channels][4]
         U = G @ wgt.double() @ G.T                                                                      # [cout][cin][4][4]
-        img = u.view(cout // 64, cin // 8, 16, 64, 2, 4)
-        swap = ((torch.arange(64, device="cuda") >> 3) & 1).bool()
-        img = torch.where(swap.view(1, 1, 1, 64, 1, 1), img.flip(4), img).reshape(cout // 64, cin // 8, 16, 64, 8)
-        want_img = U.view(cout // 64, 64, cin // 8, 8, 16).permute(0, 2, 4, 1, 3)
+        img = u.view(cout // 64, cin // 8, 16, 2, 2, 32, 4)
+        want_img = U.view(cout // 64, 2, 32, cin // 8, 2, 4, 16).permute(0, 3, 6, 1, 4, 2, 5)
         assert bool(((img.double() - want_img).abs() <= 6e-8 * want_img.abs() + 1e-30).all()), (cin, cout)   # one rounding of a double sum
         exact = F.conv2d(x.double(), wgt.double(), None, 1, 1)
         bound = 1e-5 * F.conv2d(x.double().abs(), wgt.double().abs(), None, 1, 1) + 1e-6
