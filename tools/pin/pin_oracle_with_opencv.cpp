@@ -1,6 +1,6 @@
 // pin_oracle_with_opencv.cpp -- turns "parity unpinned" into a one-command check WHERE OpenCV EXISTS.
 //
-// The oracle (oracle/orb_oracle.c) restates eight OpenCV 4.5 primitives from their published algorithms (SURVEY.md
+// The oracle (oracle/orb_oracle.c) restates OpenCV 4.5 primitives from their published algorithms (SURVEY.md
 // Appendix A) because OpenCV is not in the image this project is built in; every one sits behind one small function.
 // This program runs each of them beside the real library on seeded inputs and reports, per primitive, the first
 // mismatch (or "identical").  A mismatch localises the wrong recalled constant / rounding rule; all identical pins the
@@ -15,7 +15,10 @@
 #include <opencv2/core.hpp>
 #include <opencv2/features2d.hpp>
 #include <opencv2/imgproc.hpp>
+#include <opencv2/video/tracking.hpp>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -24,6 +27,8 @@
 extern "C" {
 #include "orb_oracle.h"
 void orc_bgr_to_lab(const uint8_t *src, size_t n_px, int blue_idx, uint8_t *dst);  // oracle/lk_oracle.c
+int orc_lk_track(const uint8_t *prev, size_t prev_stride, const uint8_t *next, size_t next_stride, int w, int h, const float *prev_pts, int n, int win,
+                 int max_level, int max_count, double epsilon, float min_eig_threshold, float *next_pts, uint8_t *status, float *err);  // oracle/lk_oracle.c
 }
 
 static int g_failures = 0;
@@ -166,6 +171,37 @@ int main()
         cv::Mat got(1000, 2, CV_32F);
         orc_undistort_points(pts.ptr<float>(), 1000, fx, fy, cx, cy, dist, 5, got.ptr<float>());
         report("undistortPoints (TUM1)", want, got);
+    }
+    // cv::calcOpticalFlowPyrLK as Tracking.cc:896 calls it: 22 x 22 window, maxLevel 5, 20 iterations / eps 0.01, default flags and
+    // minEigThreshold 1e-4.  The library accumulates the 2 x 2 system and the residual through the SIMD lanes of its build, so the
+    // last bits of the tracked positions belong to that binary: reported as identical / first mismatch like the others, plus the
+    // largest position difference in pixels so that "one ulp apart" can be told from "another algorithm".
+    {
+        const cv::Mat prev = textured(640, 480, 9);
+        cv::Mat next;
+        const cv::Mat shift = (cv::Mat_<double>(2, 3) << 1, 0, 3.25, 0, 1, -1.5);
+        cv::warpAffine(prev, next, shift, prev.size(), cv::INTER_LINEAR, cv::BORDER_REFLECT_101);
+        std::mt19937 rng(10);
+        std::vector<cv::Point2f> p0(1000), p1;
+        for (auto &p : p0) p = cv::Point2f((float)(rng() % 6400) / 10.f, (float)(rng() % 4800) / 10.f);
+        std::vector<uchar> st;
+        std::vector<float> er;
+        cv::calcOpticalFlowPyrLK(prev, next, p0, p1, st, er, cv::Size(22, 22), 5, cv::TermCriteria(cv::TermCriteria::COUNT | cv::TermCriteria::EPS, 20, 0.01));
+        cv::Mat want(1000, 2, CV_32F), got(1000, 2, CV_32F), wantSt(1000, 1, CV_8U), gotSt(1000, 1, CV_8U), wantEr(1000, 1, CV_32F), gotEr(1000, 1, CV_32F);
+        for (int i = 0; i < 1000; i++) {
+            want.at<float>(i, 0) = p1[i].x;
+            want.at<float>(i, 1) = p1[i].y;
+            wantSt.at<uchar>(i) = st[i];
+            wantEr.at<float>(i) = er[i];
+        }
+        orc_lk_track(prev.data, prev.step, next.data, next.step, 640, 480, &p0[0].x, 1000, 22, 5, 20, 0.01, 1e-4f, got.ptr<float>(), gotSt.data, gotEr.ptr<float>());
+        report("calcOpticalFlowPyrLK status", wantSt, gotSt);
+        report("calcOpticalFlowPyrLK positions", want, got);
+        report("calcOpticalFlowPyrLK error", wantEr, gotEr);
+        double worst = 0;
+        for (int i = 0; i < 1000; i++)
+            if (st[i] && gotSt.at<uchar>(i)) worst = std::max(worst, (double)std::max(std::fabs(want.at<float>(i, 0) - got.at<float>(i, 0)), std::fabs(want.at<float>(i, 1) - got.at<float>(i, 1))));
+        std::printf("%-34s largest position difference %.3g px\n", "calcOpticalFlowPyrLK", worst);
     }
     std::printf(g_failures ? "\n%d primitive(s) differ: the oracle is NOT pinned by this OpenCV build\n" : "\nall identical: the oracle is pinned to this OpenCV build\n", g_failures);
     return g_failures ? 1 : 0;
