@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_topk_rows_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_corners_create", "amos_corners_destroy", "amos_corners_stream", "amos_corners_good_features_device", "amos_corners_candidate_count", "amos_corners_subpix_device", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_topk_rows_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -671,3 +671,44 @@ class OrbMatcher:
     @property
     def stream(self):
         return self.L.amos_match_stream(self.m)
+
+
+class CornerDetector:
+    """amos_corners_*: cv::goodFeaturesToTrack (Harris) + cv::cornerSubPix of Tracking::GetSceneFlowObj (Tracking.cc:894-895) on
+    device-resident gray frames; the corners stay on the device (feed LkTracker.track_device)."""
+
+    def __init__(self, max_width=640, max_height=480, device=0, stream=None):
+        self.L = lib()
+        self.L.amos_corners_stream.restype = C.c_void_p
+        self.L.amos_corners_destroy.restype = None
+        h = C.c_void_p()
+        _check(self.L.amos_corners_create(C.c_int(device), C.c_void_p(stream), C.c_int(max_width), C.c_int(max_height), C.byref(h)), "amos_corners_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.amos_corners_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def stream(self):
+        return self.L.amos_corners_stream(self.h)
+
+    def good_features_device(self, gray_ptr, stride, width, height, xy_ptr, xy_capacity, count_ptr, max_corners=1000, quality=0.01, min_distance=8.0,
+                             harris_k=0.04, response_ptr=None):
+        _check(self.L.amos_corners_good_features_device(self.h, C.c_void_p(gray_ptr), C.c_size_t(stride), C.c_int(width), C.c_int(height), C.c_int(max_corners),
+                                                        C.c_double(quality), C.c_double(min_distance), C.c_double(harris_k), C.c_void_p(xy_ptr),
+                                                        C.c_int(xy_capacity), C.c_void_p(count_ptr), C.c_void_p(response_ptr)),
+               "amos_corners_good_features_device")
+
+    def candidate_count(self):
+        n = C.c_int(0)
+        _check(self.L.amos_corners_candidate_count(self.h, C.byref(n)), "amos_corners_candidate_count")
+        return n.value
+
+    def subpix_device(self, gray_ptr, stride, width, height, xy_ptr, count_ptr=None, n=0, win=10, max_count=20, epsilon=0.03):
+        _check(self.L.amos_corners_subpix_device(self.h, C.c_void_p(gray_ptr), C.c_size_t(stride), C.c_int(width), C.c_int(height), C.c_void_p(xy_ptr),
+                                                 C.c_void_p(count_ptr), C.c_int(n), C.c_int(win), C.c_int(max_count), C.c_double(epsilon)),
+               "amos_corners_subpix_device")

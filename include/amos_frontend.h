@@ -515,6 +515,27 @@ int amos_lk_track_device(amos_lk *k, const uint8_t *d_prev_gray, size_t prev_str
                          size_t next_stride, const float *d_prev_xy, int n, int max_count, double epsilon,
                          float min_eig_threshold, float *d_next_xy, uint8_t *d_status, float *d_err /* or NULL */);
 
+/* The corner source of Tracking::GetSceneFlowObj (Tracking.cc:894-895), resident on the device so that the corners go into
+ * amos_lk_track_device without a host round trip:
+ *   cv::goodFeaturesToTrack(imlast, prepoint, 1000, 0.01, 8, cv::Mat(), 3, true, 0.04)   -> amos_corners_good_features_device
+ *   cv::cornerSubPix(imlast, prepoint, Size(10, 10), Size(-1, -1), TermCriteria(ITER | EPS, 20, 0.03)) -> amos_corners_subpix_device
+ * Harris detector, blockSize 3, Sobel aperture 3, no mask (what the reference passes).  d_xy receives (x, y) pairs in the library's
+ * order (strongest first, equal responses: the later pixel first), d_count their number (<= max_corners, <= xy_capacity);
+ * d_response (or NULL) the Harris response plane [height][width].  amos_corners_subpix_device refines d_xy in place for the first
+ * *d_count points (d_count == NULL: n points).  Restated from OpenCV 4.5's published algorithms; PARITY UNPINNED like the other
+ * OpenCV-derived stages.  A frame with more than 65 536 local maxima above the quality threshold is truncated:
+ * amos_corners_candidate_count (synchronising) reports AMOS_ERR_CAPACITY then.  Asynchronous on the handle's stream. */
+typedef struct amos_corners amos_corners;
+int amos_corners_create(int device, void *stream, int max_width, int max_height, amos_corners **out);
+void amos_corners_destroy(amos_corners *c);
+void *amos_corners_stream(amos_corners *c);
+int amos_corners_good_features_device(amos_corners *c, const uint8_t *d_gray, size_t stride, int width, int height, int max_corners,
+                                      double quality_level, double min_distance, double harris_k, float *d_xy, int xy_capacity,
+                                      int *d_count, float *d_response /* or NULL */);
+int amos_corners_candidate_count(amos_corners *c, int *count);
+int amos_corners_subpix_device(amos_corners *c, const uint8_t *d_gray, size_t stride, int width, int height, float *d_xy,
+                               const int *d_count /* or NULL */, int n, int win, int max_count, double epsilon);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,7 @@ class OrbParams(C.Structure):
 
 
 def build_oracle():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("orb_oracle.c", "lk_oracle.c", "orb_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("orb_oracle.c", "lk_oracle.c", "corner_oracle.c", "orb_oracle.h")]
     if (not os.path.exists(ORACLE_SO)
             or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(s) for s in srcs if os.path.exists(s))):
         if os.path.exists(srcs[0]):
@@ -361,3 +361,40 @@ def bgr_to_lab(img, rgb_order=False):
     out = np.zeros_like(img)
     lib().orc_bgr_to_lab(_p(img), C.c_size_t(img.size // 3), C.c_int(2 if rgb_order else 0), _p(out))
     return out
+
+
+# ---- oracle/corner_oracle.c: goodFeaturesToTrack (Harris) + cornerSubPix, Tracking.cc:894-895
+
+def corner_harris(gray, k=0.04):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    out = np.zeros((h, w), np.float32)
+    lib().orc_corner_harris(_p(gray), C.c_size_t(gray.strides[0]), C.c_int(w), C.c_int(h), C.c_double(k), _p(out))
+    return out
+
+
+def good_features_to_track(gray, max_corners=1000, quality=0.01, min_distance=8.0, k=0.04, cap=20000, with_response=False):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    xy = np.zeros((cap, 2), np.float32)
+    resp = np.zeros((h, w), np.float32) if with_response else None
+    n = lib().orc_good_features_to_track(_p(gray), C.c_size_t(gray.strides[0]), C.c_int(w), C.c_int(h), C.c_int(max_corners), C.c_double(quality),
+                                         C.c_double(min_distance), C.c_double(k), _p(xy), C.c_int(cap), _p(resp))
+    return (xy[:n].copy(), resp) if with_response else xy[:n].copy()
+
+
+def corner_subpix(gray, xy, win=10, max_count=20, epsilon=0.03):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    out = np.ascontiguousarray(xy, np.float32).copy()
+    rc = lib().orc_corner_subpix(_p(gray), C.c_size_t(gray.strides[0]), C.c_int(w), C.c_int(h), _p(out), C.c_int(len(out)), C.c_int(win), C.c_int(max_count),
+                                 C.c_double(epsilon))
+    if rc != 0:
+        raise RuntimeError("orc_corner_subpix rc=%d" % rc)
+    return out
+
+
+def corner_subpix_mask(win=10):
+    m = np.zeros((2 * win + 1, 2 * win + 1), np.float32)
+    lib().orc_corner_subpix_mask(C.c_int(win), _p(m))
+    return m
