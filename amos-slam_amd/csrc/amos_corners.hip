@@ -2,8 +2,8 @@
 //     cv::goodFeaturesToTrack(imlast, prepoint, 1000, 0.01, 8, cv::Mat(), 3, true, 0.04);
 //     cv::cornerSubPix(imlast, prepoint, cv::Size(10, 10), cv::Size(-1, -1), cv::TermCriteria(ITER | EPS, 20, 0.03));
 // on the device, resident: the corners feed amos_lk_track_device without leaving HBM.  Restated from OpenCV 4.5's published
-// implementation (featureselect.cpp, corner.cpp, cornersubpix.cpp, samplers.cpp) like the CPU checker oracle/corner_oracle.c, whose
-// header lists the rules; PARITY UNPINNED like every OpenCV-derived stage.  What the tests pin is GPU == oracle,
+// implementation (featureselect.cpp, corner.cpp, cornersubpix.cpp, samplers.cpp) rule for rule like the project's CPU checker (whose
+// header lists them); PARITY UNPINNED like every OpenCV-derived stage.  What the tests pin is GPU == CPU checker,
 // bit for bit: responses, corner lists in order, refined positions.
 //
 //   k_harris            Sobel 3 x 3 (float, scaled smoothing taps) -> products -> 3 x 3 box sums (double, one rounding) -> response, and the

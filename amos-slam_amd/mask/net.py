@@ -51,19 +51,25 @@ def _gemm_conv(conv, x):
     return groups >= 600
 
 
-def _winograd_conv(conv, x):
-    """Should this convolution run as Winograd F(2 x 2, 3 x 3) on the fp32 MFMA units (amos_mask_winograd_conv_device)?  3 x 3, stride 1,
-    pad 1, cin % 8 == 0, cout % 64 == 0, and a launch of at least 256 work-groups of 64 tiles x 64 channels (one per CU).  Measured
-    on MI355X at 32 frames (tools/winograd_probe.py): 1.29 - 1.53 x the direct implicit GEMM on every such layer of the network.
-    AMOS_MASK_WINOGRAD=0 never, 1 by this rule (default), 2 wherever the kernel applies (tests)."""
+def winograd_rule(cin, cout, kernel, stride, padding, dilation, groups, batch, height, width):
+    """Does a convolution of this shape run as Winograd F(2 x 2, 3 x 3) on the fp32 MFMA units (amos_mask_winograd_conv_device)?  3 x 3,
+    stride 1, pad 1, channel counts the kernel takes, an input below 2 GiB, and a launch of at least 256 work-groups of 64 tiles x 64
+    channels (one per CU).  Measured on MI355X at 32 frames (tools/winograd_probe.py): 1.4 - 1.8 x the direct implicit GEMM on every
+    such layer of the network.  AMOS_MASK_WINOGRAD=0 never, 1 by this rule (default), 2 wherever the kernel applies (tests).
+    (bench.py asks the same function which layers to count at 16 instead of 36 multiplies per 2 x 2 outputs.)"""
     mode = os.environ.get("AMOS_MASK_WINOGRAD", "1")
-    if mode == "0" or conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.padding != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1:
+    if mode == "0" or tuple(kernel) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1) or tuple(dilation) != (1, 1) or groups != 1:
         return False
     from .. import mask_winograd_supported
-    if not mask_winograd_supported(conv.in_channels, conv.out_channels) or x.numel() * 4 >= 2 ** 31 - 4096:
+    if not mask_winograd_supported(cin, cout) or batch * height * width * cin * 4 >= 2 ** 31 - 4096:
         return False
-    tiles = x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)
-    return mode == "2" or ((tiles + 63) // 64) * (conv.out_channels // 64) >= 256
+    tiles = batch * ((height + 1) // 2) * ((width + 1) // 2)
+    return mode == "2" or ((tiles + 63) // 64) * (cout // 64) >= 256
+
+
+def _winograd_conv(conv, x):
+    return winograd_rule(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups,
+                         x.shape[0], x.shape[2], x.shape[3])
 
 
 def _winograd_weight(conv):

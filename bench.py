@@ -220,34 +220,49 @@ def dry_run(args):
 
 
 # --------------------------------------------------------------------------------------------- measurement
-def count_network_flops(torch, engine, batch):
-    """FLOPs (2 x multiply-accumulates) of ONE network forward per frame, counted from the shapes the convolutions
-    actually see: torch.nn.functional.conv2d is wrapped for one forward (every convolution of the network goes through it,
-    nn.Conv2d modules and the fused-epilogue path alike; the project's GEMM path is switched off for that forward)."""
+def count_network_flops(torch, engine, batch, frames_per_forward):
+    """FLOPs (2 x multiply-accumulates) of ONE network forward per frame, counted from the shapes the convolutions actually see:
+    torch.nn.functional.conv2d is wrapped for one forward with every project kernel switched off, so that every convolution of the
+    network goes through it.  Returns (direct, executed): `direct` counts every convolution at kh x kw multiplies per output and channel
+    pair (the figure every convolution library is quoted in); `executed` counts the layers that run as Winograd F(2 x 2, 3 x 3) at
+    `frames_per_forward` frames per launch (mask/net.py winograd_rule) at the 16 multiplies per 2 x 2 outputs the MFMA units really
+    perform (4 / 9 of direct; the transforms' additions and the half-empty last tiles of odd sizes are not counted)."""
+    import importlib
     import torch.nn.functional as F
-    total = [0]
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    total = {"direct": 0.0, "executed": 0.0}
     real = F.conv2d
 
-    def counting(x, w, *a, **k):
-        out = real(x, w, *a, **k)
-        total[0] += 2 * w.shape[1] * w.shape[2] * w.shape[3] * out.numel()  # weight [Cout, Cin / groups, kh, kw]
+    def counting(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
+        out = real(x, w, bias, stride, padding, dilation, groups)
+        f = 2.0 * w.shape[1] * w.shape[2] * w.shape[3] * out.numel()  # weight [Cout, Cin / groups, kh, kw]
+        pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+        os.environ["AMOS_MASK_WINOGRAD"] = rule_mode  # the rule as the timed run applies it (this forward itself runs no project kernel)
+        try:
+            wino = net_mod.winograd_rule(w.shape[1] * groups, w.shape[0], w.shape[2:], pair(stride), pair(padding), pair(dilation), groups,
+                                         frames_per_forward, x.shape[2], x.shape[3])
+        finally:
+            os.environ["AMOS_MASK_WINOGRAD"] = "0"
+        total["direct"] += f
+        total["executed"] += f * (16.0 / 36.0) if wino else f
         return out
 
     F.conv2d = counting
-    keep = {k: os.environ.get(k) for k in ("AMOS_MASK_CONV1X1", "AMOS_MASK_CONV3X3")}
-    for k in keep:  # for this one forward every layer goes through F.conv2d (the large ones run on the project's GEMM otherwise)
-        os.environ[k] = "0"
+    keep = {k: os.environ.get(k) for k in ("AMOS_MASK_CONV1X1", "AMOS_MASK_CONV3X3", "AMOS_MASK_WINOGRAD")}
+    rule_mode = keep["AMOS_MASK_WINOGRAD"] or "1"
     try:
+        for k in keep:  # for this one forward every layer goes through F.conv2d
+            os.environ[k] = "0"
         with torch.no_grad():
             engine._forward(torch.zeros((batch, 3, 550, 550), device=engine.device))
     finally:
         F.conv2d = real
         for k, v in keep.items():
             if v is None:
-                del os.environ[k]
+                os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    return total[0] / batch
+    return total["direct"] / batch, total["executed"] / batch
 
 
 def gemm_kernel_roofline(torch, amos, dev, frames):
@@ -397,7 +412,7 @@ def main():
         lanes.append(ln)
     cap = lanes[0].cap
 
-    engine, net_flops = None, None
+    engine, net_flops, net_flops_executed = None, None, None
     chunk = args.mask_chunk if args.mask_chunk > 0 else Bl
     if use_mask:
         mask_mod = importlib.import_module("amos_slam_amd.mask")
@@ -410,7 +425,7 @@ def main():
             b[1, 3] += 5.5
             head.copy_(b.view(-1).to(head.device))
         engine.prepare()  # fold the batch norms into the convolutions (inference form)
-        net_flops = count_network_flops(torch, engine, min(chunk, 4))
+        net_flops, net_flops_executed = count_network_flops(torch, engine, min(chunk, 4), chunk)
 
     def assign(nl, bl):
         """frames [li * bl, (li + 1) * bl) of the resident stream -> lane li"""
@@ -609,14 +624,19 @@ def main():
             n_fwd = (Bl + chunk - 1) // chunk
             net_ms = stage_ms.get("mask_pass", 0.0)
             step_s = elapsed / args.steps
-            tf = net_flops * B / step_s / 1e12  # every lane's forwards of one step over the step's wall time: the whole chip's rate
+            tf = net_flops_executed * B / step_s / 1e12  # every lane's forwards of one step over the step's wall time: the whole chip's rate
+            tf_direct = net_flops * B / step_s / 1e12
             out["roofline_mask"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                     "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_frame": int(net_flops),
+                                    "flops_per_frame_executed": int(net_flops_executed), "achieved_direct_equivalent": round(tf_direct, 2),
                                     "frames_per_step": B, "lanes": S, "lane_pass_ms": round(net_ms, 3), "frames_per_lane_pass": Bl,
                                     "forwards_per_lane_pass": n_fwd,
-                                    "note": "convolution FLOPs (2 x MAC, counted from the shapes of one forward) of all frames of a step / the step's wall "
-                                            "time, i.e. a lower bound of the convolution kernels' own rate: the step also holds the pre / post-processing, "
-                                            "the ORB kernels and the match.  lane_pass_ms = one lane's whole mask pass (events on its stream), lanes overlap."}
+                                    "note": "achieved / frac: convolution FLOPs AS EXECUTED on the MFMA units (2 x MAC; the stride-1 3 x 3 layers that run as "
+                                            "Winograd F(2x2,3x3) counted at 16 instead of 36 multiplies per 2 x 2 outputs: flops_per_frame_executed) of all frames "
+                                            "of a step / the step's wall time, i.e. a lower bound of the convolution kernels' own rate: the step also holds the "
+                                            "pre / post-processing, the ORB kernels and the match.  flops_per_frame / achieved_direct_equivalent: the same "
+                                            "layers counted as direct convolutions (the figure comparable with a direct-convolution implementation; it may "
+                                            "exceed the peak).  lane_pass_ms = one lane's whole mask pass (events on its stream), lanes overlap."}
             if args.mask_conv_dtype == "fp32":
                 out["roofline_mask"]["dominant_kernel"] = gemm_kernel_roofline(torch, pkg, torch.device(dev), chunk)
         if em:

@@ -53,7 +53,9 @@ def test_default_run_is_the_baseline_metric_with_the_mask(gpu_lib):
     assert abs(leg["value"] - 64 * 3 / (leg["ms_per_step"] * 3 * 1e-3)) / leg["value"] < 0.01
     m = d["roofline_mask"]
     assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and m["peak"] == 157.3 and 0 < m["frac"] < 1
-    assert 1.0e11 < m["flops_per_frame"] < 1.4e11  # YOLACT-R50 at 550 x 550: 59 G multiply-accumulates
+    assert 1.0e11 < m["flops_per_frame"] < 1.4e11  # YOLACT-R50 at 550 x 550: 59 G multiply-accumulates, counted as direct convolutions
+    assert 0.5 * m["flops_per_frame"] < m["flops_per_frame_executed"] <= m["flops_per_frame"]  # Winograd layers at 4 / 9 (few of them at 8 frames per launch)
+    assert abs(m["achieved_direct_equivalent"] / m["achieved"] - m["flops_per_frame"] / m["flops_per_frame_executed"]) < 0.01
     assert d["stage_ms_per_launch"]["mask_pass"] > 0
     k = m["dominant_kernel"]  # the project's conv GEMM on the largest layer, live
     assert "k_conv_gemm" in k["kernel"] and k["bound"] == "mfma" and k["peak"] == 157.3 and 0.3 < k["frac"] < 1.0
