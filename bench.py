@@ -265,10 +265,15 @@ def count_network_flops(torch, engine, batch, frames_per_forward):
     return total["direct"] / batch, total["executed"] / batch
 
 
-def gemm_kernel_roofline(torch, amos, dev, frames):
-    """The dominant kernel of the mask pass against the fp32 MFMA peak, measured live: amos::k_conv_gemm on the network's largest layer
-    (proto_net[8]: 3 x 3, 256 -> 256 channels at 138 x 138, `frames` frames per launch) through the C ABI, after the timed region (the chip
-    is otherwise idle), HIP events on the stream the kernel is launched on.  FLOPs = 2 x output pixels x cout x 9 x cin."""
+def conv_kernel_roofline(torch, amos, dev, frames):
+    """The dominant kernel of the mask pass against the fp32 MFMA peak, measured live: the project's convolution kernel on the network's
+    largest layer (proto_net[8]: 3 x 3, 256 -> 256 channels at 138 x 138, `frames` frames per launch) through the C ABI, after the timed
+    region (the chip is otherwise idle), HIP events on the stream the kernel is launched on.  At the bench's launch sizes that layer runs
+    as Winograd F(2 x 2, 3 x 3) (amos::k_winograd_conv): FLOPs AS EXECUTED = 2 x 16 positions x tiles x cin x cout with tiles =
+    frames x 69 x 69 (4 / 9 of the direct convolution's 2 x output pixels x cout x 9 x cin, reported beside it); a launch too small
+    for the Winograd rule runs the direct implicit GEMM (amos::k_conv_gemm) and the two figures coincide."""
+    import importlib
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
     cl = torch.channels_last
     cin = cout = 256
     hw = 138
@@ -277,10 +282,20 @@ def gemm_kernel_roofline(torch, amos, dev, frames):
     b = torch.zeros(cout, device=dev)
     y = torch.empty(frames, cout, hw, hw, device=dev).contiguous(memory_format=cl)
     stream = torch.cuda.current_stream(dev)
+    wino = net_mod.winograd_rule(cin, cout, (3, 3), (1, 1), (1, 1), (1, 1), 1, frames, hw, hw)
+    if wino:
+        u = torch.empty(16 * cin * cout, device=dev)
+        amos.mask_winograd_weights(stream.cuda_stream, w.data_ptr(), u.data_ptr(), cin, cout)
 
-    def launch():
-        amos.mask_conv(stream.cuda_stream, x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, 3, 3, 1, 1, True)
-
+        def launch():
+            amos.mask_winograd_conv(stream.cuda_stream, x.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, True)
+        name = "amos::k_winograd_conv"
+        flops = 2.0 * 16 * frames * ((hw + 1) // 2) ** 2 * cin * cout
+    else:
+        def launch():
+            amos.mask_conv(stream.cuda_stream, x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, 3, 3, 1, 1, True)
+        name = amos.mask_conv_kernel_name(frames, hw, hw, cin, cout, 3, 3, 1, 1)  # the tile shape depends on the launch size
+        flops = 2.0 * frames * hw * hw * cout * 9 * cin
     for _ in range(3):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -291,12 +306,12 @@ def gemm_kernel_roofline(torch, amos, dev, frames):
     e1.record(stream)
     e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * frames * hw * hw * cout * 9 * cin
+    direct = 2.0 * frames * hw * hw * cout * 9 * cin
     tf = flops / (ms * 1e-3) / 1e12
-    name = amos.mask_conv_kernel_name(frames, hw, hw, cin, cout, 3, 3, 1, 1)  # the tile shape depends on the launch size
     return {"kernel": name + " (proto_net 3x3 256->256 at 138x138: the largest launch of the pass)", "bound": "mfma",
             "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
-            "flops_per_launch": int(flops), "frames_per_launch": frames, "avg_launch_ms": round(ms, 4),
+            "flops_per_launch": int(flops), "direct_convolution_flops_per_launch": int(direct),
+            "achieved_direct_equivalent": round(direct / (ms * 1e-3) / 1e12, 2), "frames_per_launch": frames, "avg_launch_ms": round(ms, 4),
             "measured_in": "after the timed region, the kernel alone on the chip, HIP events on the launching stream (10 launches)"}
 
 
@@ -638,7 +653,7 @@ def main():
                                             "layers counted as direct convolutions (the figure comparable with a direct-convolution implementation; it may "
                                             "exceed the peak).  lane_pass_ms = one lane's whole mask pass (events on its stream), lanes overlap."}
             if args.mask_conv_dtype == "fp32":
-                out["roofline_mask"]["dominant_kernel"] = gemm_kernel_roofline(torch, pkg, torch.device(dev), chunk)
+                out["roofline_mask"]["dominant_kernel"] = conv_kernel_roofline(torch, pkg, torch.device(dev), chunk)
         if em:
             st = em["stage_ms"]
             alg = algorithmic_bytes(lw, lh, em["mean_kp"], W, H)
