@@ -40,6 +40,10 @@ constexpr int kWinoTiles = 64;    // tiles per work-group (rows of the 16 GEMMs)
 constexpr int kWinoCout = 64;     // output channels per work-group
 constexpr int kWinoK = 8;         // input channels per stage
 constexpr int kWinoThreads = 512;
+#ifndef AMOS_WINO_GROUP
+#define AMOS_WINO_GROUP 32
+#endif
+constexpr int kWinoGroup = AMOS_WINO_GROUP;  // consecutive work-groups of an XCD that share a cout tile (experiments: tools/wino_variants.sh G<n>)
 constexpr int kWinoStageU = 16 * kWinoCout * kWinoK;   // floats of one stage's U image (32 KB)
 constexpr int kWinoStageV = 16 * kWinoTiles * kWinoK;  // floats of one stage's V tile (32 KB)
 constexpr int kWinoRawCols = 256;                      // columns of the raw patch (64 tiles in up to 64 one-tile segments: 2 x 64 + 2 x 64)
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
     // id -> (m block, n tile): ids are dealt round-robin over the 8 XCDs; on an XCD, 32 consecutive work-groups (one per CU) share the
     // n tile, i.e. the 1 MB weight slice that stays in that XCD's L2, and walk 32 m blocks; the next 32 take the next n tile
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-    constexpr int kGroup = 32;
+    constexpr int kGroup = kWinoGroup;
     const int per = kGroup * a.nTiles, grp = seq / per, in = seq - grp * per;
     const int nt = in / kGroup, mb = (grp * kGroup + in % kGroup) * 8 + xcd;
     if (mb >= a.mBlocks) return;
@@ -424,9 +428,9 @@ int amos_mask_winograd_conv_device(void *stream, const float *d_x, const float *
     a.stages = cin / kWinoK;
     a.relu = relu;
     a.xBytes = (unsigned)xBytes;
-    // ids: 8 XCDs x groups of (32 m blocks x nTiles); the last group may be partly empty (those work-groups return at once)
-    const int perXcd = (a.mBlocks + 7) / 8, groups = (perXcd + 31) / 32;
-    const dim3 grid((unsigned)(groups * 32 * a.nTiles * 8)), block(kWinoThreads);
+    // ids: 8 XCDs x groups of (kWinoGroup m blocks x nTiles); the last group may be partly empty (those work-groups return at once)
+    const int perXcd = (a.mBlocks + 7) / 8, groups = (perXcd + kWinoGroup - 1) / kWinoGroup;
+    const dim3 grid((unsigned)(groups * kWinoGroup * a.nTiles * 8)), block(kWinoThreads);
     hipLaunchKernelGGL(k_winograd_conv, grid, block, lds, (hipStream_t)stream, a);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;

@@ -6,7 +6,11 @@ cd "$(dirname "$0")/../amos-slam_amd/csrc"
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form=1"
 OBJS=$(ls build/amos_*.o | grep -v amos_winograd)
 for v in "$@"; do
-  /opt/rocm/bin/hipcc $FLAGS -DAMOS_WINO_EXP_$v -c -o build/wino_$v.o amos_winograd.hip
+  case $v in
+    G*) DEF="-DAMOS_WINO_GROUP=${v#G}";;   # G1, G4, ...: work-groups of an XCD that share a cout tile back to back
+    *) DEF="-DAMOS_WINO_EXP_$v";;
+  esac
+  /opt/rocm/bin/hipcc $FLAGS $DEF -c -o build/wino_$v.o amos_winograd.hip
   /opt/rocm/bin/hipcc $FLAGS -shared -o build/libamos_frontend_$v.so $OBJS build/wino_$v.o 2>/dev/null
   echo built $v
 done
