@@ -53,6 +53,13 @@ constexpr int kWinoStageR = 4 * kWinoRawRow;           // floats of one raw patc
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef AMOS_WINO_EXP_TIMING  // experiment build (tools/wino_variants.sh TIMING, tools/wino_timing.py): per-wave cycle sums of the stage's phases
+__device__ unsigned long long *g_wino_timing = nullptr;  // [work-group][wave][8]: first half, wait + barrier, second half, stages, prologue + loop, epilogue, start
+#define AMOS_WINO_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime();
+#else
+#define AMOS_WINO_T(var)
+#endif
+
 struct WinoArgs {
     const float *x, *u, *bias, *res;
     float *y;
@@ -143,7 +150,10 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
         }
         if (tl >= nT) colBase = 0;  // tiles past the end of the tensor: any valid patch position (their results are not stored)
     }
-    const bool loads = 32 * wave < nCols;  // wave-uniform: this wave's column block holds pixels of the run
+    // (every wave issues its four LDS-DMA requests, also when its column block lies past the run's columns -- out-of-range offsets, zeros, no
+    // memory traffic: the compiler counts vector-memory operations per code path when it places the waits for the U loads, and a branch
+    // around the requests made it assume the shorter path)
+    (void)nCols;
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.xBytes, 0x00020000);
     typedef __attribute__((address_space(3))) void *LdsPtr;
     // the transformer's eight reads: rows (r0, r1) of B^T d B row `prow` (0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3), columns colBase + c
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
 #define AMOS_WINO_FETCH_X(s, buf) {}
 #else
 #define AMOS_WINO_FETCH_X(s, buf)                                                                                                    \
-    if (loads) {                                                                                                                     \
+    {                                                                                                                                \
         _Pragma("unroll") for (int r = 0; r < 4; r++)                                                                                \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (LdsPtr)(AMOS_WINO_R(buf) + r * kWinoRawRow + wave * 256), 16, xoff[r], (s) * (kWinoK * 4), 0, 0); \
     }
@@ -251,8 +261,14 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
 #else
 #define AMOS_WINO_BARRIER(kVm) asm volatile("s_waitcnt vmcnt(" #kVm ") lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
+#ifdef AMOS_WINO_EXP_TIMING
+#define AMOS_WINO_TSUM tsum0 += tb - ta; tsum1 += tc - tb; tsum2 += td - tc; tsum3 += 1;
+#else
+#define AMOS_WINO_TSUM
+#endif
 #define AMOS_WINO_STAGE(s, vb, fbC0, fbC1, fbN1, kNext, kNext2, kNext3, kVm)              \
     {                                                                                     \
+        AMOS_WINO_T(ta)                                                                   \
         AMOS_WINO_LDFRAG(fa1, vb, 1);                                                     \
         if (kNext) AMOS_WINO_TRANSFORM((vb) ^ 1, (vb) ^ 1);                               \
         if (kNext) AMOS_WINO_FETCH_U(fbN1, (s) + 1, 1);                                   \
@@ -272,7 +288,9 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
         }                                                                                 \
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                               \
         __builtin_amdgcn_sched_barrier(0);                                                \
+        AMOS_WINO_T(tb)                                                                   \
         AMOS_WINO_BARRIER(kVm)                                                            \
+        AMOS_WINO_T(tc)                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                \
         if (kNext) AMOS_WINO_LDFRAG(fa0, (vb) ^ 1, 0);                                    \
         if (kNext3) AMOS_WINO_FETCH_X((s) + 3, (vb) ^ 1);                                 \
@@ -282,10 +300,16 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
         AMOS_WINO_INTERLEAVE(0x020, 6, 1);                                                \
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                               \
         __builtin_amdgcn_sched_barrier(0);                                                \
+        AMOS_WINO_T(td)                                                                   \
+        AMOS_WINO_TSUM                                                                    \
     }
 #define AMOS_WINO_STAGE_EVEN(s, n1, n2, n3, vm) AMOS_WINO_STAGE(s, 0, fbE0, fbE1, fbO1, n1, n2, n3, vm)
 #define AMOS_WINO_STAGE_ODD(s, n1, n2, n3, vm) AMOS_WINO_STAGE(s, 1, fbO0, fbO1, fbE1, n1, n2, n3, vm)
 
+#ifdef AMOS_WINO_EXP_TIMING
+    unsigned long long tsum0 = 0, tsum1 = 0, tsum2 = 0, tsum3 = 0;
+    const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+#endif
     // prologue: raw patches of stages 0 and 1; U of stage 0 (both positions) and of stage 1 (position 0)
     AMOS_WINO_FETCH_X(0, 0);
     AMOS_WINO_FETCH_X(1, 1);
@@ -310,6 +334,9 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
     AMOS_WINO_STAGE_ODD(s + 3, false, false, false, 0);
 #undef AMOS_WINO_STAGE_EVEN
 #undef AMOS_WINO_STAGE_ODD
+#ifdef AMOS_WINO_EXP_TIMING
+    const unsigned long long tloop = __builtin_amdgcn_s_memtime();
+#endif
 #undef AMOS_WINO_LDFRAG
 #undef AMOS_WINO_MFMAS
 #undef AMOS_WINO_INTERLEAVE
@@ -372,6 +399,12 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
                 }
         }
     }
+#ifdef AMOS_WINO_EXP_TIMING
+    if (g_wino_timing && lane == 0 && blockIdx.x < 4096) {
+        unsigned long long *o = g_wino_timing + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = tsum0; o[1] = tsum1; o[2] = tsum2; o[3] = tsum3; o[4] = tloop - tstart; o[5] = __builtin_amdgcn_s_memtime() - tloop; o[6] = tstart;
+    }
+#endif
 }
 
 }  // namespace amos
@@ -379,6 +412,14 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
 using namespace amos;
 
 extern "C" {
+
+#ifdef AMOS_WINO_EXP_TIMING
+int amos_mask_winograd_timing_buffer(unsigned long long *d_buf)  // 4096 x 8 x 8 values, or NULL
+{
+    AMOS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_wino_timing), &d_buf, sizeof(d_buf)));
+    return AMOS_OK;
+}
+#endif
 
 int amos_mask_winograd_supported(int cin, int cout)
 {
