@@ -71,9 +71,10 @@ struct WinoArgs {
 
 // V tile: element (row, k) of a 64-row position block lives at float offset row * 8 + 4 * ((k >> 2) ^ f(row)) + (k & 3)
 __device__ __host__ __forceinline__ int wino_swz(int row, int half) { return row * 8 + 4 * (half ^ (((row >> 2) ^ (row >> 3)) & 1)); }
-// raw patch: 16-byte unit of (column, channel quad) inside a patch row -- blocks of 32 columns, inside a block [quad][column parity][column / 2]:
-// one LDS-DMA instruction fills a block lane-linearly, and the transform's reads (consecutive tiles = every second column) are conflict-free
-__device__ __forceinline__ int wino_raw_unit(int col, int quad) { return (col >> 5) * 64 + quad * 32 + (col & 1) * 16 + ((col & 31) >> 1); }
+// raw patch: 16-byte unit of (column, channel quad) inside a patch row -- blocks of 32 columns, inside a block [column parity][column / 2][quad]:
+// one LDS-DMA instruction fills a block lane-linearly with lane pairs fetching the two quads of one pixel (32 contiguous bytes), and the
+// transform's reads (lanes = consecutive tiles x both quads: every second column) are conflict-free
+__device__ __forceinline__ int wino_raw_unit(int col, int quad) { return (col >> 5) * 64 + (col & 1) * 32 + ((col & 31) >> 1) * 2 + quad; }
 
 // Weights [cout][3][3][cin] (a channels-last Conv2d weight) -> U = G g G^T in the order the MFMA's B fragments are read: for every
 // (cout tile nt, stage s, position p, 32-channel block j) 64 lanes x 4 floats, lane l = U_p[nt * 64 + j * 32 + (l & 31)][s * 8 + 4 (l >> 5) ..+3];
@@ -118,10 +119,10 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
     // ---- geometry of the work-group's tile run: segments of tiles of one tile row.  This thread is (a) the loader of raw-patch column
-    // `col` (block `wave`, lane order [quad][parity][half]) for all four patch rows and (b) the transformer of tile `tl`, channel quad
+    // `col` (block `wave`, lane order [parity][half][quad]) for all four patch rows and (b) the transformer of tile `tl`, channel quad
     // `quad`, position row `prow`.
-    const int quad = lane >> 5, tl = (lane & 31) + 32 * (wave & 1), prow = wave >> 1;
-    const int col = 32 * wave + 2 * (lane & 15) + ((lane >> 4) & 1);
+    const int quad = lane & 1, tl = (lane >> 1) + 32 * (wave & 1), prow = wave >> 1;
+    const int col = 32 * wave + 2 * ((lane >> 1) & 15) + (lane >> 5);
     int xoff[4];     // loader: byte offset of (patch row r, column col, channel quad) in x, or the buffer's size (zeros) when there is no such pixel
     int colBase = 0; // transformer: first patch column of tile tl
     int nCols = 0;   // columns the run occupies (wave-uniform)
