@@ -195,6 +195,29 @@ def test_static_shape_batch_post_equals_reference_order_post(mask):
     assert not bool(f0_[0]) and int(m0.sum()) == 0
 
 
+def test_winograd_rule(mask, pkg, monkeypatch):
+    """Which convolutions go to the Winograd kernel (mask/net.py winograd_rule; bench.py counts the executed FLOPs with the same function):
+    3 x 3 / stride 1 / pad 1, cin % 16 == 0 from 32 up, cout % 64 == 0, at least 256 work-groups of 64 tiles x 64 channels.  Host logic only."""
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    rule = lambda cin, cout, b, hw, k=(3, 3), s=(1, 1), p=(1, 1): net_mod.winograd_rule(cin, cout, k, s, p, (1, 1), 1, b, hw, hw)
+    monkeypatch.delenv("AMOS_MASK_WINOGRAD", raising=False)
+    assert rule(256, 256, 32, 138) and rule(256, 384, 32, 69) and rule(64, 64, 32, 138) and rule(512, 512, 32, 18) and rule(256, 256, 1, 138)
+    assert not rule(256, 256, 1, 69)                    # 20 x 4 work-groups: too small a launch for one per CU
+    assert not rule(256, 256, 32, 138, s=(2, 2)) and not rule(256, 256, 32, 138, k=(1, 1), p=(0, 0)) and not rule(256, 256, 32, 138, p=(0, 0))
+    assert not rule(256, 352, 32, 69) and not rule(24, 64, 32, 138) and not rule(16, 64, 32, 138)   # channel counts the kernel does not take
+    assert not rule(2048, 64, 64, 138)                  # input of 2 GiB and more: the buffer descriptor's range
+    monkeypatch.setenv("AMOS_MASK_WINOGRAD", "2")
+    assert rule(256, 256, 1, 69) and not rule(256, 352, 1, 69)
+    monkeypatch.setenv("AMOS_MASK_WINOGRAD", "0")
+    assert not rule(256, 256, 32, 138)
+    assert pkg.mask_winograd_supported(32, 64) and not pkg.mask_winograd_supported(8, 64)
+    # the merged prediction-head output layer is padded to a channel count the kernels take
+    head = net_mod.SharedHead()
+    head.merge_output_layers()
+    assert head.merged.out_channels == 384 and float(head.merged.weight[351:].abs().sum()) == 0.0 and float(head.merged.bias[351:].abs().sum()) == 0.0
+    assert torch.equal(head.merged.weight[:12], head.bbox_layer.weight) and torch.equal(head.merged.weight[12:255], head.conf_layer.weight)
+
+
 def test_no_detection_returns_none(mask):
     eng = mask.MaskEngine(device="cpu", seed=1)  # unbiased random weights: softmax ~ 1/81 < 0.05
     assert eng.eval_bgr(_frame()) is None
