@@ -786,3 +786,35 @@ def test_mask_pass_as_one_hip_graph_equals_the_eager_pass(mask, gpu_lib):
         assert torch.equal(torch.where(found[:, None, None], masks, torch.zeros_like(masks)), want)
     with pytest.raises(RuntimeError):
         eng.eval_bgr_graph(frames[:1])
+
+
+@pytest.mark.gpu
+def test_bench_sized_pass_winograd_against_direct_kernels(mask, gpu_lib, monkeypatch):
+    """The mask pass at the bench's launch size (32 frames per forward: the dispatch rule sends every large stride-1 3 x 3 layer to the
+    Winograd kernel, the work-group grid spans frames and XCD groups) against the same pass with the Winograd kernel switched off:
+    the same detections and person masks, network outputs within float32 rounding of each other."""
+    frames = torch.from_numpy(np.stack([mask_cases.frame(c) for c in ("seed0", "ref122_w0", "tum_w0", "blobs7_w1")] * 8)).cuda()
+    frames[16:] = frames[16:].flip(2)   # second half mirrored: 32 different inputs from four sources
+    eng = _engine(mask, "cuda:0", "seed0")
+    eng.prepare()
+    calls = []
+    real = gpu_lib.mask_winograd_conv
+    monkeypatch.setattr(gpu_lib, "mask_winograd_conv", lambda *a: (calls.append(a[6:11]), real(*a))[1])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AMOS_MASK_WINOGRAD", mode)
+        x = eng._preprocess_hip(frames)
+        with torch.no_grad():
+            pred = eng._forward(x)
+        out[mode] = (pred, eng.eval_net_input_batch(x, chunk=32))
+        torch.cuda.synchronize()
+    # per forward at 32 frames: 13 bottleneck conv2, the FPN prediction layers and the head's two convolutions at 69 x 69 and 35 x 35 (the
+    # 18 x 18 launches have fewer than 256 work-groups), 4 protonet layers; two forwards in this mode (_forward and eval_net_input_batch)
+    assert len(calls) == 2 * (13 + 2 + 4 + 4) and all(c[0] == 32 for c in calls), len(calls)
+    for k in ("loc", "conf", "mask", "proto"):
+        a, b = out["1"][0][k], out["0"][0][k]
+        assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1.0), k
+    m1, m0 = out["1"][1] > 0, out["0"][1] > 0
+    assert int(m0.sum()) > 32 * 5000
+    for f in range(32):
+        assert _iou(m1[f].cpu().numpy(), m0[f].cpu().numpy()) >= 1 - 1e-3, f
