@@ -479,7 +479,7 @@ def test_winograd_conv3x3_against_float64(mask, gpu_lib):
     """amos_mask_winograd_conv_device (Winograd F(2 x 2, 3 x 3) on the fp32 MFMA units: input transform, 16 GEMMs, output transform, bias +
     residual + ReLU in one kernel) against a float64 convolution, to the bound the direct kernels are held to (1e-5 of the sum of
     |terms|): odd and even image sizes (half-empty last tiles), images smaller than a tile block, tile blocks spanning frames, channel
-    counts from four stages (32) to many, a tile run of 32 two-tile segments (40 frames of 2 x 4), launches of 600 - 1 200 work-groups, every epilogue combination; and the transformed weight against G g G^T in float64."""
+    counts from four stages (32) to many, tile runs of 32 two-tile and 64 one-tile segments (40 frames of 2 x 4, 70 of 2 x 2), launches of 600 - 1 200 work-groups, every epilogue combination; and the transformed weight against G g G^T in float64."""
     F = torch.nn.functional
     cl = torch.channels_last
     torch.manual_seed(11)
@@ -490,7 +490,7 @@ def test_winograd_conv3x3_against_float64(mask, gpu_lib):
     G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device="cuda")
     worst = 0.0
     for b, cin, cout, h, w in ((1, 32, 64, 6, 6), (2, 64, 64, 21, 17), (1, 32, 128, 9, 9), (3, 256, 64, 5, 5), (3, 48, 192, 12, 7), (2, 32, 64, 1, 1),
-                               (1, 64, 128, 2, 37), (5, 80, 64, 7, 3), (40, 32, 64, 2, 4), (2, 128, 256, 35, 35), (1, 256, 384, 69, 69),
+                               (1, 64, 128, 2, 37), (5, 80, 64, 7, 3), (40, 32, 64, 2, 4), (70, 32, 64, 2, 2), (3, 32, 64, 1, 1), (2, 128, 256, 35, 35), (1, 256, 384, 69, 69),
                                (8, 64, 64, 138, 138), (4, 32, 128, 138, 138)):   # the last two: several groups of 32 work-groups per XCD, the last one partly empty
         x = torch.randn(b, cin, h, w, device="cuda").contiguous(memory_format=cl)
         wgt = (torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5).contiguous(memory_format=cl)
