@@ -44,6 +44,10 @@ def _gemm_conv(conv, x):
         groups = ((m + 127) // 128) * (conv.out_channels // 64)  # the library then runs 128 x 64 tiles (amos_mask_conv_device)
     if k != (1, 1) or conv.padding != (0, 0):
         mode3 = os.environ.get("AMOS_MASK_CONV3X3", "1")  # "0" never, "1" by the rule, "2" wherever the kernel applies (tests)
+        if groups < 1024 and s >= 2:
+            # strided layers (the stride-1 ones belong to the Winograd kernel): the 128 x 64 tiles the library then runs tie with MIOpen + the
+            # epilogue pass from 1 024 work-groups on (256 ch, 69 -> 35 at 32 frames: 0.417 against 0.422 ms, tools/conv_gemm_probe.py)
+            groups = ((m + 127) // 128) * (conv.out_channels // 64)
         return mode3 != "0" and (groups >= 1024 or mode3 == "2") and conv.weight.is_contiguous(memory_format=torch.channels_last)
     mode = os.environ.get("AMOS_MASK_CONV1X1", "auto")
     if mode in ("0", "1"):

@@ -467,6 +467,9 @@ def test_mfma_conv1x1_against_float64(mask, gpu_lib, monkeypatch):
     c3 = torch.nn.Conv2d(64, 64, 3, padding=1).to(memory_format=cl)
     assert net_mod._gemm_conv(c3, big) and not net_mod._gemm_conv(c3, small)
     assert not net_mod._gemm_conv(torch.nn.Conv2d(256, 243, 3, padding=1).to(memory_format=cl), torch.empty(32, 256, 69, 69, device="meta"))  # 243 channels
+    s2 = torch.nn.Conv2d(256, 256, 3, padding=1, stride=2).to(memory_format=cl)
+    assert net_mod._gemm_conv(s2, torch.empty(32, 256, 69, 69, device="meta"))          # strided: 307 x 4 work-groups of 128 x 64
+    assert not net_mod._gemm_conv(torch.nn.Conv2d(512, 512, 3, padding=1, stride=2).to(memory_format=cl), torch.empty(32, 512, 35, 35, device="meta"))  # 81 x 8
     monkeypatch.setenv("AMOS_MASK_CONV3X3", "0")
     assert not net_mod._gemm_conv(c3, big)
     monkeypatch.delenv("AMOS_MASK_CONV3X3")
