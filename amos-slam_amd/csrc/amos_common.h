@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/amos_frontend.h"
@@ -20,6 +21,26 @@ void set_error(const char *fmt, ...);
             return AMOS_ERR_DEVICE;                                                            \
         }                                                                                      \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting of a kernel: a "set once" flag must be kept per device (a
+// host that opens two GPUs in one process would otherwise launch with the default 64 KB limit on the second one) and be safe to reach
+// from several threads (setting the same value twice is harmless; the flag is published only after the call succeeded).  The caller
+// must have the device of the stream it is about to launch on current (as every handle of this library does).
+struct DeviceOnce {
+    std::atomic<unsigned long long> done[4] = {};  // bit per device ordinal, 256 ordinals; larger ordinals are simply set every time
+};
+inline hipError_t set_max_dynamic_lds(DeviceOnce &once, const void *kernel, int bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < 256;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (tracked && (once.done[dev >> 6].load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && tracked) once.done[dev >> 6].fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 constexpr int kEdge = AMOS_EDGE_THRESHOLD;  // 19, ORBextractor.cc:93
 constexpr int kPadLeft = 32;                // device planes keep the ROI origin 32-byte aligned

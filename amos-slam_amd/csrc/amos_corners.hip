@@ -493,11 +493,8 @@ int amos_corners_subpix_device(amos_corners *c, const uint8_t *d_gray, size_t st
     const int iters = max_count < 1 ? 1 : (max_count > 100 ? 100 : max_count);
     const size_t waveBytes = (((size_t)pw * pw * 4 + 15) & ~(size_t)15) + (size_t)5 * ww * ww * 8 + 64;
     const size_t lds = waveBytes * kSubpixWavesPerGroup;
-    static bool attrSet = false;
-    if (!attrSet) {
-        AMOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_corner_subpix), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attrSet = true;
-    }
+    static DeviceOnce ldsAttr;  // per device (amos_common.h)
+    AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttr, reinterpret_cast<const void *>(k_corner_subpix), 160 * 1024));
     hipLaunchKernelGGL(k_corner_subpix, dim3((n + kSubpixWavesPerGroup - 1) / kSubpixWavesPerGroup), dim3(64 * kSubpixWavesPerGroup), lds, c->stream, d_gray, stride,
                        width, height, d_xy, d_count, n, win, iters, eps, c->dMask);
     AMOS_HIP_CHECK(hipGetLastError());

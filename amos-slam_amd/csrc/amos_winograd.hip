@@ -453,12 +453,9 @@ int amos_mask_winograd_conv_device(void *stream, const float *d_x, const float *
         set_error("amos_mask_winograd_conv_device: invalid argument (cin %% 16 == 0, cin >= 32, cout %% 64 == 0, input below 2 GiB, 16-byte aligned channels-last tensors)");
         return AMOS_ERR_INVALID;
     }
-    static bool attrSet = false;
+    static DeviceOnce ldsAttr;  // per device (amos_common.h)
     const size_t lds = (size_t)2 * (kWinoStageV + kWinoStageR) * sizeof(float);  // two V tiles + two raw patches = 128 KB
-    if (!attrSet) {
-        AMOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_winograd_conv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet = true;
-    }
+    AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttr, reinterpret_cast<const void *>(k_winograd_conv), (int)lds));
     WinoArgs a;
     a.x = d_x; a.u = d_u; a.bias = d_bias; a.res = d_residual; a.y = d_y;
     a.B = batch; a.H = h; a.W = w; a.C = cin; a.N = cout;

@@ -52,6 +52,11 @@ class MaskEngine:
             self.net.merge_head_outputs()  # the prediction head's three output convolutions as one (net.py SharedHead.merge_output_layers)
         if self.channels_last:
             self.net.to(memory_format=torch.channels_last)
+        if self.device.type == "cuda" and os.environ.get("AMOS_MASK_WINOGRAD", "1") != "0":
+            # the Winograd-transformed weights are shared by every stream that later runs a forward: made (and waited for) here
+            from .net import prepare_winograd_weights
+            with torch.cuda.device(self.device):
+                prepare_winograd_weights(self.net)
         return self
 
     def _preprocess_hip(self, frames):

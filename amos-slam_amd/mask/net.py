@@ -78,7 +78,10 @@ def _winograd_conv(conv, x):
 
 def _winograd_weight(conv):
     """The layer's transformed weight G g G^T (16 x cin x cout floats in the kernel's staging layout), made on first use and kept on the
-    module; remade when the weight tensor changes (another storage or an in-place update)."""
+    module; remade when the weight tensor changes (another storage or an in-place update).  The cached tensor is shared by every caller
+    on every stream, so the transform is a SYNCHRONOUS step: the making stream is drained before the tensor is published (callers on
+    other streams would otherwise read it with nothing ordering them after the transform kernel).  MaskEngine.prepare() transforms all
+    eligible layers up front (prepare_winograd_weights), so in steady state this is a dictionary hit."""
     w = conv.weight
     key = (w.data_ptr(), w._version, str(w.device))
     cached = getattr(conv, "_amos_winograd", None)
@@ -86,10 +89,29 @@ def _winograd_weight(conv):
         from .. import mask_winograd_weights
         wl = w.detach().contiguous(memory_format=torch.channels_last)  # [cout][3][3][cin] in memory
         u = torch.empty(16 * conv.in_channels * conv.out_channels, dtype=torch.float32, device=w.device)
-        mask_winograd_weights(torch.cuda.current_stream(w.device).cuda_stream, wl.data_ptr(), u.data_ptr(), conv.in_channels, conv.out_channels)
+        stream = torch.cuda.current_stream(w.device)
+        mask_winograd_weights(stream.cuda_stream, wl.data_ptr(), u.data_ptr(), conv.in_channels, conv.out_channels)
+        if not torch.cuda.is_current_stream_capturing():  # (inside a capture the transform is a node of that graph, ordered by it)
+            stream.synchronize()
         cached = (key, u)
         object.__setattr__(conv, "_amos_winograd", cached)
     return cached[1]
+
+
+def prepare_winograd_weights(module):
+    """Transforms the weights of every convolution of `module` the Winograd kernel can take (3 x 3, stride 1, pad 1, supported channel
+    counts -- whether a launch then USES the kernel still depends on its size, winograd_rule) and waits for them: after this no forward
+    on any stream creates a shared tensor.  Returns the number of layers transformed."""
+    from .. import mask_winograd_supported
+    convs = [m for m in module.modules() if isinstance(m, nn.Conv2d)]
+    merged = [getattr(m, "merged", None) for m in module.modules()]
+    n = 0
+    for conv in convs + [m for m in merged if isinstance(m, nn.Conv2d)]:
+        if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+                and conv.weight.is_cuda and conv.weight.dtype == torch.float32 and mask_winograd_supported(conv.in_channels, conv.out_channels)):
+            _winograd_weight(conv)
+            n += 1
+    return n
 
 
 def conv_raw(conv, x):

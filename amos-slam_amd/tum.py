@@ -77,14 +77,21 @@ def read_depth(path):
     return np.ascontiguousarray(d)
 
 
-def bgr_to_gray(bgr):
-    """cvtColor(BGR2GRAY) in OpenCV's 8-bit fixed point, (R 9798 + G 19235 + B 3735 + 16384) >> 15 -- Tracking.cc:308-321 turns the
-    colour frame gray before the extractor sees it.  Data preparation for the gray-input leg of the bench (the colour-input
-    leg hands the BGR frame to the library, which does this on the GPU)."""
-    b = bgr[..., 0].astype(np.uint32)
-    g = bgr[..., 1].astype(np.uint32)
-    r = bgr[..., 2].astype(np.uint32)
-    return ((r * 9798 + g * 19235 + b * 3735 + 16384) >> 15).astype(np.uint8)
+CAMERA_RGB = 1  # `Camera.RGB: 1` in every RGB-D settings file of the reference (Examples/RGB-D/TUM1.yaml:29, TUM2.yaml:29, TUM3.yaml:28)
+
+
+def bgr_to_gray(bgr, rgb_flag=CAMERA_RGB):
+    """The gray frame Tracking::GrabImageRGBD hands the extractor (Tracking.cc:308-314) for a cv::imread buffer (B, G, R in memory), in
+    OpenCV's 8-bit fixed point (c0 * w0 + c1 * 19235 + c2 * w2 + 16384) >> 15.  `rgb_flag` is the settings file's Camera.RGB (mbRGB):
+    the TUM yamls set it to 1, so the reference applies CV_RGB2GRAY to the B, G, R buffer -- the R weight 9798 lands on the BLUE channel
+    and the B weight 3735 on the RED one.  That quirk is part of what the reference's extractor sees on TUM, so it is the default here;
+    rgb_flag=0 is the plain CV_BGR2GRAY.  Data preparation for the gray-input leg of the bench (the colour-input leg hands the buffer
+    to the library with rgb_order=rgb_flag, which does this on the GPU)."""
+    c0 = bgr[..., 0].astype(np.uint32)
+    c1 = bgr[..., 1].astype(np.uint32)
+    c2 = bgr[..., 2].astype(np.uint32)
+    w0, w2 = (9798, 3735) if rgb_flag else (3735, 9798)
+    return ((c0 * w0 + c1 * 19235 + c2 * w2 + 16384) >> 15).astype(np.uint8)
 
 
 def load_sequence(root, sequence, n_frames, associations=None, with_depth=False, start=0):

@@ -77,12 +77,12 @@ def algorithmic_bytes(level_w, level_h, n_kp, width, height):
 
 # --------------------------------------------------------------------------------------------- CPU baseline
 def _source_frames(synth, cfg, source, n):
-    """n gray frames of a frame source: ("synth", stream) or ("tum", root, sequence, associations, first frame)."""
+    """n gray frames of a frame source: ("synth", stream) or ("tum", root, sequence, associations, first frame, Camera.RGB flag)."""
     if source[0] == "tum":
         import importlib
         tum = importlib.import_module("amos_slam_amd.tum")
         seq = tum.load_sequence(source[1], source[2], n, associations=source[3], start=source[4])
-        return [tum.bgr_to_gray(f) for f in seq["bgr"]]
+        return [tum.bgr_to_gray(f, source[5] if len(source) > 5 else tum.CAMERA_RGB) for f in seq["bgr"]]
     return [synth.frame(source[1], k, cfg["height"], cfg["width"]) for k in range(n)]
 
 
@@ -162,7 +162,7 @@ def cpu_baseline_all_cores(cfg, workers, n_per_worker, tum_source=None):
     ctx = mp.get_context("spawn")
     barrier, q = ctx.Barrier(workers), ctx.Queue()
     small = {k: cfg[k] for k in ("n_features", "n_levels", "height", "width")}
-    sources = [(("synth", 100 + w) if tum_source is None else tum_source[:4] + (tum_source[4] + w * n_per_worker,)) for w in range(workers)]
+    sources = [(("synth", 100 + w) if tum_source is None else tum_source[:4] + (tum_source[4] + w * n_per_worker,) + tum_source[5:]) for w in range(workers)]
     procs = [ctx.Process(target=_cpu_worker, args=(ROOT, small, sources[w], n_per_worker, barrier, q)) for w in range(workers)]
     for p in procs:
         p.start()
@@ -335,6 +335,8 @@ def main():
                     "configs then run on real frames (BASELINE north_star: fr3/walking_xyz) instead of the synthetic stream")
     ap.add_argument("--tum-sequence", default="", help="sequence(s), comma separated; rank r takes entry r modulo the list (default: fr3_walking_halfsphere for c3, fr3_walking_xyz for c2)")
     ap.add_argument("--tum-associations", default="", help="associations file (`t rgb t depth` per line, rgbd_tum.cc:182-210); default: associations.txt inside the sequence")
+    ap.add_argument("--tum-camera-rgb", type=int, choices=[0, 1], default=1, help="Camera.RGB of the settings file (mbRGB, Tracking.cc:308-314): 1 in the reference's "
+                    "TUM1/2/3.yaml, i.e. CV_RGB2GRAY applied to the imread B,G,R buffer (default); 0 = CV_BGR2GRAY")
     ap.add_argument("--mask-conv-dtype", choices=["fp32", "fp16", "bf16"], default="fp32",
                     help="precision of the mask network's convolutions (c3 only; fp32 is the parity configuration)")
     ap.add_argument("--mask-chunk", type=int, default=0, help="frames per network forward (default: frames per lane)")
@@ -400,13 +402,16 @@ def main():
         seq = tum.load_sequence(args.tum_root, seq_name, n_frames_dev, associations=args.tum_associations or None, start=first)
         if seq["bgr"].shape[1:3] != (H, W):
             raise SystemExit(f"TUM frames are {seq['bgr'].shape[2]}x{seq['bgr'].shape[1]}, the config wants {W}x{H}")
-        frames_np = tum.bgr_to_gray(seq["bgr"])  # what Tracking.cc:308-321 hands the extractor (the gray-input leg)
+        frames_np = tum.bgr_to_gray(seq["bgr"], args.tum_camera_rgb)  # what Tracking.cc:308-321 hands the extractor (the gray-input leg)
         d_bgr = torch.from_numpy(seq["bgr"]).to(dev)  # the colour-input leg reads these (one read: gray pyramid + network input)
-        tum_source = ("tum", args.tum_root, seq_name, args.tum_associations or None, first)
-        data_label = "tum:" + seq["name"] + (" (wrapped: %d frames in the sequence)" % seq["frames_in_sequence"] if seq["wrapped"] else "")
+        tum_source = ("tum", args.tum_root, seq_name, args.tum_associations or None, first, args.tum_camera_rgb)
+        data_label = ("tum:" + seq["name"] + (" (wrapped: %d frames in the sequence)" % seq["frames_in_sequence"] if seq["wrapped"] else "")
+                      + " [Camera.RGB=%d: %s on the imread buffer]" % (args.tum_camera_rgb, "CV_RGB2GRAY" if args.tum_camera_rgb else "CV_BGR2GRAY"))
     else:
         frames_np = synth.frames(shard.stream_for_rank(rank), 0, n_frames_dev, H, W)  # one stream per GPU
     d_frames = torch.from_numpy(frames_np).to(dev)
+    # gray weights of the colour-input leg: the settings file's Camera.RGB for real frames (the replicated-gray synthetic frames do not care)
+    color_rgb_order = bool(args.tum_camera_rgb) if tum_source is not None else False
 
     # Lanes: extractor + matcher handle with their own HIP streams; kernels of one lane (e.g. the memory-bound
     # pyramid) overlap kernels of another (e.g. the VALU-bound FAST).  Created FIRST: their streams' mapping onto
@@ -469,7 +474,8 @@ def main():
                 rec = timed and li == 0  # per-kernel events on lane 0 only
                 if masked:
                     # ONE read of the colour frame feeds the gray pyramid (then FAST ... orientation) and the network's input tensor
-                    ln.ext.detect_color_with_mask_pre_batch_device(ln.pre, ln.bgr.data_ptr(), H * W * 3, W * 3, W, H, bl, ln.net_in.data_ptr())
+                    ln.ext.detect_color_with_mask_pre_batch_device(ln.pre, ln.bgr.data_ptr(), H * W * 3, W * 3, W, H, bl, ln.net_in.data_ptr(),
+                                                                   rgb_order=color_rgb_order)
                     with torch.cuda.stream(ln.stream):  # the network runs on the lane's stream: ordering is implicit
                         if rec:
                             m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -662,10 +668,13 @@ def main():
             # so its per-launch figures are the averages over those launches (what rocprofv3 --stats reports)
             launches = {k: 1 for k in st}
             launches["pyramid"] = lanes[0].ext.pyramid_launches()
-            dominant = max((k for k in st if k in alg), key=lambda k: st[k])
-            dom_bytes = alg[dominant] * em["Bl"] / launches[dominant]  # algorithmic bytes of one (average) launch
-            dom_ms = st[dominant] / launches[dominant]
-            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            # only byte-moving stages can be the HBM-roofline kernel: the quad-tree selection (alg 0, latency-bound,
+            # ~constant time per launch) may out-last FAST at toy batches but has no bandwidth figure to report
+            movers = [k for k in st if alg.get(k, 0) > 0 and st[k] > 0]
+            dominant = max(movers, key=lambda k: st[k]) if movers else "fast"
+            dom_bytes = alg[dominant] * em["Bl"] / launches.get(dominant, 1)  # algorithmic bytes of one (average) launch
+            dom_ms = st.get(dominant, 0.0) / launches.get(dominant, 1)
+            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
             traffic, traffic_src = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
@@ -678,8 +687,9 @@ def main():
                 except Exception:
                     traffic = None
             em_fps = em["fps"]
-            out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": (round(achieved, 2) if achieved is not None else None),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": (round(achieved / HBM_PEAK_GBS, 5) if achieved is not None else None), "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
                                "launches_per_pass": launches[dominant],
                                "measured_in": "extract_match_leg timed region (HIP events on lane 0's streams)" if use_mask else "the timed region (HIP events on lane 0's streams)"}

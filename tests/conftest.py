@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU check")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Collection order under `pytest -x`: the GPU parity tests proper first (every single-GPU BASELINE config is exercised by
+    tests/test_gpu_parity.py), the other parity files in name order, the bench.py harness contract last."""
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        if name == "test_gpu_parity.py":
+            return 0
+        if name.startswith("test_zz_"):
+            return 2
+        return 1
+    items.sort(key=rank)  # stable: the order inside a class of files is unchanged
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return entry.load_package()

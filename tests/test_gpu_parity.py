@@ -37,6 +37,37 @@ def test_tables(gpu_lib, ob):
     assert list(lh) == [480, 400, 333, 278, 231, 193, 161, 134]
 
 
+@pytest.mark.parametrize("config", ["c2", "c3", "c5"])
+def test_every_single_gpu_baseline_config(gpu_lib, ob, synth, config):
+    """Collected FIRST on purpose (tests/conftest.py orders this file first): two consecutive frames of every single-GPU
+    BASELINE.json configuration at full geometry -- configs[1] (c2: 640x480 L8 N1000, mask off), configs[2] (c3: the same
+    geometry through detect -> gate with a person mask -> describe; the mask NETWORK has its own parity tests in test_mask.py)
+    and configs[4] (c5: 1920x1080 L12 N4000) -- extract + N x N best-2 match of frame 1 against frame 0, bit-exact vs the oracle,
+    so that no later failure can leave a configuration unexercised."""
+    w, h, nf, nl = (1920, 1080, 4000, 12) if config == "c5" else (640, 480, 1000, 8)
+    ext, orc = _pair(gpu_lib, ob, w, h, nf, nl)
+    got_d, want_d = [], []
+    for k in range(2):
+        img = synth.frame(31, k, h, w)
+        if config == "c3":
+            mask = synth.person_mask(31, k)
+            ext.detect(img)
+            orc.detect(img)
+            _same(ext.gate(mask), orc.gate(mask), f"{config} frame {k} removed keypoints")
+            kg, dg = ext.describe()
+            ko, do = orc.describe()
+        else:
+            kg, dg = ext.extract(img)
+            ko, do = orc.extract(img)
+        _same(kg, ko, f"{config} frame {k} keypoints")
+        _same(dg, do, f"{config} frame {k} descriptors")
+        assert len(kg) > nf * 0.5
+        got_d.append(dg)
+        want_d.append(do)
+    m = gpu_lib.OrbMatcher()
+    _same(m.bruteforce_best2(got_d[1], got_d[0]), ob.bruteforce_best2(want_d[1], want_d[0]), f"{config} match frame 1 vs 0")
+
+
 @pytest.mark.parametrize("w,h,nf,nl", SIZES)
 def test_stages_bit_exact(gpu_lib, ob, synth, w, h, nf, nl):
     img = synth.frame(11, 3, h, w)

@@ -478,6 +478,78 @@ def test_mfma_conv1x1_against_float64(mask, gpu_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_strided_3x3_layer_on_the_automatic_tile_rule_at_32_frames(mask, gpu_lib):
+    """The strided-layer dispatch (net.py _gemm_conv: groups recomputed at 128 x 64 when stride >= 2) at the launch the bench issues: the
+    256 -> 256 stride-2 3 x 3 layer, 69 -> 35 at 32 frames (307 x 4 narrow work-groups), through conv_bias_act under the AUTOMATIC
+    tile mode, against a float64 convolution with the bound of the other kernels (float32 rounding of a 2 304-term sum)."""
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    F = torch.nn.functional
+    cl = torch.channels_last
+    torch.manual_seed(21)
+    conv = torch.nn.Conv2d(256, 256, 3, stride=2, padding=1).cuda().to(memory_format=cl)
+    x = torch.randn(32, 256, 69, 69, device="cuda").contiguous(memory_format=cl)
+    assert net_mod._gemm_conv(conv, x)
+    name = gpu_lib.mask_conv_kernel_name(32, 69, 69, 256, 256, 3, 3, 2, 1)
+    assert "k_conv_gemm" in name and "<2, 2, 2, true>" not in name, name   # the rule's 128 x 64 work-groups, not the 128 x 128 ones
+    calls = []
+    real = gpu_lib.mask_conv
+    try:
+        gpu_lib.mask_conv = lambda *a: (calls.append(a[6:15]), real(*a))[1]
+        with torch.no_grad():
+            y = net_mod.conv_bias_act(conv, x, True)
+    finally:
+        gpu_lib.mask_conv = real
+    torch.cuda.synchronize()
+    assert calls == [(32, 69, 69, 256, 256, 3, 3, 2, 1)] and y.shape == (32, 256, 35, 35) and y.is_contiguous(memory_format=cl)
+    with torch.no_grad():
+        for lo in range(0, 32, 8):  # float64 reference in slices (memory)
+            xs = x[lo:lo + 8].double()
+            want = F.conv2d(xs, conv.weight.double(), conv.bias.double(), 2, 1).relu()
+            bound = 1e-5 * F.conv2d(xs.abs(), conv.weight.double().abs(), None, 2, 1) + 1e-6
+            assert bool(((y[lo:lo + 8].double() - want).abs() <= bound).all()), lo
+
+
+@pytest.mark.gpu
+def test_first_forward_on_a_second_stream_after_prepare(mask, gpu_lib):
+    """The Winograd-transformed weights are shared by every stream: MaskEngine.prepare() makes all of them (and waits), so a FIRST
+    forward issued on a non-default stream -- and two lanes' first forwards issued back to back on two streams, as bench.py's lanes
+    do -- read finished weights.  The results must equal the default-stream forward of a second engine with the same seed."""
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    eng = _engine(mask, "cuda:0", "seed0").prepare()
+    eligible = [m for m in list(eng.net.modules()) + [eng.net.prediction_layers[0].merged] if isinstance(m, torch.nn.Conv2d)
+                and m.kernel_size == (3, 3) and m.stride == (1, 1) and gpu_lib.mask_winograd_supported(m.in_channels, m.out_channels)]
+    assert len(eligible) >= 20 and all(getattr(m, "_amos_winograd", None) is not None for m in eligible)
+    made = []
+    real = gpu_lib.mask_winograd_weights
+    frames = torch.from_numpy(np.stack([mask_cases.frame(c) for c in ("seed0", "ref122_w0", "tum_w0", "blobs7_w1")] * 8)).cuda()
+    x = eng._preprocess_hip(frames)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    try:
+        gpu_lib.mask_winograd_weights = lambda *a: (made.append(a), real(*a))[1]
+        with torch.no_grad():
+            with torch.cuda.stream(s1):
+                p1 = eng._forward(x)
+            with torch.cuda.stream(s2):
+                p2 = eng._forward(x)
+    finally:
+        gpu_lib.mask_winograd_weights = real
+    torch.cuda.synchronize()
+    assert made == [], "a forward after prepare() must not create shared weight tensors"
+    ref = _engine(mask, "cuda:0", "seed0").prepare()
+    with torch.no_grad():
+        want = ref._forward(x)
+    torch.cuda.synchronize()
+    for k in ("loc", "conf", "mask", "proto"):
+        assert torch.equal(p1[k], want[k]) and torch.equal(p2[k], want[k]), k
+    # a layer transformed lazily (no prepare) on a side stream is published only after its stream has drained
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).cuda().to(memory_format=torch.channels_last)
+    with torch.cuda.stream(s1):
+        u = net_mod._winograd_weight(conv)
+    assert s1.query() and bool(torch.isfinite(u).all())
+
+
+@pytest.mark.gpu
 def test_winograd_conv3x3_against_float64(mask, gpu_lib):
     """amos_mask_winograd_conv_device (Winograd F(2 x 2, 3 x 3) on the fp32 MFMA units: input transform, 16 GEMMs, output transform, bias +
     residual + ReLU in one kernel) against a float64 convolution, to the bound the direct kernels are held to (1e-5 of the sum of

@@ -67,8 +67,15 @@ def test_sequence_frames(tum, fake_root, ob):
     rgb = np.asarray(Image.open(os.path.join(REF, "1341846313.553992.png")).convert("RGB"))
     assert np.array_equal(seq["bgr"][0][:, :, ::-1], rgb)                         # B, G, R order like cv::imread
     assert 5000 <= int(seq["depth"][0].min()) and int(seq["depth"][0].max()) <= 10000
-    # the gray frame the extractor sees == the oracle's cvtColor(BGR2GRAY)
-    assert np.array_equal(tum.bgr_to_gray(seq["bgr"][1]), ob.color_to_gray(seq["bgr"][1]))
+    # the gray frame the extractor sees: the TUM yamls set Camera.RGB: 1, so Tracking.cc:311 applies CV_RGB2GRAY to the imread (B, G, R)
+    # buffer == the oracle's cvtColor with rgb_order (the default here); Camera.RGB: 0 is the plain BGR2GRAY
+    assert tum.CAMERA_RGB == 1
+    assert np.array_equal(tum.bgr_to_gray(seq["bgr"][1]), ob.color_to_gray(seq["bgr"][1], rgb_order=True))
+    assert np.array_equal(tum.bgr_to_gray(seq["bgr"][1], rgb_flag=0), ob.color_to_gray(seq["bgr"][1], rgb_order=False))
+    assert not np.array_equal(tum.bgr_to_gray(seq["bgr"][1], 1), tum.bgr_to_gray(seq["bgr"][1], 0))
+    px = np.array([[[200, 10, 30]]], np.uint8)   # B = 200: weighted 0.299 under Camera.RGB = 1, 0.114 under 0
+    assert int(tum.bgr_to_gray(px, 1)[0, 0]) == (200 * 9798 + 10 * 19235 + 30 * 3735 + 16384) >> 15 == 69
+    assert int(tum.bgr_to_gray(px, 0)[0, 0]) == (200 * 3735 + 10 * 19235 + 30 * 9798 + 16384) >> 15 == 38
     later = tum.load_sequence(fake_root, "rgbd_dataset_freiburg3_walking_xyz", 2, start=1)
     assert np.array_equal(later["bgr"][0], seq["bgr"][1]) and later["depth"] is None
     with pytest.raises(FileNotFoundError):
@@ -80,7 +87,7 @@ def test_bench_cpu_leg_reads_the_sequence(tum, fake_root, ob, synth):
     sys.path.insert(0, ROOT)
     import bench
     cfg = bench.CONFIGS["c2"]
-    src = ("tum", fake_root, "fr3_walking_xyz", None, 0)
+    src = ("tum", fake_root, "fr3_walking_xyz", None, 0, 1)
     frames = bench._source_frames(synth, cfg, src, 3)
     assert len(frames) == 3 and frames[0].shape == (480, 640) and frames[0].dtype == np.uint8
     one = bench.cpu_baseline_one_thread(synth, cfg, 2, src)
@@ -97,6 +104,6 @@ def test_bench_on_a_tum_sequence(gpu_lib, fake_root):
                           "--cpu-cores", "2", "--check", "--tum-root", fake_root], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
-    assert d["data"].startswith("tum:rgbd_dataset_freiburg3_walking_xyz") and "wrapped" in d["data"]
+    assert d["data"].startswith("tum:rgbd_dataset_freiburg3_walking_xyz") and "wrapped" in d["data"] and "Camera.RGB=1: CV_RGB2GRAY" in d["data"]
     assert d["oracle_checked_frames"] == 2 and d["value"] > 0 and d["config"]["mean_keypoints_per_frame"] > 500
     assert "TUM" in d["cpu_baseline"]["sample"]

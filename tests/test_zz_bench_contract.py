@@ -1,4 +1,7 @@
-"""The bench.py output contract (one JSON line with the driver's keys, the roofline and cpu_baseline objects)."""
+"""The bench.py output contract (one JSON line with the driver's keys, the roofline and cpu_baseline objects).
+
+Named test_zz_*: a harness test must sort AFTER every parity test, so that under `pytest -x` a harness assertion can never hide them
+(tests/conftest.py also orders the collection: parity first, this file last)."""
 import json
 import os
 import subprocess
@@ -28,8 +31,12 @@ def _common(d, steps, warmup):
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and ("traffic" in r)
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 0.02
+    # whichever byte-moving stage was slowest at this toy batch (timing-dependent: nothing below depends on WHICH), its figures
+    # must be self-consistent; a zero-byte stage (the latency-bound quad-tree) may never be the roofline kernel
+    assert r["kernel"] != "octree" and r["algorithmic_bytes_per_launch"] > 0 and r["avg_launch_ms"] > 0
+    assert r["achieved"] is not None and r["achieved"] > 0 and ("traffic" in r)
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 0.02 * r["achieved"] + 0.02
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 2 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
     assert c["single_thread"]["cores"] == 1 and c["single_thread"]["value"] > 0
