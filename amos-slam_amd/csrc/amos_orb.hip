@@ -17,6 +17,9 @@
 #include <cstring>
 #include <vector>
 
+#ifndef AMOS_FAST_LDS_PAD
+#define AMOS_FAST_LDS_PAD 0  /* experiments (tools/orb_variants.sh): extra LDS bytes per FAST wave, to hold the occupancy down */
+#endif
 namespace amos {
 
 static thread_local std::string g_error;
@@ -283,7 +286,7 @@ static int build_geometry(const amos_orb *h, int W, int Hh, Geom &g, std::vector
     g.fastMapRows = maxTh + 2;
     g.fastKeptCap = ((maxTw + 1) / 2) * ((maxTh + 1) / 2);
     g.fastWaveBytes = (int)align_up_sz(align_up_sz((size_t)g.fastTileRows * g.fastTileStrideDw * 4, 16) + (size_t)g.fastMapRows * kFastMapStride +
-                                       kFastCandCap * 2 + (size_t)g.fastKeptCap * 4, 16);
+                                       fast_list_bytes(g.fastKeptCap) + AMOS_FAST_LDS_PAD, 16);
     return AMOS_OK;
 }
 

@@ -41,7 +41,10 @@ constexpr int kWinoCout = 64;     // output channels per work-group
 constexpr int kWinoK = 8;         // input channels per stage
 constexpr int kWinoThreads = 512;
 #ifndef AMOS_WINO_GROUP
-#define AMOS_WINO_GROUP 32
+#define AMOS_WINO_GROUP 4
+#endif
+#ifndef AMOS_WINO_MAP
+#define AMOS_WINO_MAP 1
 #endif
 constexpr int kWinoGroup = AMOS_WINO_GROUP;  // consecutive work-groups of an XCD that share a cout tile (experiments: tools/wino_variants.sh G<n>)
 constexpr int kWinoStageU = 16 * kWinoCout * kWinoK;   // floats of one stage's U image (32 KB)
@@ -109,13 +112,25 @@ __global__ __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2,
     extern __shared__ __align__(16) float smem[];
 #define AMOS_WINO_V(buf) (smem + (buf) * kWinoStageV)
 #define AMOS_WINO_R(buf) (smem + 2 * kWinoStageV + (buf) * kWinoStageR)
-    // id -> (m block, n tile): ids are dealt round-robin over the 8 XCDs; on an XCD, 32 consecutive work-groups (one per CU) share the
-    // n tile, i.e. the 1 MB weight slice that stays in that XCD's L2, and walk 32 m blocks; the next 32 take the next n tile
+    // id -> (m block, n tile): ids are dealt round-robin over the 8 XCDs by the hardware.  Map 1 (default): an XCD owns a contiguous run
+    // of m blocks and runs the n tiles of kGroup (4) m blocks side by side -- the patch of an m block is fetched from memory once and
+    // found in the XCD's L2 by the work-groups of the other n tiles and, for two of its four rows, by the next tile row's m block:
+    // measured on proto_net 256 -> 256 at 138 x 138, 32 frames (tools/r4_wino_map.sh): L2 fetch traffic 1.93 GB per launch (3.1 x the
+    // input tensor) against 7.92 GB (12.7 x) for map 0 with groups of 32, 2.88 against 2.95 ms.  Map 0 (round 3): m blocks dealt round-robin
+    // over the XCDs, kGroup consecutive work-groups of an XCD share the n tile (the 1 MB weight slice)
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
     constexpr int kGroup = kWinoGroup;
     const int per = kGroup * a.nTiles, grp = seq / per, in = seq - grp * per;
+#if AMOS_WINO_MAP == 1
+    // an XCD owns a CONTIGUOUS run of m blocks (consecutive tile rows share two of their four patch rows: the second one finds them in
+    // this XCD's L2), and the n tiles of kGroup m blocks run side by side on it (the patch is fetched from memory by the first of them)
+    const int perXcd = (a.mBlocks + 7) >> 3, mbLocal = grp * kGroup + in % kGroup;
+    const int nt = in / kGroup, mb = xcd * perXcd + mbLocal;
+    if (mbLocal >= perXcd || mb >= a.mBlocks) return;
+#else
     const int nt = in / kGroup, mb = (grp * kGroup + in % kGroup) * 8 + xcd;
     if (mb >= a.mBlocks) return;
+#endif
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
     // ---- geometry of the work-group's tile run: segments of tiles of one tile row.  This thread is (a) the loader of raw-patch column

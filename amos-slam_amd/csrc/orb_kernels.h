@@ -13,6 +13,15 @@
 #include "../../include/amos_orb_pattern.h"
 #include "../../include/amos_host_types.h"
 
+// Wave priority of the latency-bound kernels (quad-tree, orientation, rBRIEF, matcher): with several lanes on the chip their waves share
+// SIMDs with the VALU-dense FAST waves of another lane; a higher s_setprio lets the few instructions of a latency-bound wave issue ahead
+// of those (the arbiter picks by priority, then age: MI355X_MICROARCH.md), which shortens that lane's critical path at almost no cost
+// to FAST.  0 = off (experiments: tools/orb_variants.sh).
+#ifndef AMOS_LATENCY_PRIO
+#define AMOS_LATENCY_PRIO 0
+#endif
+#define AMOS_SET_LATENCY_PRIO() do { if (AMOS_LATENCY_PRIO > 0) __builtin_amdgcn_s_setprio(AMOS_LATENCY_PRIO); } while (0)
+
 namespace amos {
 
 __constant__ signed char c_pattern[1024];
@@ -395,44 +404,20 @@ __global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr
 //      max(min(n,s), min(e,w)) < c - t  (dark) or  min(max(n,s), max(e,w)) > c + t  (bright).  Even and odd
 //      pixels of a dword are isolated by one v_and each (odd ones stay shifted left by 8) and everything is
 //      unsigned packed 16-bit with saturating c -+ t -- no unpacking; survivors go onto an LDS list;
-//   2. the survivors (dense lanes again) get the exact arc value: up to 64 at a time with v_pk_min_i16 on
-//      (d, -d) pairs (one chain serves both polarities), 65..128 two per lane with one packed max-chain and
-//      one min-chain on the raw circle pixels;
+//   2. the survivors (dense lanes again) get the exact arc value, two per lane (128 per pass) with ONE unsigned
+//      packed max-ladder on the raw circle pixels: a candidate is scored in the polarity its compass test
+//      passed in, bright ones on complemented bytes (fast_score_chunk2);
 //   3. 3x3 strict non-max suppression over the survivors only; the kept ones are ranked by pixel
 //      index (row-major = FAST's output order) and written to the cell's slots.
 // The cell is processed at iniThFAST first and, only if that leaves it EMPTY, again at minThFAST
 // (ORBextractor.cc:1126-1139) -- a block-uniform retry.
+#ifndef AMOS_FAST_EXP
+#define AMOS_FAST_EXP 0  /* timing experiments, results are wrong (tools/orb_variants.sh): 1 no arc scoring, 2 no phase 3, 3 no candidate stores (1 - 3 also without the second sweep), 4 staging only, 5 no second sweep */
+#endif
 typedef short short2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ short2v pk_min(short2v a, short2v b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ short2v pk_max(short2v a, short2v b) { return __builtin_elementwise_max(a, b); }
-
-__device__ __forceinline__ int fast_arc_value(const uint8_t *c, int s)
-{
-    const int v = c[0];
-    short2v x[16];
-#define AMOS_FAST_D(k, off)                                \
-    {                                                      \
-        const int d = v - (int)c[off];                     \
-        x[k] = short2v{(short)d, (short)-d};               \
-    }
-    AMOS_FAST_D(0, 3 * s) AMOS_FAST_D(1, 3 * s + 1) AMOS_FAST_D(2, 2 * s + 2) AMOS_FAST_D(3, s + 3)
-    AMOS_FAST_D(4, 3) AMOS_FAST_D(5, -s + 3) AMOS_FAST_D(6, -2 * s + 2) AMOS_FAST_D(7, -3 * s + 1)
-    AMOS_FAST_D(8, -3 * s) AMOS_FAST_D(9, -3 * s - 1) AMOS_FAST_D(10, -2 * s - 2) AMOS_FAST_D(11, -s - 3)
-    AMOS_FAST_D(12, -3) AMOS_FAST_D(13, s - 3) AMOS_FAST_D(14, 2 * s - 2) AMOS_FAST_D(15, 3 * s - 1)
-#undef AMOS_FAST_D
-    short2v m2[16], m4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) m2[k] = pk_min(x[k], x[(k + 1) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) m4[k] = pk_min(m2[k], m2[(k + 2) & 15]);
-    short2v best = short2v{-256, -256};
-#pragma unroll
-    for (int k = 0; k < 16; k++)  // 9 contiguous = two groups of four + the ninth
-        best = pk_max(best, pk_min(pk_min(m4[k], m4[(k + 4) & 15]), x[(k + 8) & 15]));
-    // .x = max over arcs of min(v - p) (dark), .y = max over arcs of min(p - v) (bright)
-    return max(max((int)best.x, (int)best.y), 0);
-}
 
 constexpr int kFastMapStride = 64;   // cell + 2 halo <= 61 columns
 constexpr int kFastMaxCell = 59;
@@ -472,30 +457,40 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
     return v;
 }
 
-constexpr int kFastCandCap = 1024;  // candidate list; a cell with more falls back to scanning the arc map
+#ifndef AMOS_FAST_CAND_CAP
+#define AMOS_FAST_CAND_CAP 768
+#endif
+// candidate list (uint16 entries); one phase-1 iteration appends up to 512, so the list is flushed (scored, forgotten: phase 3 then scans
+// the arc map instead) once it holds more than kFastCandCap - 512 with iterations to go.  A 30 x 30-pixel cell has 75 - 150 candidates.
+// The list shares its LDS with the overflow path's `kept` list (written only after the last candidate has its arc value): LDS per wave
+// decides how many cells a CU works on at a time (6 work-groups of four at 640 x 480, was 4 with separate 2 KB + 1.3 KB lists).
+constexpr int kFastCandCap = AMOS_FAST_CAND_CAP;
+__host__ __device__ constexpr size_t fast_list_bytes(int keptCap) { return (size_t)kFastCandCap * 2 > (size_t)keptCap * 4 ? (size_t)kFastCandCap * 2 : (size_t)keptCap * 4; }
 
-__device__ __forceinline__ void fast_score_chunk(const uint8_t *tile, int tileStride, uint8_t *amap, const uint16_t *cand,
-                                                 int first, int count, int lane, int t)
+// Exact arc value of up to 128 survivors, TWO PER LANE (A in the low halves of the packed registers, B in the high halves; the `count`
+// survivors are split in two halves of (count + 1) / 2 so that a short list keeps few lanes busy: the 17 scattered byte reads of a
+// candidate are what the LDS spends its conflict cycles on), on the raw pixel values and in ONE polarity per candidate:
+//   dark:    A = v - min_arcs max_{k in arc} p_k          bright:  A = max_arcs min_{k in arc} p_k - v  =  v' - min_arcs max p'_k  with x' = 255 - x,
+// so a bright candidate's 17 bytes are complemented (one xor with 0x00ff per half) and both kinds run the same unsigned packed max-ladder
+// (80 packed operations for two candidates instead of 160 for both polarities).  A 9-arc of one polarity excludes one of the other (9 + 9 >
+// 16), so the polarity that can be a corner is the one whose compass test passed (phase 1's test, recomputed here from the four compass
+// pixels already in registers): bright iff the bright compass score is the larger one.  A candidate whose BOTH compass scores exceed t
+// (a saddle: 0.2 % of the survivors at threshold 20, 1.3 % at 7) may be a corner in either polarity: when a chunk holds one (wave-uniform
+// ballot) the ladder runs a second time with every lane's polarity flipped and the maximum of the two passes is kept -- exact for every
+// candidate: the polarity that failed the compass test has A <= t, so it changes neither "A > t" nor the value of an A > t.
+// (A one-candidate-per-lane ladder on 16-bit scalars -- v_max_u16 / v_xor_b32 issue at twice the packed instructions' rate,
+// profiles/r04_valu_issue.md -- was measured too: 13 % more instructions, the same kernel time.)
+template <int kStride>
+__device__ __forceinline__ void fast_score_chunk2(const uint8_t *tile, uint8_t *amap, const uint16_t *cand, int first, int count, int lane, int t)
 {
-    if (lane < count) {
-        const int p = cand[first + lane];
-        const int y = p >> 6, x = p & 63;
-        const int a = fast_arc_value(tile + y * tileStride + x, tileStride);
-        amap[(y + 1) * kFastMapStride + x + 1] = (uint8_t)(a > t ? a : 0);
-    }
-}
-
-// The same for 65 .. 128 survivors, TWO PER LANE (A = cand[first + lane] in the low halves of the packed
-// registers, B = cand[first + 64 + lane] in the high halves), on the raw pixel values -- no differences, no
-// polarity:  A = max( v - min_arcs max_{k in arc} p_k ,  max_arcs min_{k in arc} p_k - v )  clamped at 0,
-// i.e. one unsigned packed max-chain and one min-chain over the 16 circle pixels of both candidates.
-__device__ __forceinline__ void fast_score_chunk2(const uint8_t *tile, int tileStride, uint8_t *amap, const uint16_t *cand,
-                                                  int first, int count, int lane, int t)
-{
+#if AMOS_FAST_EXP == 1
+    return;
+#endif
     typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-    const bool hasA = lane < count, hasB = lane + 64 < count;
-    const int pA = cand[first + (hasA ? lane : 0)], pB = hasB ? cand[first + 64 + lane] : pA;
-    const int s = tileStride;
+    const int half = (count + 1) >> 1;  // wave-uniform, <= 64
+    const bool hasA = lane < half, hasB = lane + half < count;
+    const int pA = cand[first + (hasA ? lane : 0)], pB = hasB ? cand[first + half + lane] : pA;
+    constexpr int s = kStride;
     const uint8_t *cA = tile + (pA >> 6) * s + (pA & 63), *cB = tile + (pB >> 6) * s + (pB & 63);
     ushort2v x[16];
 #define AMOS_FAST_P(k, off) x[k] = __builtin_bit_cast(ushort2v, (unsigned)cA[off] | ((unsigned)cB[off] << 16));
@@ -504,36 +499,40 @@ __device__ __forceinline__ void fast_score_chunk2(const uint8_t *tile, int tileS
     AMOS_FAST_P(8, -3 * s) AMOS_FAST_P(9, -3 * s - 1) AMOS_FAST_P(10, -2 * s - 2) AMOS_FAST_P(11, -s - 3)
     AMOS_FAST_P(12, -3) AMOS_FAST_P(13, s - 3) AMOS_FAST_P(14, 2 * s - 2) AMOS_FAST_P(15, 3 * s - 1)
 #undef AMOS_FAST_P
-    ushort2v lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo2[k] = __builtin_elementwise_min(x[k], x[(k + 1) & 15]);
-        hi2[k] = __builtin_elementwise_max(x[k], x[(k + 1) & 15]);
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo4[k] = __builtin_elementwise_min(lo2[k], lo2[(k + 2) & 15]);
-        hi4[k] = __builtin_elementwise_max(hi2[k], hi2[(k + 2) & 15]);
-    }
-    ushort2v maxMin = ushort2v{0, 0}, minMax = ushort2v{255, 255};
-#pragma unroll
-    for (int k = 0; k < 16; k++) {  // 9 contiguous = two groups of four + the ninth
-        maxMin = __builtin_elementwise_max(maxMin, __builtin_elementwise_min(__builtin_elementwise_min(lo4[k], lo4[(k + 4) & 15]), x[(k + 8) & 15]));
-        minMax = __builtin_elementwise_min(minMax, __builtin_elementwise_max(__builtin_elementwise_max(hi4[k], hi4[(k + 4) & 15]), x[(k + 8) & 15]));
-    }
     const ushort2v vv = __builtin_bit_cast(ushort2v, (unsigned)cA[0] | ((unsigned)cB[0] << 16));
-    const ushort2v a2 = __builtin_elementwise_max(__builtin_elementwise_sub_sat(vv, minMax), __builtin_elementwise_sub_sat(maxMin, vv));
-    const int aA = a2.x, aB = a2.y;
+    // compass scores of both polarities (circle pixels 0 / 8 and 4 / 12), as in phase 1
+    const ushort2v lo = __builtin_elementwise_max(__builtin_elementwise_min(x[0], x[8]), __builtin_elementwise_min(x[4], x[12]));
+    const ushort2v hi = __builtin_elementwise_min(__builtin_elementwise_max(x[0], x[8]), __builtin_elementwise_max(x[4], x[12]));
+    const ushort2v qd = __builtin_elementwise_sub_sat(vv, lo), qb = __builtin_elementwise_sub_sat(hi, vv);
+    const ushort2v t2 = __builtin_bit_cast(ushort2v, (unsigned)t * 0x00010001u);
+    const bool saddle = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_elementwise_min(qd, qb), t2)) != 0u;
+    // 0x00ff in the halves whose candidate is scored as bright: qb > qd  <=>  the 16-bit difference qd - qb is negative
+    typedef short short2s __attribute__((ext_vector_type(2)));
+    unsigned flip = __builtin_bit_cast(unsigned, (__builtin_bit_cast(short2s, qd) - __builtin_bit_cast(short2s, qb)) >> short2s{15, 15}) & 0x00ff00ffu;
+    ushort2v best = ushort2v{0, 0};
+    for (int pass = 0;; pass++) {   // one trip; two when the chunk holds a saddle candidate (wave-uniform)
+        const ushort2v fv = __builtin_bit_cast(ushort2v, flip);
+        ushort2v y[16], hi2[16], hi4[16], arc[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) y[k] = x[k] ^ fv;
+#pragma unroll
+        for (int k = 0; k < 16; k++) hi2[k] = __builtin_elementwise_max(y[k], y[(k + 1) & 15]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) hi4[k] = __builtin_elementwise_max(hi2[k], hi2[(k + 2) & 15]);
+#pragma unroll
+        for (int k = 0; k < 16; k++)  // 9 contiguous = two groups of four + the ninth
+            arc[k] = __builtin_elementwise_max(__builtin_elementwise_max(hi4[k], hi4[(k + 4) & 15]), y[(k + 8) & 15]);
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)  // minimum over the 16 arcs as a tree (no serial chain of dependent packed operations)
+#pragma unroll
+            for (int k = 0; k < w; k++) arc[k] = __builtin_elementwise_min(arc[k], arc[k + w]);
+        best = __builtin_elementwise_max(best, __builtin_elementwise_sub_sat(vv ^ fv, arc[0]));
+        if (pass == 1 || __ballot(saddle) == 0ull) break;
+        flip ^= 0x00ff00ffu;
+    }
+    const int aA = best.x, aB = best.y;
     if (hasA) amap[((pA >> 6) + 1) * kFastMapStride + (pA & 63) + 1] = (uint8_t)(aA > t ? aA : 0);
     if (hasB) amap[((pB >> 6) + 1) * kFastMapStride + (pB & 63) + 1] = (uint8_t)(aB > t ? aB : 0);
-}
-
-// count survivors starting at first: two per lane when that fills more than one wave's worth of lanes
-__device__ __forceinline__ void fast_score_tail(const uint8_t *tile, int tileStride, uint8_t *amap, const uint16_t *cand, int first,
-                                                int count, int lane, int t)
-{
-    if (count > 64) fast_score_chunk2(tile, tileStride, amap, cand, first, count, lane, t);  // wave-uniform
-    else fast_score_chunk(tile, tileStride, amap, cand, first, count, lane, t);
 }
 
 #ifndef AMOS_FAST_CELLS_PER_GROUP
@@ -589,7 +588,7 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
     uint32_t *tile32 = reinterpret_cast<uint32_t *>(base);
     uint8_t *amap = base + (((size_t)g->fastTileRows * tileStride + 15) & ~(size_t)15);
     uint16_t *cand = reinterpret_cast<uint16_t *>(amap + (size_t)g->fastMapRows * kFastMapStride);
-    uint32_t *kept = reinterpret_cast<uint32_t *>(cand + kFastCandCap);
+    uint32_t *kept = reinterpret_cast<uint32_t *>(cand);  // overflow path only, after the candidate list's last use (fast_list_bytes)
     const uint8_t *img = level_origin(pyr, g, frame, c.level);
     const int tw = c.tw, th = c.th;
     // LDS row r holds image row y0 - 3 + r; LDS byte b of a row holds image column x0 - 4 + b.  Rows are
@@ -605,6 +604,10 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
     for (int idx = lane; idx < (th + 2) * (kFastMapStride / 16); idx += 64) reinterpret_cast<uint4 *>(amap)[idx] = uint4{0, 0, 0, 0};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (AMOS_FAST_EXP == 4) {  // (the compare keeps the staged tile alive)
+        if (lane == 0 || tile32[lane] == 0xdeadbeefu) slotCount[(size_t)frame * g->totalCells + cellIdx] = 0;
+        return;
+    }
     const uint8_t *tile = reinterpret_cast<const uint8_t *>(tile32) + 3 * tileStride + 4;  // pixel (x0, y0)
     const int iniTh = min(max(g->iniTh, 0), 255), minTh = min(max(g->minTh, 0), 255);
     const int groups = c.groups, nitems = th * groups;
@@ -656,13 +659,14 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
                 p0 = (y << 6) | (8 * gx);
             }
             if (ncand + 512 > kFastCandCap) {  // wave-uniform: make room (one iteration adds <= 64 x 8), remember that the list is no longer complete
-                fast_score_tail(tile, tileStride, amap, cand, done, ncand - done, lane, t);  // < 128 left over
+                if (ncand > done) fast_score_chunk2<tileStride>(tile, amap, cand, done, ncand - done, lane, t);  // < 128 left over
                 ncand = done = 0;
                 overflow = true;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
             {   // append the survivors: one wave-wide prefix sum of the per-lane counts, then up to 8 stores
+                if (AMOS_FAST_EXP == 3) bits = 0;
                 const int cnt = __popc(bits);
                 const int incl = wave_inclusive_scan(cnt);
                 int o = ncand + incl - cnt;
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             while (ncand - done >= 128) {  // wave-uniform: dense chunks of 128 survivors, two per lane
-                fast_score_chunk2(tile, tileStride, amap, cand, done, 128, lane, t);
+                fast_score_chunk2<tileStride>(tile, amap, cand, done, 128, lane, t);
                 done += 128;
             }
         }
@@ -687,12 +691,13 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
             const unsigned m2 = ((unsigned)minTh * 0x00010001u) << 8;
             anyLower = __ballot(((qmax & 0xffffu) > (m2 & 0xffffu)) || ((qmax >> 16) > (m2 >> 16))) != 0ull;
         }
-        fast_score_tail(tile, tileStride, amap, cand, done, ncand - done, lane, t);
+        if (ncand > done) fast_score_chunk2<tileStride>(tile, amap, cand, done, ncand - done, lane, t);  // wave-uniform
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- phase 3: strict 3x3 NMS.  For a corner at threshold t (a > t) every non-corner neighbour is
         // smaller than a anyway: keep <=> a > all 8 neighbours.  Over the survivor list, or (list overflowed)
         // over the non-zero entries of the arc map.
+        if (AMOS_FAST_EXP == 2) return;
         if (!overflow) {
             // The list is in item order = row-major pixel order and the ordered ballots below keep that order, which
             // is FAST's output order: the kept corners go straight to their final slots.
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(64 * kFastCellsPerGroup) void k_fast_cells(const ui
     sweep(iniTh, std::true_type{});
     // a second cv::FAST at a higher (or equal) threshold finds nothing new; neither does one on a cell without
     // a single pixel whose compass score exceeds minThFAST
-    if (nkept == 0 && minTh < iniTh && anyLower) sweep(minTh, std::false_type{});
+    if (AMOS_FAST_EXP == 0 && nkept == 0 && minTh < iniTh && anyLower) sweep(minTh, std::false_type{});
     if (lane == 0) slotCount[(size_t)frame * g->totalCells + cellIdx] = nkept;
 }
 
@@ -1111,6 +1116,7 @@ __global__ __launch_bounds__(256) void k_octree(const Geom *__restrict__ g, cons
                                                int *__restrict__ candCount, amos_keypoint *__restrict__ lvKps,
                                                int *__restrict__ lvCount, int NC, int SC)
 {
+    AMOS_SET_LATENCY_PRIO();
     extern __shared__ __align__(16) unsigned char oct_smem[];
     const OctLds L = oct_carve(oct_smem, NC, SC);
     const int tid = threadIdx.x;
@@ -1201,6 +1207,7 @@ __device__ __forceinline__ int group16_sum(int v)
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
                                                amos_keypoint *__restrict__ lvKps, const int *__restrict__ lvCount, int nFrames)
 {
+    AMOS_SET_LATENCY_PRIO();
     // wt[row][half][0] = weights u + 16 of the 16 bytes of that half row (0 outside the circle),
     // wt[row][half][1] = 0/1 masks; row = v + 15, row 31 (v = 16) does not exist: all zero
     __shared__ uint4 wt[32][2][2];
@@ -1450,6 +1457,7 @@ __global__ __launch_bounds__(kDescKps * 16) void k_describe(const uint8_t *__res
                                                            amos_keypoint *__restrict__ outKps, uint8_t *__restrict__ outDesc,
                                                            int *__restrict__ outCount, int nFrames)
 {
+    AMOS_SET_LATENCY_PRIO();
     __shared__ float4 pat[256];
     __shared__ uint4 patch[kDescKps][kDescRows * 3];
     int frame, chunk;

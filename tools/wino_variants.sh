@@ -7,6 +7,7 @@ FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx9
 OBJS=$(ls build/amos_*.o | grep -v amos_winograd)
 for v in "$@"; do
   case $v in
+    M*G*) m=${v#M}; DEF="-DAMOS_WINO_MAP=${m%%G*} -DAMOS_WINO_GROUP=${v#*G}";;   # M1G4: work-group -> (m block, n tile) map 1 with groups of 4
     G*) DEF="-DAMOS_WINO_GROUP=${v#G}";;   # G1, G4, ...: work-groups of an XCD that share a cout tile back to back
     *) DEF="-DAMOS_WINO_EXP_$v";;
   esac
