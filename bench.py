@@ -230,12 +230,24 @@ def count_network_flops(torch, engine, batch, frames_per_forward):
     import importlib
     import torch.nn.functional as F
     net_mod = importlib.import_module("amos_slam_amd.mask.net")
-    total = {"direct": 0.0, "executed": 0.0}
+    total = {"direct": 0.0, "executed": 0.0, "padding": 0.0}
     real = F.conv2d
+    # the merged prediction-head convolution carries 33 all-zero filters (351 -> 384 output channels: a multiple of 64 for the project's
+    # kernels, mask/net.py SharedHead.merge_output_layers): they are launch padding, not work of the network -- not counted, neither as
+    # direct nor as executed FLOPs (they were in round 3: + 0.8 %)
+    head = engine.net.prediction_layers[0]
+    merged = getattr(head, "merged", None)
+    real_share = 1.0
+    if merged is not None:
+        n_real = head.bbox_layer.out_channels + head.conf_layer.out_channels + head.mask_layer.out_channels
+        real_share = n_real / float(merged.out_channels)
 
     def counting(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
         out = real(x, w, bias, stride, padding, dilation, groups)
         f = 2.0 * w.shape[1] * w.shape[2] * w.shape[3] * out.numel()  # weight [Cout, Cin / groups, kh, kw]
+        if merged is not None and w.data_ptr() == merged.weight.data_ptr():
+            total["padding"] += f * (1.0 - real_share)
+            f *= real_share
         pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)
         os.environ["AMOS_MASK_WINOGRAD"] = rule_mode  # the rule as the timed run applies it (this forward itself runs no project kernel)
         try:
@@ -657,7 +669,8 @@ def main():
                                             "of a step / the step's wall time, i.e. a lower bound of the convolution kernels' own rate: the step also holds the "
                                             "pre / post-processing, the ORB kernels and the match.  flops_per_frame / achieved_direct_equivalent: the same "
                                             "layers counted as direct convolutions (the figure comparable with a direct-convolution implementation; it may "
-                                            "exceed the peak).  lane_pass_ms = one lane's whole mask pass (events on its stream), lanes overlap."}
+                                            "exceed the peak).  The 33 all-zero filters that pad the merged prediction head to 384 channels are counted in neither figure.  "
+                                            "lane_pass_ms = one lane's whole mask pass (events on its stream), lanes overlap."}
             if args.mask_conv_dtype == "fp32":
                 out["roofline_mask"]["dominant_kernel"] = conv_kernel_roofline(torch, pkg, torch.device(dev), chunk)
         if em:

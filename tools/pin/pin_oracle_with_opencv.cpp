@@ -6,7 +6,7 @@
 // mismatch (or "identical").  A mismatch localises the wrong recalled constant / rounding rule; all identical pins the
 // oracle, and with it every GPU parity test, to OpenCV.
 //
-//   g++ -O2 -std=c++17 tools/pin/pin_oracle_with_opencv.cpp oracle/orb_oracle.c oracle/lk_oracle.c -Iinclude -Ioracle \
+//   g++ -O2 -std=c++17 tools/pin/pin_oracle_with_opencv.cpp oracle/orb_oracle.c oracle/lk_oracle.c oracle/corner_oracle.c -Iinclude -Ioracle \
 //       $(pkg-config --cflags --libs opencv4) -lm -o pin_oracle && ./pin_oracle
 //
 // NOT BUILT in this project's image (no OpenCV headers there): it is a tool for the reference's maintainer, outside
@@ -29,6 +29,10 @@ extern "C" {
 void orc_bgr_to_lab(const uint8_t *src, size_t n_px, int blue_idx, uint8_t *dst);  // oracle/lk_oracle.c
 int orc_lk_track(const uint8_t *prev, size_t prev_stride, const uint8_t *next, size_t next_stride, int w, int h, const float *prev_pts, int n, int win,
                  int max_level, int max_count, double epsilon, float min_eig_threshold, float *next_pts, uint8_t *status, float *err);  // oracle/lk_oracle.c
+void orc_corner_harris(const uint8_t *img, size_t stride, int w, int h, double k, float *dst);                                          // oracle/corner_oracle.c
+int orc_good_features_to_track(const uint8_t *img, size_t stride, int w, int h, int max_corners, double quality, double min_distance, double k,
+                               float *xy, int cap, float *response_out);                                                              // oracle/corner_oracle.c
+int orc_corner_subpix(const uint8_t *img, size_t stride, int w, int h, float *xy, int n, int win, int max_count, double epsilon);      // oracle/corner_oracle.c
 }
 
 static int g_failures = 0;
@@ -202,6 +206,38 @@ int main()
         for (int i = 0; i < 1000; i++)
             if (st[i] && gotSt.at<uchar>(i)) worst = std::max(worst, (double)std::max(std::fabs(want.at<float>(i, 0) - got.at<float>(i, 0)), std::fabs(want.at<float>(i, 1) - got.at<float>(i, 1))));
         std::printf("%-34s largest position difference %.3g px\n", "calcOpticalFlowPyrLK", worst);
+    }
+    // cv::goodFeaturesToTrack + cv::cornerSubPix as Tracking.cc:894-895 call them (the corner source of GetSceneFlowObj): 1000 corners,
+    // quality 0.01, minDistance 8, blockSize 3, Harris detector with k = 0.04; refinement window 10 x 10 (half size), no dead zone,
+    // 20 iterations / eps 0.03.  cornerHarris itself first (its response plane decides everything after it), then the selected corners
+    // in the library's order, then the refined positions (float arithmetic of the library's build: largest difference reported too).
+    {
+        const cv::Mat img = textured(640, 480, 11);
+        cv::Mat wantR, gotR(480, 640, CV_32F);
+        cv::cornerHarris(img, wantR, 3, 3, 0.04, cv::BORDER_DEFAULT);
+        orc_corner_harris(img.data, img.step, 640, 480, 0.04, gotR.ptr<float>());
+        report("cornerHarris(3, 3, 0.04)", wantR, gotR);
+        std::vector<cv::Point2f> pts;
+        cv::goodFeaturesToTrack(img, pts, 1000, 0.01, 8, cv::Mat(), 3, true, 0.04);
+        std::vector<float> xy(2 * 1000);
+        const int n = orc_good_features_to_track(img.data, img.step, 640, 480, 1000, 0.01, 8.0, 0.04, xy.data(), 1000, nullptr);
+        cv::Mat want((int)pts.size(), 2, CV_32F), got(n, 2, CV_32F);
+        for (int i = 0; i < (int)pts.size(); i++) { want.at<float>(i, 0) = pts[i].x; want.at<float>(i, 1) = pts[i].y; }
+        for (int i = 0; i < n; i++) { got.at<float>(i, 0) = xy[2 * i]; got.at<float>(i, 1) = xy[2 * i + 1]; }
+        if ((int)pts.size() != n) { std::printf("%-34s MISMATCH: %zu corners, oracle %d\n", "goodFeaturesToTrack count", pts.size(), n); g_failures++; }
+        else report("goodFeaturesToTrack (Harris, 8 px)", want, got);
+        if (!pts.empty() && (int)pts.size() == n) {
+            cv::cornerSubPix(img, pts, cv::Size(10, 10), cv::Size(-1, -1), cv::TermCriteria(cv::TermCriteria::COUNT | cv::TermCriteria::EPS, 20, 0.03));
+            orc_corner_subpix(img.data, img.step, 640, 480, xy.data(), n, 10, 20, 0.03);
+            double worst = 0;
+            for (int i = 0; i < n; i++) {
+                want.at<float>(i, 0) = pts[i].x; want.at<float>(i, 1) = pts[i].y;
+                got.at<float>(i, 0) = xy[2 * i]; got.at<float>(i, 1) = xy[2 * i + 1];
+                worst = std::max(worst, (double)std::max(std::fabs(pts[i].x - xy[2 * i]), std::fabs(pts[i].y - xy[2 * i + 1])));
+            }
+            report("cornerSubPix(10 x 10, 20 / 0.03)", want, got);
+            std::printf("%-34s largest position difference %.3g px\n", "cornerSubPix", worst);
+        }
     }
     std::printf(g_failures ? "\n%d primitive(s) differ: the oracle is NOT pinned by this OpenCV build\n" : "\nall identical: the oracle is pinned to this OpenCV build\n", g_failures);
     return g_failures ? 1 : 0;
