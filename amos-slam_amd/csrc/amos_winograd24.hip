@@ -1,0 +1,423 @@
+// amos_winograd24.hip -- the stride-1 3 x 3 convolutions of the mask network (a15, yolact.py:47-200, 265-400, backbone.py:60-200) as Winograd
+// F(2 x 4, 3 x 3) on the fp32 MFMA units: the vertical direction as F(2, 3) (four positions per two output rows), the horizontal one as
+// F(4, 3) (six positions per four output columns) -- 24 multiplies per 2 x 4 outputs and channel pair, 3.0 per output against 4.0 for
+// F(2 x 2) (amos_winograd.hip) and 9.0 for the direct convolution.  Float32 in, float32 accumulate.
+//
+//   Y (2 x 4) = A2^T [ sum_c (G2 g G4^T) . (B2^T d B4) ] A4          d: 4 x 6 input tile (pad 1), g: 3 x 3 filter
+//   B2^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]      G2 = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]        A2^T = [1 1 1 0; 0 1 -1 -1]
+//   B4^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G4   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]    A4^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+//
+// Why this shape and not F(4 x 4): 24 positions divide over the 8 waves of a work-group (3 each, two waves per SIMD, the MFMA load of the
+// four SIMDs balanced) and their accumulators for 32 tiles x 64 output channels are 96 registers per lane; the 36 positions of F(4 x 4)
+// need 9 or 12 waves (an unbalanced SIMD, or 3 waves per SIMD at 170 registers for 96 accumulators + fragments + transform) and either
+// half the output channels per work-group or 295 KB of accumulators per CU.
+//
+// Structure (the F(2 x 2) kernel's, amos_winograd.hip, with these differences): one work-group = 512 threads = 8 waves owns 32 consecutive
+// tiles (2 x 4 outputs each: the same 256 output pixels) x 64 output channels x all 24 positions.  Wave w multiplies positions 3w .. 3w + 2
+// = row w >> 1 of the 4 x 6 position grid, columns 3 (w & 1) .. + 2 -- and the SAME wave makes exactly these rows of B2^T d B4 for all 32
+// tiles (lane = tile x channel quad), so a V tile is private to its wave (only the raw patch is shared: one work-group barrier per stage).
+//   U (G2 g G4^T, k_winograd24_weights, MFMA fragment order) goes from global memory straight into the owning wave's registers;
+//   X: the raw patch [4 rows][columns][8 channels] by LDS-DMA (buffer_load_dwordx4 ... lds), out-of-image pixels as out-of-range offsets
+//      (zeros); the tiles of a row segment share their columns (column = 4 x tile + c, c = 0 .. 5);
+//   V: thread (tile, channel quad) reads 2 rows x 5 columns of the patch, 44 multiply-adds, three ds_write_b128;
+//   a stage (8 input channels) = positions 0 and 1 (16 MFMAs) | barrier | position 2 (8 MFMAs), fragments and the next V tile made under
+//   the MFMAs, U fetched one and a half stages ahead, the raw patch a whole stage ahead behind a counted vmcnt.
+// Epilogue: every wave applies A4 to its half row (four partial sums per tile and channel), the partials meet in LDS (two rounds of 32
+// output channels), every thread finishes one output row of a tile for four channels: A2^T, bias (+ residual), ReLU, 16-byte stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../include/amos_frontend.h"
+#include "amos_common.h"
+
+namespace amos {
+
+constexpr int kW24Tiles = 32;     // tiles per work-group (one 32-row MFMA block)
+constexpr int kW24Cout = 64;      // output channels per work-group (two 32-column MFMA blocks)
+constexpr int kW24K = 8;          // input channels per stage
+constexpr int kW24Threads = 512;
+constexpr int kW24Pos = 24;       // 4 x 6 positions
+#ifndef AMOS_W24_GROUP
+#define AMOS_W24_GROUP 4
+#endif
+constexpr int kW24Group = AMOS_W24_GROUP;                 // m blocks of an XCD whose n tiles run side by side (amos_winograd.hip, map 1)
+constexpr int kW24StageU = kW24Pos * kW24Cout * kW24K;    // floats of one stage's U image (48 KB)
+constexpr int kW24PosV = kW24Tiles * kW24K;               // floats of one position's V block (1 KB)
+constexpr int kW24StageV = kW24Pos * kW24PosV;            // floats of one stage's V tile (24 KB)
+constexpr int kW24RawCols = 256;                          // columns of the raw patch (32 tiles in up to 32 one-tile segments: 32 x 6 = 192)
+constexpr int kW24RawRow = kW24RawCols * kW24K;           // floats of one patch row
+constexpr int kW24StageR = 4 * kW24RawRow;                // floats of one raw patch (32 KB)
+constexpr int kW24LdsFloats = 8 * 4 * 32 * 32;            // the epilogue's exchange image (128 KB) > 2 V tiles + 2 raw patches (112 KB)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct W24Args {
+    const float *x, *u, *bias, *res;
+    float *y;
+    int B, H, W, C, N;          // frames, image size, input channels, output channels
+    int tilesX, tilesY, tilesPerImage, totalTiles;
+    int mBlocks, nTiles, stages, relu;
+    unsigned xBytes;            // size of x in bytes (the buffer descriptor's range)
+};
+
+// k * a + b per component as one fused multiply-add each (the file is compiled with -ffp-contract=off)
+__device__ __forceinline__ f32x4 w24_fma(float k, f32x4 a, f32x4 b)
+{
+    return f32x4{__builtin_fmaf(k, a.x, b.x), __builtin_fmaf(k, a.y, b.y), __builtin_fmaf(k, a.z, b.z), __builtin_fmaf(k, a.w, b.w)};
+}
+
+// V block of one position: element (row = tile, k) at float offset row * 8 + 4 * ((k >> 2) ^ f(row)) + (k & 3)  (amos_winograd.hip)
+__device__ __host__ __forceinline__ int w24_swz(int row, int half) { return row * 8 + 4 * (half ^ (((row >> 2) ^ (row >> 3)) & 1)); }
+// raw patch: 16-byte unit of (column, channel quad) inside a patch row -- blocks of 32 columns, inside a block [column parity][column / 2][quad]
+__device__ __forceinline__ int w24_raw_unit(int col, int quad) { return (col >> 5) * 64 + (col & 1) * 32 + ((col & 31) >> 1) * 2 + quad; }
+
+// Weights [cout][3][3][cin] (a channels-last Conv2d weight) -> U = G2 g G4^T in the order the MFMA's B fragments are read: for every
+// (cout tile nt, stage s, position p = 6 a + b, 32-channel block j) 64 lanes x 4 floats, lane l = U_p[nt * 64 + j * 32 + (l & 31)][s * 8 + 4 (l >> 5) ..+3];
+// sums in double, one rounding.
+__global__ __launch_bounds__(256) void k_winograd24_weights(const float *__restrict__ w, float *__restrict__ u, int cin, int cout)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= cin * cout) return;
+    const int c = idx % cin, n = idx / cin;
+    double g[3][3];
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) g[a][b] = (double)w[((size_t)(n * 3 + a) * 3 + b) * cin + c];
+    double t[4][3];  // G2 g
+    for (int b = 0; b < 3; b++) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5 * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5 * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const int stages = cin / kW24K, nt = n / kW24Cout, nr = n % kW24Cout, s = c / kW24K, k = c % kW24K;
+    float *img = u + (size_t)(nt * stages + s) * kW24StageU + (size_t)((nr >> 5) * 64 + (k >> 2) * 32 + (nr & 31)) * 4 + (k & 3);
+    for (int a = 0; a < 4; a++) {
+        const double t0 = t[a][0], t1 = t[a][1], t2 = t[a][2];
+        const double r[6] = {t0 / 4.0, -(t0 + t1 + t2) / 6.0, -(t0 - t1 + t2) / 6.0, t0 / 24.0 + t1 / 12.0 + t2 / 6.0, t0 / 24.0 - t1 / 12.0 + t2 / 6.0, t2};
+        for (int b = 0; b < 6; b++) img[(size_t)(a * 6 + b) * 512] = (float)r[b];
+    }
+}
+
+// The whole work of one wave, compiled once per half of the position row (kHalf = wave & 1): the two halves combine the patch columns
+// differently, and a run-time branch on that inside a stage would split the stage's basic block -- the interleaving of the transform
+// with the MFMAs (sched_group_barrier) only works inside one.  Every wave of a work-group passes the same barriers in either copy.
+template <int kHalf>
+__device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
+{
+    constexpr int half = kHalf;
+#define AMOS_W24_V(buf) (smem24 + (buf) * kW24StageV)
+#define AMOS_W24_R(buf) (smem24 + 2 * kW24StageV + (buf) * kW24StageR)
+    // id -> (m block, n tile): an XCD (ids are dealt round-robin over the 8 XCDs) owns a contiguous run of m blocks and runs the n tiles of
+    // kW24Group of them side by side (amos_winograd.hip, map 1: the patch of an m block is fetched from memory once per XCD)
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int per = kW24Group * a.nTiles, grp = seq / per, in = seq - grp * per;
+    const int perXcd = (a.mBlocks + 7) >> 3, mbLocal = grp * kW24Group + in % kW24Group;
+    const int nt = in / kW24Group, mb = xcd * perXcd + mbLocal;
+    if (mbLocal >= perXcd || mb >= a.mBlocks) return;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    // ---- geometry of the work-group's tile run: segments of tiles of one tile row.  This thread is (a) the loader of raw-patch column
+    // `col` (block `wave`, lane order [parity][half][quad]) for all four patch rows and (b) the transformer of tile `tl`, channel quad
+    // `quad`, position row `prow`, position columns 3 * half .. + 2.
+    const int quad = lane & 1, tl = lane >> 1, prow = wave >> 1;
+    const int col = 32 * wave + 2 * ((lane >> 1) & 15) + (lane >> 5);
+    int xoff[4];     // loader: byte offset of (patch row r, column col, channel quad) in x, or the buffer's size (zeros) when there is no such pixel
+    int colBase = 0; // transformer: first patch column of tile tl
+    {
+        const int T0 = mb * kW24Tiles, nT = min(kW24Tiles, a.totalTiles - T0);
+        int b = T0 / a.tilesPerImage, rem = T0 - b * a.tilesPerImage, ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+#pragma unroll
+        for (int r = 0; r < 4; r++) xoff[r] = (int)a.xBytes;
+        for (int t0 = 0, cb = 0; t0 < nT;) {  // (b, ty, tx) = the segment's first tile, t0 its index in the run, cb its first column
+            const int n = min(a.tilesX - tx, nT - t0);
+            if (col >= cb && col < cb + 4 * n + 2) {
+                const int lc = col - cb, tloc = min(lc >> 2, n - 1), ix = 4 * (tx + tloc) - 1 + (lc - 4 * tloc);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int iy = 2 * ty - 1 + r;
+                    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                        xoff[r] = (int)((((unsigned)(b * a.H + iy) * a.W + ix) * a.C + 4 * quad) * 4u);
+                }
+            }
+            if (tl >= t0 && tl < t0 + n) colBase = cb + 4 * (tl - t0);
+            t0 += n;
+            cb += 4 * n + 2;
+            tx = 0;
+            if (++ty == a.tilesY) { ty = 0; b++; }
+        }
+        if (tl >= nT) colBase = 0;  // tiles past the end of the tensor: any valid patch position (their results are not stored)
+    }
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.xBytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    // the transformer's ten reads: rows (r0, r1) of B2^T d row `prow` (0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3), columns colBase + half + c, c = 0 .. 4
+    const int r0 = prow == 0 ? 0 : (prow == 2 ? 2 : 1), r1 = prow == 0 ? 2 : (prow == 1 ? 2 : (prow == 2 ? 1 : 3));
+    int rsrc0[5];  // float offsets inside a raw patch of (row r0, column colBase + half + c); row r1 is (r1 - r0) * kW24RawRow further
+#pragma unroll
+    for (int c = 0; c < 5; c++) rsrc0[c] = r0 * kW24RawRow + w24_raw_unit(colBase + half + c, quad) * 4;
+    const int rdelta = (r1 - r0) * kW24RawRow;
+    const float sgn = prow == 1 ? 1.f : -1.f;                 // the row's second term is added (row 1) or subtracted
+    const int vdst = (3 * wave) * kW24PosV + w24_swz(tl, quad);  // + p * kW24PosV for position 3 * wave + p
+    // U fragments of this wave's three positions: [position of the triple][cout block] x 16 bytes per lane and stage
+    const float *usrc = a.u + (size_t)nt * a.stages * kW24StageU + (size_t)(wave * 3) * 512 + lane * 4;
+
+#define AMOS_W24_FETCH_X(s, buf)                                                                                                     \
+    {                                                                                                                                \
+        _Pragma("unroll") for (int r = 0; r < 4; r++)                                                                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (LdsPtr)(AMOS_W24_R(buf) + r * kW24RawRow + wave * 256), 16, xoff[r], (s) * (kW24K * 4), 0, 0); \
+    }
+#define AMOS_W24_FETCH_U(fb, s, p)                                                                                                   \
+    {                                                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                                \
+            fb[j] = *reinterpret_cast<const f32x4 *>(usrc + (size_t)(s) * kW24StageU + ((p) * 2 + j) * 256);                         \
+    }
+    // raw patch (buffer rb) -> this thread's half row of B2^T d B4 -> the wave's V blocks (buffer vb).  s_c = d[r0][c] +- d[r1][c] for the five
+    // columns; half 0: V0 = 4 s0 - 5 s2 + s4, V1 = (s4 - 4 s2) + (s3 - 4 s1), V2 = (s4 - 4 s2) - (s3 - 4 s1);
+    // half 1 (s = t1 .. t5): V3 = (s3 - s1) + 2 (s2 - s0), V4 = (s3 - s1) - 2 (s2 - s0), V5 = 4 s0 - 5 s2 + s4.
+#define AMOS_W24_SCOL(c)                                                                                                             \
+    ([&]() -> f32x4 {                                                                                                                \
+        const f32x4 d0 = *reinterpret_cast<const f32x4 *>(rp + rsrc0[c]), d1 = *reinterpret_cast<const f32x4 *>(rp + rsrc0[c] + rdelta); \
+        return f32x4{__builtin_fmaf(sgn, d1.x, d0.x), __builtin_fmaf(sgn, d1.y, d0.y), __builtin_fmaf(sgn, d1.z, d0.z),              \
+                     __builtin_fmaf(sgn, d1.w, d0.w)};  /* exact: sgn = +-1 */                                                       \
+    }())
+#define AMOS_W24_TRANSFORM(rb, vb)                                                                                                   \
+    {                                                                                                                                \
+        const float *rp = AMOS_W24_R(rb);                                                                                            \
+        float *vd = AMOS_W24_V(vb) + vdst;                                                                                           \
+        const f32x4 s0 = AMOS_W24_SCOL(0), s2 = AMOS_W24_SCOL(2), s4 = AMOS_W24_SCOL(4);                                             \
+        const f32x4 e = w24_fma(4.f, s0, w24_fma(-5.f, s2, s4));   /* the end position of the half row */                            \
+        const f32x4 s1 = AMOS_W24_SCOL(1), s3 = AMOS_W24_SCOL(3);                                                                    \
+        if (half == 0) {                                                                                                             \
+            const f32x4 p = w24_fma(-4.f, s2, s4), q = w24_fma(-4.f, s1, s3);                                                        \
+            *reinterpret_cast<f32x4 *>(vd) = e;                                                                                      \
+            *reinterpret_cast<f32x4 *>(vd + kW24PosV) = p + q;                                                                       \
+            *reinterpret_cast<f32x4 *>(vd + 2 * kW24PosV) = p - q;                                                                   \
+        } else {                                                                                                                     \
+            const f32x4 p = s3 - s1, q = s2 - s0;                                                                                    \
+            *reinterpret_cast<f32x4 *>(vd) = w24_fma(2.f, q, p);                                                                     \
+            *reinterpret_cast<f32x4 *>(vd + kW24PosV) = w24_fma(-2.f, q, p);                                                         \
+            *reinterpret_cast<f32x4 *>(vd + 2 * kW24PosV) = e;                                                                       \
+        }                                                                                                                            \
+    }
+
+    f32x16 acc[3][2];  // [position of the triple][cout block]
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[p][j][r] = 0.f;
+    const int foff = w24_swz(lane & 31, lane >> 5);  // this lane's 4 floats inside a position's block
+    f32x4 fa0, fa1, fa2, fbE0[2], fbE1[2], fbE2[2], fbO0[2], fbO1[2], fbO2[2];
+#define AMOS_W24_LDFRAG(fa, buf, p) fa = *reinterpret_cast<const f32x4 *>(AMOS_W24_V(buf) + (wave * 3 + (p)) * kW24PosV + foff);
+#define AMOS_W24_MFMAS(fa, fb, p)                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 2; j++) {                                                  \
+        acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[j].x, acc[p][j], 0, 0, 0);         \
+        acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[j].y, acc[p][j], 0, 0, 0);         \
+        acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[j].z, acc[p][j], 0, 0, 0);         \
+        acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[j].w, acc[p][j], 0, 0, 0);         \
+    }
+// behind each of the next `n` MFMAs: up to `dr` LDS reads, `va` vector instructions, `dw` LDS writes, `vm` vector-memory requests
+#define AMOS_W24_INTERLEAVE(n, dr, va, dw, vm)                                            \
+    _Pragma("unroll") for (int q = 0; q < (n); q++) {                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                \
+        if (dr) __builtin_amdgcn_sched_group_barrier(0x100, dr, 0);                       \
+        if (va) __builtin_amdgcn_sched_group_barrier(0x002, va, 0);                       \
+        if (dw) __builtin_amdgcn_sched_group_barrier(0x200, dw, 0);                       \
+        if (vm) __builtin_amdgcn_sched_group_barrier(0x020, vm, 0);                       \
+    }
+    // One stage s (V buffer and raw-patch buffer s & 1):
+    //   first part (16 MFMAs): positions 0 and 1 multiply (position 0's A fragment was read in the second part of stage s - 1); the A fragments
+    //     of positions 1 and 2 are read; the wave's V blocks of stage s + 1 are made from the raw patch of stage s + 1 (complete since the
+    //     barrier of stage s - 1) into the other V buffer; U(s + 1, position 2) is requested into the other parity's registers;
+    //   barrier: this wave's pieces of the raw patch of stage s + 2 (requested a whole stage ago) have landed -- vmcnt(2): the two U loads of
+    //     the first part are the only younger vector-memory operations; nobody reads the raw patch of stage s + 1 any more;
+    //   second part (8 MFMAs): position 2 multiplies; position 0's A fragment of stage s + 1 is read; U(s + 2, positions 0 and 1) is requested
+    //     into the registers this stage's first part has finished with; the raw patch of stage s + 3 is requested into the buffer the
+    //     transform has just released.
+#define AMOS_W24_BARRIER(kVm) asm volatile("s_waitcnt vmcnt(" #kVm ") lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#define AMOS_W24_STAGE(s, vb, fbC0, fbC1, fbC2, fbN2, kNext, kNext2, kNext3, kVm)         \
+    {                                                                                     \
+        AMOS_W24_LDFRAG(fa1, vb, 1);                                                      \
+        AMOS_W24_LDFRAG(fa2, vb, 2);                                                      \
+        if (kNext) AMOS_W24_TRANSFORM((vb) ^ 1, (vb) ^ 1);                                \
+        if (kNext) AMOS_W24_FETCH_U(fbN2, (s) + 1, 2);                                    \
+        AMOS_W24_MFMAS(fa0, fbC0, 0);                                                     \
+        AMOS_W24_MFMAS(fa1, fbC1, 1);                                                     \
+        AMOS_W24_INTERLEAVE(2, 1, 0, 0, 0);  /* the A fragments of positions 1 and 2 */   \
+        if (kNext) {                                                                      \
+            AMOS_W24_INTERLEAVE(5, 2, 4, 0, 0);   /* ten patch reads, the column sums */  \
+            AMOS_W24_INTERLEAVE(6, 0, 5, 1, 0);   /* the six outputs, three writes */     \
+            AMOS_W24_INTERLEAVE(2, 0, 0, 0, 1);   /* U of position 2 */                   \
+        }                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                               \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        AMOS_W24_BARRIER(kVm)                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (kNext) AMOS_W24_LDFRAG(fa0, (vb) ^ 1, 0);                                     \
+        if (kNext2) AMOS_W24_FETCH_U(fbC0, (s) + 2, 0);                                   \
+        if (kNext2) AMOS_W24_FETCH_U(fbC1, (s) + 2, 1);                                   \
+        if (kNext3) AMOS_W24_FETCH_X((s) + 3, (vb) ^ 1);                                  \
+        AMOS_W24_MFMAS(fa2, fbC2, 2);                                                     \
+        AMOS_W24_INTERLEAVE(1, 1, 0, 0, 0);                                               \
+        AMOS_W24_INTERLEAVE(7, 0, 0, 0, 2);                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    }
+#define AMOS_W24_STAGE_EVEN(s, n1, n2, n3, vm) AMOS_W24_STAGE(s, 0, fbE0, fbE1, fbE2, fbO2, n1, n2, n3, vm)
+#define AMOS_W24_STAGE_ODD(s, n1, n2, n3, vm) AMOS_W24_STAGE(s, 1, fbO0, fbO1, fbO2, fbE2, n1, n2, n3, vm)
+
+    // prologue: raw patches of stages 0 and 1; U of stage 0 (three positions) and of stage 1 (positions 0 and 1)
+    AMOS_W24_FETCH_X(0, 0);
+    AMOS_W24_FETCH_X(1, 1);
+    AMOS_W24_FETCH_U(fbE0, 0, 0);
+    AMOS_W24_FETCH_U(fbE1, 0, 1);
+    AMOS_W24_FETCH_U(fbE2, 0, 2);
+    AMOS_W24_FETCH_U(fbO0, 1, 0);
+    AMOS_W24_FETCH_U(fbO1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    AMOS_W24_TRANSFORM(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    AMOS_W24_LDFRAG(fa0, 0, 0);
+    AMOS_W24_FETCH_X(2, 0);
+    int s = 0;
+    for (; s + 4 < a.stages; s += 2) {  // two stages per trip: the register names follow the stage parity
+        AMOS_W24_STAGE_EVEN(s, true, true, true, 2);
+        AMOS_W24_STAGE_ODD(s + 1, true, true, true, 2);
+    }
+    // the last four stages (the stage count is even and at least four: amos_mask_winograd_supported): less and less left to request
+    AMOS_W24_STAGE_EVEN(s, true, true, true, 0);
+    AMOS_W24_STAGE_ODD(s + 1, true, true, false, 0);
+    AMOS_W24_STAGE_EVEN(s + 2, true, false, false, 0);
+    AMOS_W24_STAGE_ODD(s + 3, false, false, false, 0);
+
+    // ---- epilogue.  This wave holds M[pr][pc] for pr = wave >> 1, pc = 3 * half + p.  Along A4's columns (M A4)[pr][j] = sum_pc M[pr][pc] A4^T[j][pc]:
+    // half 0 contributes (M0 + M1 + M2, M1 - M2, M1 + M2, M1 - M2), half 1 (M3 + M4, 2 (M3 - M4), 4 (M3 + M4), 8 (M3 - M4) + M5).  Exchange image:
+    // [wave][j][tile 32][cout 32] floats, one cout block of 32 per round.  Accumulator register r of lane l is tile row
+    // (r & 3) + 8 (r >> 2) + 4 (l >> 5), channel l & 31 of its 32 x 32 block.
+    __syncthreads();  // every wave is done with the V tiles and the raw patches
+    const int oq = t & 7, otl = (t >> 3) & 31, oy = t >> 8;  // finishing thread: channel quad of the round, tile, output row of the tile
+#pragma unroll
+    for (int jb = 0; jb < 2; jb++) {
+        if (jb) __syncthreads();  // the previous round's readers are done
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float m0 = acc[0][jb][r], m1 = acc[1][jb][r], m2 = acc[2][jb][r];
+            float c0, c1, c2, c3;
+            if (half == 0) {
+                const float dlt = m1 - m2, sm = m1 + m2;
+                c0 = m0 + sm; c1 = dlt; c2 = sm; c3 = dlt;
+            } else {
+                const float dlt = m0 - m1, sm = m0 + m1;
+                c0 = sm; c1 = 2.f * dlt; c2 = 4.f * sm; c3 = 8.f * dlt + m2;
+            }
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), cc = lane & 31;
+            float *dst = smem24 + ((wave * 4) * 32 + row) * 32 + cc;
+            dst[0] = c0;
+            dst[1 * 32 * 32] = c1;
+            dst[2 * 32 * 32] = c2;
+            dst[3 * 32 * 32] = c3;
+        }
+        __syncthreads();
+        // S[pr][j] = (M A4)[pr][j];  Y[0][j] = S[0][j] + S[1][j] + S[2][j];  Y[1][j] = S[1][j] - S[2][j] - S[3][j]
+        const int n0 = nt * kW24Cout + jb * 32 + 4 * oq;
+        const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 yv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f32x4 sp[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int pr = oy + k;  // rows 0, 1, 2 for the upper output row, 1, 2, 3 for the lower one
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(&smem24[(((pr * 2 + 0) * 4 + j) * 32 + otl) * 32 + 4 * oq]);
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(&smem24[(((pr * 2 + 1) * 4 + j) * 32 + otl) * 32 + 4 * oq]);
+                sp[k] = lo + hi;
+            }
+            yv[j] = oy == 0 ? (sp[0] + sp[1]) + sp[2] : (sp[0] - sp[1]) - sp[2];
+        }
+        const int T = mb * kW24Tiles + otl;
+        if (T < a.totalTiles) {
+            const int b = T / a.tilesPerImage, rem = T - b * a.tilesPerImage, ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+            const int py = 2 * ty + oy;
+            if (py < a.H) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int px = 4 * tx + j;
+                    if (px >= a.W) continue;
+                    const size_t o = ((size_t)(b * a.H + py) * a.W + px) * a.N + n0;
+                    f32x4 v = yv[j] + bv;
+                    if (a.res) v = v + *reinterpret_cast<const f32x4 *>(a.res + o);
+                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<f32x4 *>(a.y + o) = v;
+                }
+            }
+        }
+    }
+#undef AMOS_W24_V
+#undef AMOS_W24_R
+}
+
+__global__ __launch_bounds__(kW24Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_winograd24_conv(const W24Args a)
+{
+    extern __shared__ __align__(16) float smem24[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) w24_run<1>(a, smem24);
+    else w24_run<0>(a, smem24);
+}
+
+}  // namespace amos
+
+using namespace amos;
+
+extern "C" {
+
+size_t amos_mask_winograd24_weight_floats(int cin, int cout)
+{
+    return amos_mask_winograd_supported(cin, cout) == AMOS_OK ? (size_t)kW24Pos * cin * cout : 0;
+}
+
+int amos_mask_winograd24_weights_device(void *stream, const float *d_w, float *d_u, int cin, int cout)
+{
+    if (!d_w || !d_u || amos_mask_winograd_supported(cin, cout) != AMOS_OK) {
+        set_error("amos_mask_winograd24_weights_device: invalid argument (cin %% 16 == 0, cin >= 32, cout %% 64 == 0)");
+        return AMOS_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(k_winograd24_weights, dim3((unsigned)((cin * cout + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_w, d_u, cin, cout);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_mask_winograd24_conv_device(void *stream, const float *d_x, const float *d_u, const float *d_bias, const float *d_residual, float *d_y,
+                                     int batch, int h, int w, int cin, int cout, int relu)
+{
+    const long long xBytes = (long long)batch * h * w * cin * 4;
+    if (!d_x || !d_u || !d_y || batch < 1 || h < 1 || w < 1 || amos_mask_winograd_supported(cin, cout) != AMOS_OK || xBytes > 0x7fffffffLL - 4096 ||
+        ((uintptr_t)d_x | (uintptr_t)d_u | (uintptr_t)d_y | (uintptr_t)d_bias | (uintptr_t)d_residual) % 16 != 0) {
+        set_error("amos_mask_winograd24_conv_device: invalid argument (cin %% 16 == 0, cin >= 32, cout %% 64 == 0, input below 2 GiB, 16-byte aligned channels-last tensors)");
+        return AMOS_ERR_INVALID;
+    }
+    static DeviceOnce ldsAttr;  // per device (amos_common.h)
+    const size_t lds = (size_t)kW24LdsFloats * sizeof(float);  // 128 KB
+    AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttr, reinterpret_cast<const void *>(k_winograd24_conv), (int)lds));
+    W24Args a;
+    a.x = d_x; a.u = d_u; a.bias = d_bias; a.res = d_residual; a.y = d_y;
+    a.B = batch; a.H = h; a.W = w; a.C = cin; a.N = cout;
+    a.tilesX = (w + 3) / 4; a.tilesY = (h + 1) / 2;
+    a.tilesPerImage = a.tilesX * a.tilesY;
+    a.totalTiles = batch * a.tilesPerImage;
+    a.mBlocks = (a.totalTiles + kW24Tiles - 1) / kW24Tiles;
+    a.nTiles = cout / kW24Cout;
+    a.stages = cin / kW24K;
+    a.relu = relu;
+    a.xBytes = (unsigned)xBytes;
+    // ids: 8 XCDs x groups of (kW24Group m blocks x nTiles); the last group may be partly empty (those work-groups return at once)
+    const int perXcd = (a.mBlocks + 7) / 8, groups = (perXcd + kW24Group - 1) / kW24Group;
+    const dim3 grid((unsigned)(groups * kW24Group * a.nTiles * 8)), block(kW24Threads);
+    hipLaunchKernelGGL(k_winograd24_conv, grid, block, lds, (hipStream_t)stream, a);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+}  // extern "C"

@@ -76,21 +76,36 @@ def _winograd_conv(conv, x):
                          x.shape[0], x.shape[2], x.shape[3])
 
 
+def winograd_family():
+    """Which Winograd form the eligible layers run in: "24" = F(2 x 4, 3 x 3) (amos_mask_winograd24_conv_device: 24 multiplies per 2 x 4
+    outputs, the default) or "22" = F(2 x 2, 3 x 3) (amos_mask_winograd_conv_device: 16 per 2 x 2).  AMOS_MASK_WINOGRAD_F selects (A/B runs, tests)."""
+    return "22" if os.environ.get("AMOS_MASK_WINOGRAD_F", "22") == "22" else "24"
+
+
+def _winograd_fns():
+    """(family, positions, weight transform, convolution) of the Winograd form in force"""
+    if winograd_family() == "22":
+        from .. import mask_winograd_weights, mask_winograd_conv
+        return "22", 16, mask_winograd_weights, mask_winograd_conv
+    from .. import mask_winograd24_weights, mask_winograd24_conv
+    return "24", 24, mask_winograd24_weights, mask_winograd24_conv
+
+
 def _winograd_weight(conv):
-    """The layer's transformed weight G g G^T (16 x cin x cout floats in the kernel's staging layout), made on first use and kept on the
+    """The layer's transformed weight G g G^T (16 or 24 x cin x cout floats in the kernel's staging layout), made on first use and kept on the
     module; remade when the weight tensor changes (another storage or an in-place update).  The cached tensor is shared by every caller
     on every stream, so the transform is a SYNCHRONOUS step: the making stream is drained before the tensor is published (callers on
     other streams would otherwise read it with nothing ordering them after the transform kernel).  MaskEngine.prepare() transforms all
     eligible layers up front (prepare_winograd_weights), so in steady state this is a dictionary hit."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, str(w.device))
+    family, positions, make_weights, _ = _winograd_fns()
+    key = (w.data_ptr(), w._version, str(w.device), family)
     cached = getattr(conv, "_amos_winograd", None)
     if cached is None or cached[0] != key:
-        from .. import mask_winograd_weights
         wl = w.detach().contiguous(memory_format=torch.channels_last)  # [cout][3][3][cin] in memory
-        u = torch.empty(16 * conv.in_channels * conv.out_channels, dtype=torch.float32, device=w.device)
+        u = torch.empty(positions * conv.in_channels * conv.out_channels, dtype=torch.float32, device=w.device)
         stream = torch.cuda.current_stream(w.device)
-        mask_winograd_weights(stream.cuda_stream, wl.data_ptr(), u.data_ptr(), conv.in_channels, conv.out_channels)
+        make_weights(stream.cuda_stream, wl.data_ptr(), u.data_ptr(), conv.in_channels, conv.out_channels)
         if not torch.cuda.is_current_stream_capturing():  # (inside a capture the transform is a node of that graph, ordered by it)
             stream.synchronize()
         cached = (key, u)
@@ -119,10 +134,9 @@ def conv_raw(conv, x):
     cl = torch.channels_last
     if x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and x.is_contiguous(memory_format=cl) and conv.weight.dtype == torch.float32:
         if _winograd_conv(conv, x):
-            from .. import mask_winograd_conv
             b, _, h, w = x.shape
             y = torch.empty((b, conv.out_channels, h, w), device=x.device, dtype=torch.float32, memory_format=cl)
-            mask_winograd_conv(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), _winograd_weight(conv).data_ptr(), None, None, y.data_ptr(),
+            _winograd_fns()[3](torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), _winograd_weight(conv).data_ptr(), None, None, y.data_ptr(),
                                b, h, w, conv.in_channels, conv.out_channels, False)
             return y
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
@@ -138,12 +152,11 @@ def conv_bias_act(conv, x, relu, residual=None):
         cl = torch.channels_last
         if _winograd_conv(conv, x) and x.is_contiguous(memory_format=cl) and conv.weight.dtype == torch.float32 and (residual is None or (
                 residual.dtype == torch.float32 and residual.is_contiguous(memory_format=cl))):
-            from .. import mask_winograd_conv
             b, _, h, w = x.shape
             y = torch.empty((b, conv.out_channels, h, w), device=x.device, dtype=torch.float32, memory_format=cl)
             if residual is not None and residual.shape != y.shape:
                 raise ValueError("conv_bias_act: residual shape %s, output shape %s" % (tuple(residual.shape), tuple(y.shape)))
-            mask_winograd_conv(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), _winograd_weight(conv).data_ptr(), conv.bias.data_ptr(),
+            _winograd_fns()[3](torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), _winograd_weight(conv).data_ptr(), conv.bias.data_ptr(),
                                residual.data_ptr() if residual is not None else None, y.data_ptr(), b, h, w, conv.in_channels, conv.out_channels, relu)
             return y
         if _gemm_conv(conv, x) and x.is_contiguous(memory_format=cl) and conv.weight.dtype == torch.float32 and (

@@ -375,6 +375,15 @@ size_t amos_mask_winograd_weight_floats(int cin, int cout);
 int amos_mask_winograd_weights_device(void *stream, const float *d_w, float *d_u, int cin, int cout);
 int amos_mask_winograd_conv_device(void *stream, const float *d_x, const float *d_u, const float *d_bias, const float *d_residual,
                                    float *d_y, int batch, int h, int w, int cin, int cout, int relu);
+/* The same layers as Winograd F(2 x 4, 3 x 3): F(2, 3) vertically, F(4, 3) horizontally -- 24 multiplies per 2 x 4 outputs and channel
+ * pair (3.0 per output against 4.0 for F(2 x 2) and 9.0 direct); same arguments, same support rule (amos_mask_winograd_supported),
+ * same epilogue; the transformed weight G2 g G4^T has 24 * cin * cout floats and its own layout (make it with the matching function).
+ * Rounding: the F(4, 3) transforms carry the factors 4, 5, 8 and 1 / 24, so its error against a float64 convolution is a few times
+ * that of F(2 x 2) -- tests/test_mask.py holds both to the direct kernels' bound (1e-5 of the sum of |terms|). */
+size_t amos_mask_winograd24_weight_floats(int cin, int cout);
+int amos_mask_winograd24_weights_device(void *stream, const float *d_w, float *d_u, int cin, int cout);
+int amos_mask_winograd24_conv_device(void *stream, const float *d_x, const float *d_u, const float *d_bias, const float *d_residual,
+                                     float *d_y, int batch, int h, int w, int cin, int cout, int relu);
 int amos_mask_conv1x1_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual,
                              float *d_y, int batch, int in_h, int in_w, int cin, int cout, int stride, int relu);
 

@@ -75,6 +75,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--small-only", action="store_true")
+    ap.add_argument("--f24", action="store_true", help="F(2 x 4) against F(2 x 2): time and error on the network's layer shapes")
     ap.add_argument("--big-only", action="store_true", help="timing of the three largest layer shapes only, no checks (experiment builds)")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -82,6 +83,36 @@ if __name__ == "__main__":
         for cin, cout, hw in ((256, 256, 138), (256, 256, 69), (64, 64, 138)):
             r = run(a.frames, cin, cout, hw, hw, check=False)
             print((cin, cout, hw), r["wino_ms"], r["wino_direct_equiv_TF"], flush=True)
+        sys.exit(0)
+    if a.f24:
+        # F(2 x 4) against F(2 x 2) on every stride-1 3 x 3 layer shape of the network: time and error relative to the sum of |terms|
+        for cin, cout, hw in ((256, 256, 138), (256, 256, 69), (256, 384, 69), (64, 64, 138), (128, 128, 69), (256, 256, 35), (256, 384, 35), (512, 512, 18)):
+            b = a.frames
+            x = torch.randn(b, cin, hw, hw, device="cuda").contiguous(memory_format=cl)
+            wgt = (torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5).contiguous(memory_format=cl)
+            bias = torch.randn(cout, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            out = {}
+            n = min(b, 2)
+            exact = F.conv2d(x[:n].double(), wgt.double(), bias.double(), 1, 1).relu()
+            bound = F.conv2d(x[:n].double().abs(), wgt.double().abs(), None, 1, 1)
+            for fam, npos, mk, cv in (("22", 16, amos.mask_winograd_weights, amos.mask_winograd_conv), ("24", 24, amos.mask_winograd24_weights, amos.mask_winograd24_conv)):
+                u = torch.empty(npos * cin * cout, device="cuda")
+                mk(st, wgt.data_ptr(), u.data_ptr(), cin, cout)
+                y = torch.full((b, cout, hw, hw), float("nan"), device="cuda").contiguous(memory_format=cl)
+                fn = lambda: cv(st, x.data_ptr(), u.data_ptr(), bias.data_ptr(), None, y.data_ptr(), b, hw, hw, cin, cout, True)
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                e1.synchronize()
+                out[fam + "_ms"] = round(e0.elapsed_time(e1) / 10, 4)
+                out[fam + "_err"] = float(((y[:n].double() - exact).abs() / bound).max())
+            out["speedup_24_over_22"] = round(out["22_ms"] / out["24_ms"], 3)
+            print((b, cin, cout, hw), out, flush=True)
         sys.exit(0)
     for shape in ((1, 32, 64, 6, 6), (2, 64, 64, 21, 17), (1, 32, 128, 9, 9), (2, 256, 64, 5, 5), (3, 48, 192, 12, 7), (2, 32, 64, 1, 3), (40, 32, 64, 2, 4)):
         print(shape, run(*shape, reps=2, relu=(shape[1] != 32), use_res=(shape[1] == 64)), flush=True)
