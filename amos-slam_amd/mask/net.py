@@ -56,9 +56,9 @@ def _gemm_conv(conv, x):
 
 
 def winograd_rule(cin, cout, kernel, stride, padding, dilation, groups, batch, height, width):
-    """Does a convolution of this shape run as Winograd F(2 x 2, 3 x 3) on the fp32 MFMA units (amos_mask_winograd_conv_device)?  3 x 3,
-    stride 1, pad 1, channel counts the kernel takes, an input below 2 GiB, and a launch of at least 256 work-groups of 64 tiles x 64
-    channels (one per CU).  Measured on MI355X at 32 frames (tools/winograd_probe.py): 1.4 - 1.8 x the direct implicit GEMM on every
+    """Does a convolution of this shape run as Winograd (F(2 x 4, 3 x 3) or F(2 x 2, 3 x 3): winograd_family) on the fp32 MFMA units
+    (amos_mask_winograd24_conv_device / amos_mask_winograd_conv_device)?  3 x 3, stride 1, pad 1, channel counts the kernel takes, an
+    input below 2 GiB, and a launch of at least 256 work-groups of 256 output pixels x 64 channels (one per CU).  Measured on MI355X at 32 frames (tools/winograd_probe.py): 1.4 - 1.8 x the direct implicit GEMM on every
     such layer of the network.  AMOS_MASK_WINOGRAD=0 never, 1 by this rule (default), 2 wherever the kernel applies (tests).
     (bench.py asks the same function which layers to count at 16 instead of 36 multiplies per 2 x 2 outputs.)"""
     mode = os.environ.get("AMOS_MASK_WINOGRAD", "1")
@@ -67,8 +67,10 @@ def winograd_rule(cin, cout, kernel, stride, padding, dilation, groups, batch, h
     from .. import mask_winograd_supported
     if not mask_winograd_supported(cin, cout) or batch * height * width * cin * 4 >= 2 ** 31 - 4096:
         return False
-    tiles = batch * ((height + 1) // 2) * ((width + 1) // 2)
-    return mode == "2" or ((tiles + 63) // 64) * (cout // 64) >= 256
+    # work-groups of 256 output pixels (64 tiles of 2 x 2; F(2 x 4)'s 32 tiles of 2 x 4 give the same count within a few per cent, and the
+    # same layers run in either family: the threshold was measured per layer, tools/winograd_probe.py)
+    groups = (batch * ((height + 1) // 2) * ((width + 1) // 2) + 63) // 64
+    return mode == "2" or groups * (cout // 64) >= 256
 
 
 def _winograd_conv(conv, x):
@@ -79,7 +81,7 @@ def _winograd_conv(conv, x):
 def winograd_family():
     """Which Winograd form the eligible layers run in: "24" = F(2 x 4, 3 x 3) (amos_mask_winograd24_conv_device: 24 multiplies per 2 x 4
     outputs, the default) or "22" = F(2 x 2, 3 x 3) (amos_mask_winograd_conv_device: 16 per 2 x 2).  AMOS_MASK_WINOGRAD_F selects (A/B runs, tests)."""
-    return "22" if os.environ.get("AMOS_MASK_WINOGRAD_F", "22") == "22" else "24"
+    return "22" if os.environ.get("AMOS_MASK_WINOGRAD_F", "24") == "22" else "24"
 
 
 def _winograd_fns():

@@ -226,11 +226,14 @@ def count_network_flops(torch, engine, batch, frames_per_forward):
     network goes through it.  Returns (direct, executed): `direct` counts every convolution at kh x kw multiplies per output and channel
     pair (the figure every convolution library is quoted in); `executed` counts the layers that run as Winograd F(2 x 2, 3 x 3) at
     `frames_per_forward` frames per launch (mask/net.py winograd_rule) at the 16 multiplies per 2 x 2 outputs the MFMA units really
-    perform (4 / 9 of direct; the transforms' additions and the half-empty last tiles of odd sizes are not counted)."""
+    perform (4 / 9 of direct; F(2 x 4, 3 x 3), the default form: 24 per 2 x 4 outputs, 1 / 3 of direct; the transforms' additions and
+    the partly empty last tiles of sizes that are not multiples of the tile are not counted)."""
     import importlib
     import torch.nn.functional as F
     net_mod = importlib.import_module("amos_slam_amd.mask.net")
     total = {"direct": 0.0, "executed": 0.0, "padding": 0.0}
+    # multiplies per output and channel pair of the Winograd form in force over the direct convolution's 9: F(2 x 4): 24 / 8, F(2 x 2): 16 / 4
+    wino_share = (24.0 / 8.0 if net_mod.winograd_family() == "24" else 16.0 / 4.0) / 9.0
     real = F.conv2d
     # the merged prediction-head convolution carries 33 all-zero filters (351 -> 384 output channels: a multiple of 64 for the project's
     # kernels, mask/net.py SharedHead.merge_output_layers): they are launch padding, not work of the network -- not counted, neither as
@@ -256,7 +259,7 @@ def count_network_flops(torch, engine, batch, frames_per_forward):
         finally:
             os.environ["AMOS_MASK_WINOGRAD"] = "0"
         total["direct"] += f
-        total["executed"] += f * (16.0 / 36.0) if wino else f
+        total["executed"] += f * wino_share if wino else f
         return out
 
     F.conv2d = counting
@@ -281,8 +284,9 @@ def conv_kernel_roofline(torch, amos, dev, frames):
     """The dominant kernel of the mask pass against the fp32 MFMA peak, measured live: the project's convolution kernel on the network's
     largest layer (proto_net[8]: 3 x 3, 256 -> 256 channels at 138 x 138, `frames` frames per launch) through the C ABI, after the timed
     region (the chip is otherwise idle), HIP events on the stream the kernel is launched on.  At the bench's launch sizes that layer runs
-    as Winograd F(2 x 2, 3 x 3) (amos::k_winograd_conv): FLOPs AS EXECUTED = 2 x 16 positions x tiles x cin x cout with tiles =
-    frames x 69 x 69 (4 / 9 of the direct convolution's 2 x output pixels x cout x 9 x cin, reported beside it); a launch too small
+    as Winograd F(2 x 4, 3 x 3) (amos::k_winograd24_conv): FLOPs AS EXECUTED = 2 x 24 positions x tiles x cin x cout with tiles =
+    frames x 69 x 35 (0.338 of the direct convolution's 2 x output pixels x cout x 9 x cin, reported beside it; F(2 x 2), when
+    AMOS_MASK_WINOGRAD_F=22 selects it: 2 x 16 x frames x 69 x 69, 4 / 9); a launch too small
     for the Winograd rule runs the direct implicit GEMM (amos::k_conv_gemm) and the two figures coincide."""
     import importlib
     net_mod = importlib.import_module("amos_slam_amd.mask.net")
@@ -296,13 +300,16 @@ def conv_kernel_roofline(torch, amos, dev, frames):
     stream = torch.cuda.current_stream(dev)
     wino = net_mod.winograd_rule(cin, cout, (3, 3), (1, 1), (1, 1), (1, 1), 1, frames, hw, hw)
     if wino:
-        u = torch.empty(16 * cin * cout, device=dev)
-        amos.mask_winograd_weights(stream.cuda_stream, w.data_ptr(), u.data_ptr(), cin, cout)
+        f24 = net_mod.winograd_family() == "24"
+        make_u, conv = (amos.mask_winograd24_weights, amos.mask_winograd24_conv) if f24 else (amos.mask_winograd_weights, amos.mask_winograd_conv)
+        u = torch.empty((24 if f24 else 16) * cin * cout, device=dev)
+        make_u(stream.cuda_stream, w.data_ptr(), u.data_ptr(), cin, cout)
 
         def launch():
-            amos.mask_winograd_conv(stream.cuda_stream, x.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, True)
-        name = "amos::k_winograd_conv"
-        flops = 2.0 * 16 * frames * ((hw + 1) // 2) ** 2 * cin * cout
+            conv(stream.cuda_stream, x.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, True)
+        name = "amos::k_winograd24_conv" if f24 else "amos::k_winograd_conv"
+        # as executed: 2 x positions x tiles x cin x cout (tiles of 2 x 4 outputs, 24 positions; or of 2 x 2 outputs, 16 positions)
+        flops = (2.0 * 24 * frames * ((hw + 1) // 2) * ((hw + 3) // 4) * cin * cout) if f24 else (2.0 * 16 * frames * ((hw + 1) // 2) ** 2 * cin * cout)
     else:
         def launch():
             amos.mask_conv(stream.cuda_stream, x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, 3, 3, 1, 1, True)
@@ -665,7 +672,7 @@ def main():
                                     "frames_per_step": B, "lanes": S, "lane_pass_ms": round(net_ms, 3), "frames_per_lane_pass": Bl,
                                     "forwards_per_lane_pass": n_fwd,
                                     "note": "achieved / frac: convolution FLOPs AS EXECUTED on the MFMA units (2 x MAC; the stride-1 3 x 3 layers that run as "
-                                            "Winograd F(2x2,3x3) counted at 16 instead of 36 multiplies per 2 x 2 outputs: flops_per_frame_executed) of all frames "
+                                            "Winograd F(2x4,3x3) counted at 24 instead of 72 multiplies per 2 x 4 outputs: flops_per_frame_executed) of all frames "
                                             "of a step / the step's wall time, i.e. a lower bound of the convolution kernels' own rate: the step also holds the "
                                             "pre / post-processing, the ORB kernels and the match.  flops_per_frame / achieved_direct_equivalent: the same "
                                             "layers counted as direct convolutions (the figure comparable with a direct-convolution implementation; it may "

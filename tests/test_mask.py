@@ -36,6 +36,13 @@ def _engine(mask, device, case="seed0"):
     return eng
 
 
+def _spy_winograd(gpu_lib, monkeypatch, calls, lo, hi):
+    """Records arguments [lo:hi] of every Winograd convolution launch of either family (F(2 x 2): mask_winograd_conv, F(2 x 4): mask_winograd24_conv)."""
+    for name in ("mask_winograd_conv", "mask_winograd24_conv"):
+        real = getattr(gpu_lib, name)
+        monkeypatch.setattr(gpu_lib, name, lambda *a, _real=real: (calls.append(a[lo:hi]), _real(*a))[1])
+
+
 def _iou(got, want):
     """Intersection over union of two boolean masks; two empty masks agree (the cars-only case)."""
     union = int((got | want).sum())
@@ -256,14 +263,15 @@ def test_network_on_the_project_gemm_vs_reference_gpu(mask, gpu_lib, monkeypatch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("family", ["22", "24"])
 @pytest.mark.parametrize("case", CASES)
-def test_network_with_winograd_everywhere_vs_reference_gpu(mask, gpu_lib, monkeypatch, case):
-    """The golden tensors and the person-mask IoU with EVERY stride-1 3 x 3 convolution of the network forced onto the Winograd kernel (the
-    rule leaves the small launches of one frame to the other paths): same tolerances, same IoU bar."""
+def test_network_with_winograd_everywhere_vs_reference_gpu(mask, gpu_lib, monkeypatch, case, family):
+    """The golden tensors and the person-mask IoU with EVERY stride-1 3 x 3 convolution of the network forced onto the Winograd kernel of
+    either family, F(2 x 2) and F(2 x 4) (the rule leaves the small launches of one frame to the other paths): same tolerances, same IoU bar."""
     monkeypatch.setenv("AMOS_MASK_WINOGRAD", "2")
+    monkeypatch.setenv("AMOS_MASK_WINOGRAD_F", family)
     calls = []
-    real = gpu_lib.mask_winograd_conv
-    monkeypatch.setattr(gpu_lib, "mask_winograd_conv", lambda *a: (calls.append(a[7:11]), real(*a))[1])
+    _spy_winograd(gpu_lib, monkeypatch, calls, 7, 11)
     assert _run(mask, "cuda", 5e-3, 5e-3, fold=True, case=case) >= 1 - 1e-3
     # one forward: 13 bottleneck conv2 with stride 1, 3 FPN prediction layers, 4 protonet layers, 5 levels x (upfeature + merged head
     # output); _run also calls the backbone and the FPN once more on their own
@@ -520,20 +528,21 @@ def test_first_forward_on_a_second_stream_after_prepare(mask, gpu_lib):
                 and m.kernel_size == (3, 3) and m.stride == (1, 1) and gpu_lib.mask_winograd_supported(m.in_channels, m.out_channels)]
     assert len(eligible) >= 20 and all(getattr(m, "_amos_winograd", None) is not None for m in eligible)
     made = []
-    real = gpu_lib.mask_winograd_weights
+    real = (gpu_lib.mask_winograd_weights, gpu_lib.mask_winograd24_weights)
     frames = torch.from_numpy(np.stack([mask_cases.frame(c) for c in ("seed0", "ref122_w0", "tum_w0", "blobs7_w1")] * 8)).cuda()
     x = eng._preprocess_hip(frames)
     torch.cuda.synchronize()
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     try:
-        gpu_lib.mask_winograd_weights = lambda *a: (made.append(a), real(*a))[1]
+        gpu_lib.mask_winograd_weights = lambda *a: (made.append(a), real[0](*a))[1]
+        gpu_lib.mask_winograd24_weights = lambda *a: (made.append(a), real[1](*a))[1]
         with torch.no_grad():
             with torch.cuda.stream(s1):
                 p1 = eng._forward(x)
             with torch.cuda.stream(s2):
                 p2 = eng._forward(x)
     finally:
-        gpu_lib.mask_winograd_weights = real
+        gpu_lib.mask_winograd_weights, gpu_lib.mask_winograd24_weights = real
     torch.cuda.synchronize()
     assert made == [], "a forward after prepare() must not create shared weight tensors"
     ref = _engine(mask, "cuda:0", "seed0").prepare()
@@ -617,7 +626,9 @@ def test_winograd_conv3x3_against_float64(mask, gpu_lib, family):
 
 
 @pytest.mark.gpu
-def test_winograd_dispatch_and_weight_cache(mask, gpu_lib, monkeypatch):
+@pytest.mark.parametrize("family", ["22", "24"])
+def test_winograd_dispatch_and_weight_cache(mask, gpu_lib, monkeypatch, family):
+    monkeypatch.setenv("AMOS_MASK_WINOGRAD_F", family)
     net_mod = importlib.import_module("amos_slam_amd.mask.net")
     F = torch.nn.functional
     cl = torch.channels_last
@@ -626,8 +637,7 @@ def test_winograd_dispatch_and_weight_cache(mask, gpu_lib, monkeypatch):
     x = torch.randn(2, 64, 23, 31, device="cuda").contiguous(memory_format=cl)
     res = torch.randn(2, 128, 23, 31, device="cuda").contiguous(memory_format=cl)
     calls = []
-    real = gpu_lib.mask_winograd_conv
-    monkeypatch.setattr(gpu_lib, "mask_winograd_conv", lambda *a: (calls.append(a[7:11]), real(*a))[1])
+    _spy_winograd(gpu_lib, monkeypatch, calls, 7, 11)
     with torch.no_grad():
         for round_ in range(2):
             want = (F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), 1, 1) + res.double()).relu()
@@ -887,8 +897,7 @@ def test_bench_sized_pass_winograd_against_direct_kernels(mask, gpu_lib, monkeyp
     eng = _engine(mask, "cuda:0", "seed0")
     eng.prepare()
     calls = []
-    real = gpu_lib.mask_winograd_conv
-    monkeypatch.setattr(gpu_lib, "mask_winograd_conv", lambda *a: (calls.append(a[6:11]), real(*a))[1])
+    _spy_winograd(gpu_lib, monkeypatch, calls, 6, 11)
     out = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("AMOS_MASK_WINOGRAD", mode)
