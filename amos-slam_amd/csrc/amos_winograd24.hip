@@ -72,8 +72,11 @@ __device__ __forceinline__ f32x4 w24_fma(float k, f32x4 a, f32x4 b)
 
 // V block of one position: element (row = tile, k) at float offset row * 8 + 4 * ((k >> 2) ^ f(row)) + (k & 3)  (amos_winograd.hip)
 __device__ __host__ __forceinline__ int w24_swz(int row, int half) { return row * 8 + 4 * (half ^ (((row >> 2) ^ (row >> 3)) & 1)); }
-// raw patch: 16-byte unit of (column, channel quad) inside a patch row -- blocks of 32 columns, inside a block [column parity][column / 2][quad]
-__device__ __forceinline__ int w24_raw_unit(int col, int quad) { return (col >> 5) * 64 + (col & 1) * 32 + ((col & 31) >> 1) * 2 + quad; }
+// raw patch: 16-byte unit of (column, channel quad) inside a patch row -- blocks of 32 columns, inside a block [column % 4][column / 4][quad]:
+// one LDS-DMA instruction fills a block lane-linearly with lane pairs fetching the two quads of one pixel (32 contiguous bytes), and the
+// transform's reads (lanes = consecutive tiles x both quads: every FOURTH column) are 32-byte pieces at a 32-byte pitch: conflict-free
+// (with F(2 x 2)'s [parity][column / 2] order the pitch would be 64 bytes: two-way bank conflicts on all ten reads)
+__device__ __forceinline__ int w24_raw_unit(int col, int quad) { return (col >> 5) * 64 + (col & 3) * 16 + ((col & 31) >> 2) * 2 + quad; }
 
 // Weights [cout][3][3][cin] (a channels-last Conv2d weight) -> U = G2 g G4^T in the order the MFMA's B fragments are read: for every
 // (cout tile nt, stage s, position p = 6 a + b, 32-channel block j) 64 lanes x 4 floats, lane l = U_p[nt * 64 + j * 32 + (l & 31)][s * 8 + 4 (l >> 5) ..+3];
@@ -121,10 +124,10 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
     // ---- geometry of the work-group's tile run: segments of tiles of one tile row.  This thread is (a) the loader of raw-patch column
-    // `col` (block `wave`, lane order [parity][half][quad]) for all four patch rows and (b) the transformer of tile `tl`, channel quad
+    // `col` (block `wave`, lane order [column % 4][column / 4][quad]) for all four patch rows and (b) the transformer of tile `tl`, channel quad
     // `quad`, position row `prow`, position columns 3 * half .. + 2.
     const int quad = lane & 1, tl = lane >> 1, prow = wave >> 1;
-    const int col = 32 * wave + 2 * ((lane >> 1) & 15) + (lane >> 5);
+    const int col = 32 * wave + 4 * ((lane >> 1) & 7) + (lane >> 4);  // lane l fills unit l of its block: w24_raw_unit(col, lane & 1) == 64 * wave + l
     int xoff[4];     // loader: byte offset of (patch row r, column col, channel quad) in x, or the buffer's size (zeros) when there is no such pixel
     int colBase = 0; // transformer: first patch column of tile tl
     {
@@ -164,16 +167,24 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     // U fragments of this wave's three positions: [position of the triple][cout block] x 16 bytes per lane and stage
     const float *usrc = a.u + (size_t)nt * a.stages * kW24StageU + (size_t)(wave * 3) * 512 + lane * 4;
 
+#ifdef AMOS_W24_EXP_NOX  /* timing experiments (results are wrong): tools/w24_variants.sh */
+#define AMOS_W24_FETCH_X(s, buf) {}
+#else
 #define AMOS_W24_FETCH_X(s, buf)                                                                                                     \
     {                                                                                                                                \
         _Pragma("unroll") for (int r = 0; r < 4; r++)                                                                                \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (LdsPtr)(AMOS_W24_R(buf) + r * kW24RawRow + wave * 256), 16, xoff[r], (s) * (kW24K * 4), 0, 0); \
     }
+#endif
+#ifdef AMOS_W24_EXP_NOU
+#define AMOS_W24_FETCH_U(fb, s, p) { _Pragma("unroll") for (int j = 0; j < 2; j++) fb[j] = f32x4{(float)(s), (float)lane, 1.f, (float)(p)}; }
+#else
 #define AMOS_W24_FETCH_U(fb, s, p)                                                                                                   \
     {                                                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                                \
             fb[j] = *reinterpret_cast<const f32x4 *>(usrc + (size_t)(s) * kW24StageU + ((p) * 2 + j) * 256);                         \
     }
+#endif
     // raw patch (buffer rb) -> this thread's half row of B2^T d B4 -> the wave's V blocks (buffer vb).  s_c = d[r0][c] +- d[r1][c] for the five
     // columns; half 0: V0 = 4 s0 - 5 s2 + s4, V1 = (s4 - 4 s2) + (s3 - 4 s1), V2 = (s4 - 4 s2) - (s3 - 4 s1);
     // half 1 (s = t1 .. t5): V3 = (s3 - s1) + 2 (s2 - s0), V4 = (s3 - s1) - 2 (s2 - s0), V5 = 4 s0 - 5 s2 + s4.
@@ -183,6 +194,9 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
         return f32x4{__builtin_fmaf(sgn, d1.x, d0.x), __builtin_fmaf(sgn, d1.y, d0.y), __builtin_fmaf(sgn, d1.z, d0.z),              \
                      __builtin_fmaf(sgn, d1.w, d0.w)};  /* exact: sgn = +-1 */                                                       \
     }())
+#ifdef AMOS_W24_EXP_NOT
+#define AMOS_W24_TRANSFORM(rb, vb) {}
+#else
 #define AMOS_W24_TRANSFORM(rb, vb)                                                                                                   \
     {                                                                                                                                \
         const float *rp = AMOS_W24_R(rb);                                                                                            \
@@ -202,6 +216,7 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
             *reinterpret_cast<f32x4 *>(vd + 2 * kW24PosV) = e;                                                                       \
         }                                                                                                                            \
     }
+#endif
 
     f32x16 acc[3][2];  // [position of the triple][cout block]
 #pragma unroll
@@ -238,7 +253,18 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     //   second part (8 MFMAs): position 2 multiplies; position 0's A fragment of stage s + 1 is read; U(s + 2, positions 0 and 1) is requested
     //     into the registers this stage's first part has finished with; the raw patch of stage s + 3 is requested into the buffer the
     //     transform has just released.
+#ifdef AMOS_W24_EXP_NOBAR
+#define AMOS_W24_BARRIER(kVm) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
 #define AMOS_W24_BARRIER(kVm) asm volatile("s_waitcnt vmcnt(" #kVm ") lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#ifndef AMOS_W24_VM_EVERY
+#define AMOS_W24_VM_EVERY 2  /* MFMAs between two vector-memory requests of a stage's second part */
+#endif
+#ifndef AMOS_W24_SPLIT
+#define AMOS_W24_SPLIT 1  /* 1: position 0 | barrier | positions 1, 2 (3 % faster);  0: positions 0, 1 | barrier | position 2 */
+#endif
+#if AMOS_W24_SPLIT == 0
 #define AMOS_W24_STAGE(s, vb, fbC0, fbC1, fbC2, fbN2, kNext, kNext2, kNext3, kVm)         \
     {                                                                                     \
         AMOS_W24_LDFRAG(fa1, vb, 1);                                                      \
@@ -247,10 +273,11 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
         if (kNext) AMOS_W24_FETCH_U(fbN2, (s) + 1, 2);                                    \
         AMOS_W24_MFMAS(fa0, fbC0, 0);                                                     \
         AMOS_W24_MFMAS(fa1, fbC1, 1);                                                     \
-        AMOS_W24_INTERLEAVE(2, 1, 0, 0, 0);  /* the A fragments of positions 1 and 2 */   \
+        /* all twelve LDS reads under the first three MFMAs, their consumers from the fourth on: no LDS latency between two MFMAs */ \
+        AMOS_W24_INTERLEAVE(3, 4, 0, 0, 0);                                               \
         if (kNext) {                                                                      \
-            AMOS_W24_INTERLEAVE(5, 2, 4, 0, 0);   /* ten patch reads, the column sums */  \
-            AMOS_W24_INTERLEAVE(6, 0, 5, 1, 0);   /* the six outputs, three writes */     \
+            AMOS_W24_INTERLEAVE(8, 0, 5, 0, 0);   /* column sums and outputs */           \
+            AMOS_W24_INTERLEAVE(3, 0, 2, 1, 0);   /* three writes */                      \
             AMOS_W24_INTERLEAVE(2, 0, 0, 0, 1);   /* U of position 2 */                   \
         }                                                                                 \
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                               \
@@ -269,15 +296,54 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     }
 #define AMOS_W24_STAGE_EVEN(s, n1, n2, n3, vm) AMOS_W24_STAGE(s, 0, fbE0, fbE1, fbE2, fbO2, n1, n2, n3, vm)
 #define AMOS_W24_STAGE_ODD(s, n1, n2, n3, vm) AMOS_W24_STAGE(s, 1, fbO0, fbO1, fbO2, fbE2, n1, n2, n3, vm)
+#define AMOS_W24_PROLOGUE_U() { AMOS_W24_FETCH_U(fbE0, 0, 0); AMOS_W24_FETCH_U(fbE1, 0, 1); AMOS_W24_FETCH_U(fbE2, 0, 2); AMOS_W24_FETCH_U(fbO0, 1, 0); AMOS_W24_FETCH_U(fbO1, 1, 1); }
+#define AMOS_W24_LOOP_VM 2
+
+#else
+#define AMOS_W24_STAGE(s, vb, fbC0, fbC1, fbC2, fbN1, fbN2, kNext, kNext2, kNext3, kVm)   \
+    {                                                                                     \
+        AMOS_W24_LDFRAG(fa1, vb, 1);                                                      \
+        AMOS_W24_LDFRAG(fa2, vb, 2);                                                      \
+        if (kNext) AMOS_W24_TRANSFORM((vb) ^ 1, (vb) ^ 1);                                \
+        if (kNext) AMOS_W24_FETCH_U(fbN1, (s) + 1, 1);                                    \
+        if (kNext) AMOS_W24_FETCH_U(fbN2, (s) + 1, 2);                                    \
+        AMOS_W24_MFMAS(fa0, fbC0, 0);                                                     \
+        /* all twelve LDS reads under the first three MFMAs, their consumers from the fourth on: no LDS latency between two MFMAs */ \
+        AMOS_W24_INTERLEAVE(3, 4, 0, 0, 0);                                               \
+        if (kNext) {                                                                      \
+            AMOS_W24_INTERLEAVE(2, 0, 12, 0, 1);                                          \
+            AMOS_W24_INTERLEAVE(2, 0, 10, 1, 1);                                          \
+            AMOS_W24_INTERLEAVE(1, 0, 4, 1, 0);                                           \
+        }                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        AMOS_W24_BARRIER(kVm)                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (kNext) AMOS_W24_LDFRAG(fa0, (vb) ^ 1, 0);                                     \
+        if (kNext2) AMOS_W24_FETCH_U(fbC0, (s) + 2, 0);                                   \
+        if (kNext3) AMOS_W24_FETCH_X((s) + 3, (vb) ^ 1);                                  \
+        AMOS_W24_MFMAS(fa1, fbC1, 1);                                                     \
+        AMOS_W24_MFMAS(fa2, fbC2, 2);                                                     \
+        AMOS_W24_INTERLEAVE(1, 1, 0, 0, 0);                                               \
+        /* the six vector-memory requests one per two MFMAs: all eight waves pass here together, and 48 KB requested within a few   \
+           hundred cycles fill the CU's memory pipeline -- the waves then wait to ISSUE, with their MFMAs behind */               \
+        _Pragma("unroll") for (int q = 0; q < 6; q++) {                                   \
+            __builtin_amdgcn_sched_group_barrier(0x008, AMOS_W24_VM_EVERY, 0);            \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                            \
+        }                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                               \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    }
+#define AMOS_W24_STAGE_EVEN(s, n1, n2, n3, vm) AMOS_W24_STAGE(s, 0, fbE0, fbE1, fbE2, fbO1, fbO2, n1, n2, n3, vm)
+#define AMOS_W24_STAGE_ODD(s, n1, n2, n3, vm) AMOS_W24_STAGE(s, 1, fbO0, fbO1, fbO2, fbE1, fbE2, n1, n2, n3, vm)
+#define AMOS_W24_PROLOGUE_U() { AMOS_W24_FETCH_U(fbE0, 0, 0); AMOS_W24_FETCH_U(fbE1, 0, 1); AMOS_W24_FETCH_U(fbE2, 0, 2); AMOS_W24_FETCH_U(fbO0, 1, 0); }
+#define AMOS_W24_LOOP_VM 4
+#endif
 
     // prologue: raw patches of stages 0 and 1; U of stage 0 (three positions) and of stage 1 (positions 0 and 1)
     AMOS_W24_FETCH_X(0, 0);
     AMOS_W24_FETCH_X(1, 1);
-    AMOS_W24_FETCH_U(fbE0, 0, 0);
-    AMOS_W24_FETCH_U(fbE1, 0, 1);
-    AMOS_W24_FETCH_U(fbE2, 0, 2);
-    AMOS_W24_FETCH_U(fbO0, 1, 0);
-    AMOS_W24_FETCH_U(fbO1, 1, 1);
+    AMOS_W24_PROLOGUE_U();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     AMOS_W24_TRANSFORM(0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -285,8 +351,8 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     AMOS_W24_FETCH_X(2, 0);
     int s = 0;
     for (; s + 4 < a.stages; s += 2) {  // two stages per trip: the register names follow the stage parity
-        AMOS_W24_STAGE_EVEN(s, true, true, true, 2);
-        AMOS_W24_STAGE_ODD(s + 1, true, true, true, 2);
+        AMOS_W24_STAGE_EVEN(s, true, true, true, AMOS_W24_LOOP_VM);
+        AMOS_W24_STAGE_ODD(s + 1, true, true, true, AMOS_W24_LOOP_VM);
     }
     // the last four stages (the stage count is even and at least four: amos_mask_winograd_supported): less and less left to request
     AMOS_W24_STAGE_EVEN(s, true, true, true, 0);
@@ -298,6 +364,10 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     // half 0 contributes (M0 + M1 + M2, M1 - M2, M1 + M2, M1 - M2), half 1 (M3 + M4, 2 (M3 - M4), 4 (M3 + M4), 8 (M3 - M4) + M5).  Exchange image:
     // [wave][j][tile 32][cout 32] floats, one cout block of 32 per round.  Accumulator register r of lane l is tile row
     // (r & 3) + 8 (r >> 2) + 4 (l >> 5), channel l & 31 of its 32 x 32 block.
+#ifdef AMOS_W24_EXP_NOEPI
+    if (acc[0][0][0] == 12345.f && acc[1][1][3] == 5.f && acc[2][0][7] == 1.f) a.y[t] = acc[0][1][1] + acc[1][0][2] + acc[2][1][3];  // keeps the accumulators alive
+    return;
+#endif
     __syncthreads();  // every wave is done with the V tiles and the raw patches
     const int oq = t & 7, otl = (t >> 3) & 31, oy = t >> 8;  // finishing thread: channel quad of the round, tile, output row of the tile
 #pragma unroll

@@ -15,12 +15,13 @@ b, cin, cout, hw = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (3
 cl = torch.channels_last
 x = torch.randn(b, cin, hw, hw, device="cuda").contiguous(memory_format=cl)
 w = (torch.randn(cout, cin, 3, 3, device="cuda") / 48).contiguous(memory_format=cl)
-u = torch.empty(16 * cin * cout, device="cuda")
+f24 = os.environ.get("W_FAMILY", "24") == "24"   # F(2 x 4) (default) or F(2 x 2)
+u = torch.empty((24 if f24 else 16) * cin * cout, device="cuda")
 y = torch.empty(b, cout, hw, hw, device="cuda").contiguous(memory_format=cl)
 bias = torch.zeros(cout, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-amos.mask_winograd_weights(st, w.data_ptr(), u.data_ptr(), cin, cout)
+(amos.mask_winograd24_weights if f24 else amos.mask_winograd_weights)(st, w.data_ptr(), u.data_ptr(), cin, cout)
 for _ in range(4):
-    amos.mask_winograd_conv(st, x.data_ptr(), u.data_ptr(), bias.data_ptr(), None, y.data_ptr(), b, hw, hw, cin, cout, True)
+    (amos.mask_winograd24_conv if f24 else amos.mask_winograd_conv)(st, x.data_ptr(), u.data_ptr(), bias.data_ptr(), None, y.data_ptr(), b, hw, hw, cin, cout, True)
 torch.cuda.synchronize()
 print("ok", float(y.sum()))

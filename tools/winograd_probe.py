@@ -76,6 +76,7 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--small-only", action="store_true")
     ap.add_argument("--f24", action="store_true", help="F(2 x 4) against F(2 x 2): time and error on the network's layer shapes")
+    ap.add_argument("--f24-time", action="store_true", help="time of the F(2 x 4) kernel on four layer shapes, no checks (experiment builds)")
     ap.add_argument("--big-only", action="store_true", help="timing of the three largest layer shapes only, no checks (experiment builds)")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -83,6 +84,28 @@ if __name__ == "__main__":
         for cin, cout, hw in ((256, 256, 138), (256, 256, 69), (64, 64, 138)):
             r = run(a.frames, cin, cout, hw, hw, check=False)
             print((cin, cout, hw), r["wino_ms"], r["wino_direct_equiv_TF"], flush=True)
+        sys.exit(0)
+    if a.f24_time:
+        for cin, cout, hw in ((256, 256, 138), (256, 256, 69), (64, 64, 138), (512, 512, 18)):
+            b = a.frames
+            x = torch.randn(b, cin, hw, hw, device="cuda").contiguous(memory_format=cl)
+            wgt = (torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5).contiguous(memory_format=cl)
+            bias = torch.randn(cout, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            u = torch.empty(24 * cin * cout, device="cuda")
+            amos.mask_winograd24_weights(st, wgt.data_ptr(), u.data_ptr(), cin, cout)
+            y = torch.empty((b, cout, hw, hw), device="cuda").contiguous(memory_format=cl)
+            fn = lambda: amos.mask_winograd24_conv(st, x.data_ptr(), u.data_ptr(), bias.data_ptr(), None, y.data_ptr(), b, hw, hw, cin, cout, True)
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            e1.synchronize()
+            print((cin, cout, hw), round(e0.elapsed_time(e1) / 10, 4), end="  ", flush=True)
+        print()
         sys.exit(0)
     if a.f24:
         # F(2 x 4) against F(2 x 2) on every stride-1 3 x 3 layer shape of the network: time and error relative to the sum of |terms|
