@@ -399,9 +399,9 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
                                frameStride, rowStride, h->dPyr, h->dGeom);
         }
         else if (h->p.scale_factor < 1.99f)  // the four taps of a thread fit one 8-byte window
-            hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);
+            hipLaunchKernelGGL(k_pyramid_level<true>, dim3(xcd_grid((int)(grid.x * grid.y), nFrames)), block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l, nFrames);
         else
-            hipLaunchKernelGGL(k_pyramid_level<false>, grid, block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l);
+            hipLaunchKernelGGL(k_pyramid_level<false>, dim3(xcd_grid((int)(grid.x * grid.y), nFrames)), block, 0, h->stream, h->dPyr, h->dGeom, h->dTaps, l, nFrames);
         if (ev && l == 0) (void)hipEventRecord(ev[1], h->stream);
     }
     if (ev) (void)hipEventRecord(ev[2], h->stream);
@@ -410,7 +410,7 @@ static int launch_detect(amos_orb *h, const uint8_t *dSrc, size_t frameStride, s
     AMOS_HIP_CHECK(hipEventRecord(h->evFork, h->stream));
     AMOS_HIP_CHECK(hipStreamWaitEvent(h->streamB, h->evFork, 0));
     if (ev) (void)hipEventRecord(h->evBlur0, h->streamB);
-    hipLaunchKernelGGL(k_blur, dim3((g.blurItems + 255) / 256, nFrames), dim3(256), 0, h->streamB, h->dPyr, h->dBlur, h->dGeom);
+    hipLaunchKernelGGL(k_blur, dim3(xcd_grid((g.blurItems + 255) / 256, nFrames)), dim3(256), 0, h->streamB, h->dPyr, h->dBlur, h->dGeom, nFrames);
     if (ev) (void)hipEventRecord(h->evBlur1, h->streamB);
     AMOS_HIP_CHECK(hipEventRecord(h->evJoin, h->streamB));
     h->blurDone = true;

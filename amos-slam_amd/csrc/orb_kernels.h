@@ -70,7 +70,7 @@ __device__ __forceinline__ uint8_t *level_origin(uint8_t *pyr, const Geom *g, in
 // reflect-101 source coordinate (the host-built tap tables are indexed by padded
 // coordinate with the reflection folded in).
 // Level 0 is imported by k_pyramid_level0_wide (16 bytes per lane); levels >= 1 by k_pyramid_level with
-// grid = (ceil(groups/64), ceil((h+38)/(4*kPyrRows)), frames), block = (64, 4).
+// grid = xcd_grid(ceil(groups/64) * ceil((h+38)/(4*kPyrRows)), frames), block = (64, 4).
 constexpr int kPyrRows = 8;  // padded rows per thread (x taps are loaded once; consecutive rows share source rows)
 
 // Level 0, 16 bytes per lane.  Interior pieces (16 consecutive bytes of the padded plane whose source is
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_import_color_mask(const uint8_t *__rest
 //     row of output row r is the first of row r+1" (most rows at scale 1.2) is a scalar branch that
 //     reuses the four H values;
 //   * vertical pass ((b*(H>>4))>>16 per tap) = v_and + v_mul_hi_u32_u24 with b << 12.
-// grid = (ceil(groups/64), ceil((h+38)/(4*kPyrRows)), frames), block = (64, 4).
+// grid = xcd_grid(ceil(groups/64) * ceil((h+38)/(4*kPyrRows)), frames), block = (64, 4).
 __device__ __forceinline__ unsigned mul_hi_u24(unsigned a, unsigned b)
 {
     unsigned r;
@@ -285,16 +285,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_buffer(const void *p, uns
 
 template <bool kWide>
 __global__ __launch_bounds__(256) void k_pyramid_level(uint8_t *__restrict__ pyr, const Geom *__restrict__ g,
-                                                      const ResizeTap *__restrict__ taps, int level)
+                                                      const ResizeTap *__restrict__ taps, int level, int nFrames)
 {
     typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
     typedef unsigned uint2v __attribute__((ext_vector_type(2)));
     const LevelGeom &lg = g->lv[level];
-    const int frame = blockIdx.z;
-    const int gx = blockIdx.x * 64 + threadIdx.x;
-    const int row0 = __builtin_amdgcn_readfirstlane((blockIdx.y * 4 + threadIdx.y) * kPyrRows);  // padded row, 0 = yo -19
     const int groups = (kPadLeft + lg.w + kEdge + 3) >> 2;
     const int nrows = lg.h + 2 * kEdge;
+    // 1-D grid decoded XCD-aware (xcd_frame_chunk): all work-groups of a frame's level run on ONE XCD close together in time, so a source
+    // row that several row groups (and the 8-byte windows of neighbouring lanes) read comes from HBM once -- with the (x, y, frame) grid
+    // the work-groups of a frame were dealt over all eight XCDs and each L2 fetched the rows again (2.6 x the level's bytes)
+    const int nbx = (groups + 63) >> 6, nby = (nrows + 4 * kPyrRows - 1) / (4 * kPyrRows);
+    int frame, chunk;
+    if (!xcd_frame_chunk(blockIdx.x, nbx * nby, nFrames, frame, chunk)) return;
+    const int by = chunk / nbx, bx = chunk - by * nbx;
+    const int gx = bx * 64 + threadIdx.x;
+    const int row0 = __builtin_amdgcn_readfirstlane((by * 4 + threadIdx.y) * kPyrRows);  // padded row, 0 = yo -19
     if (row0 >= nrows) return;
     const bool active = gx < groups;
     const LevelGeom &pg = g->lv[level - 1];
@@ -1292,13 +1298,14 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
 constexpr int kBlurStrip = 64;
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
-                                             const Geom *__restrict__ g)
+                                             const Geom *__restrict__ g, int nFrames)
 {
     typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
     typedef unsigned uint4v __attribute__((ext_vector_type(4)));
     typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-    const int item = blockIdx.x * 256 + threadIdx.x;
-    const int frame = blockIdx.y;
+    int frame, chunk;  // XCD-aware: vertically adjacent strips (six shared halo rows) of a frame run on one XCD
+    if (!xcd_frame_chunk(blockIdx.x, (g->blurItems + 255) >> 8, nFrames, frame, chunk)) return;
+    const int item = chunk * 256 + threadIdx.x;
     const bool active = item < g->blurItems;
     int level = 0;
     for (int l = 1; l < g->nLevels; l++)
