@@ -176,13 +176,18 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (LdsPtr)(AMOS_W24_R(buf) + r * kW24RawRow + wave * 256), 16, xoff[r], (s) * (kW24K * 4), 0, 0); \
     }
 #endif
+#ifdef AMOS_W24_U_NT   /* experiment: the weight stream with the non-temporal hint */
+#define AMOS_W24_ULOAD(p) __builtin_nontemporal_load(p)
+#else
+#define AMOS_W24_ULOAD(p) (*(p))
+#endif
 #ifdef AMOS_W24_EXP_NOU
 #define AMOS_W24_FETCH_U(fb, s, p) { _Pragma("unroll") for (int j = 0; j < 2; j++) fb[j] = f32x4{(float)(s), (float)lane, 1.f, (float)(p)}; }
 #else
 #define AMOS_W24_FETCH_U(fb, s, p)                                                                                                   \
     {                                                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                                \
-            fb[j] = *reinterpret_cast<const f32x4 *>(usrc + (size_t)(s) * kW24StageU + ((p) * 2 + j) * 256);                         \
+            fb[j] = AMOS_W24_ULOAD(reinterpret_cast<const f32x4 *>(usrc + (size_t)(s) * kW24StageU + ((p) * 2 + j) * 256));          \
     }
 #endif
     // raw patch (buffer rb) -> this thread's half row of B2^T d B4 -> the wave's V blocks (buffer vb).  s_c = d[r0][c] +- d[r1][c] for the five
