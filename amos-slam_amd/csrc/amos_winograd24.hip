@@ -50,7 +50,13 @@ constexpr int kW24StageV = kW24Pos * kW24PosV;            // floats of one stage
 constexpr int kW24RawCols = 256;                          // columns of the raw patch (32 tiles in up to 32 one-tile segments: 32 x 6 = 192)
 constexpr int kW24RawRow = kW24RawCols * kW24K;           // floats of one patch row
 constexpr int kW24StageR = 4 * kW24RawRow;                // floats of one raw patch (32 KB)
-constexpr int kW24LdsFloats = 8 * 4 * 32 * 32;            // the epilogue's exchange image (128 KB) > 2 V tiles + 2 raw patches (112 KB)
+#ifndef AMOS_W24_XAHEAD
+#define AMOS_W24_XAHEAD 1  /* stages between the request of a raw patch and the barrier that needs it: 1 (two patch buffers) or 2 (three, experiment) */
+#endif
+constexpr int kW24RawBufs = AMOS_W24_XAHEAD + 1;
+constexpr int kW24ExchangeFloats = 8 * 4 * 32 * 32;       // the epilogue's exchange image (128 KB)
+constexpr int kW24LoopFloats = 2 * kW24StageV + kW24RawBufs * kW24StageR;  // 2 V tiles + 2 (3) raw patches: 112 (144) KB
+constexpr int kW24LdsFloats = kW24ExchangeFloats > kW24LoopFloats ? kW24ExchangeFloats : kW24LoopFloats;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -309,7 +315,7 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     {                                                                                     \
         AMOS_W24_LDFRAG(fa1, vb, 1);                                                      \
         AMOS_W24_LDFRAG(fa2, vb, 2);                                                      \
-        if (kNext) AMOS_W24_TRANSFORM((vb) ^ 1, (vb) ^ 1);                                \
+        if (kNext) AMOS_W24_TRANSFORM(AMOS_W24_RB_READ(vb), (vb) ^ 1);                                \
         if (kNext) AMOS_W24_FETCH_U(fbN1, (s) + 1, 1);                                    \
         if (kNext) AMOS_W24_FETCH_U(fbN2, (s) + 1, 2);                                    \
         AMOS_W24_MFMAS(fa0, fbC0, 0);                                                     \
@@ -326,7 +332,7 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
         __builtin_amdgcn_sched_barrier(0);                                                \
         if (kNext) AMOS_W24_LDFRAG(fa0, (vb) ^ 1, 0);                                     \
         if (kNext2) AMOS_W24_FETCH_U(fbC0, (s) + 2, 0);                                   \
-        if (kNext3) AMOS_W24_FETCH_X((s) + 3, (vb) ^ 1);                                  \
+        if (kNext3) AMOS_W24_FETCH_X((s) + 2 + AMOS_W24_XAHEAD, AMOS_W24_RB_READ(vb));                                  \
         AMOS_W24_MFMAS(fa1, fbC1, 1);                                                     \
         AMOS_W24_MFMAS(fa2, fbC2, 2);                                                     \
         AMOS_W24_INTERLEAVE(1, 1, 0, 0, 0);                                               \
@@ -338,29 +344,46 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
         }                                                                                 \
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                               \
         __builtin_amdgcn_sched_barrier(0);                                                \
+        AMOS_W24_RB_ADVANCE();                                                            \
     }
 #define AMOS_W24_STAGE_EVEN(s, n1, n2, n3, vm) AMOS_W24_STAGE(s, 0, fbE0, fbE1, fbE2, fbO1, fbO2, n1, n2, n3, vm)
 #define AMOS_W24_STAGE_ODD(s, n1, n2, n3, vm) AMOS_W24_STAGE(s, 1, fbO0, fbO1, fbO2, fbE1, fbE2, n1, n2, n3, vm)
 #define AMOS_W24_PROLOGUE_U() { AMOS_W24_FETCH_U(fbE0, 0, 0); AMOS_W24_FETCH_U(fbE1, 0, 1); AMOS_W24_FETCH_U(fbE2, 0, 2); AMOS_W24_FETCH_U(fbO0, 1, 0); }
+#if AMOS_W24_XAHEAD == 1
 #define AMOS_W24_LOOP_VM 4
+#define AMOS_W24_RB_READ(vb) ((vb) ^ 1)   /* the raw patch of stage s + 1 sits in buffer (s + 1) & 1 */
+#define AMOS_W24_RB_ADVANCE()
+#else
+#define AMOS_W24_LOOP_VM 14               /* younger than the patch request the barrier needs: 4 + 2 U and 4 X of the stage before, 4 U of this one */
+#define AMOS_W24_RB_READ(vb) rbuf         /* ... in buffer (s + 1) % 3, a wave-uniform run-time index */
+#define AMOS_W24_RB_ADVANCE() rbuf = rbuf == 2 ? 0 : rbuf + 1;
+#endif
 #endif
 
     // prologue: raw patches of stages 0 and 1; U of stage 0 (three positions) and of stage 1 (positions 0 and 1)
     AMOS_W24_FETCH_X(0, 0);
     AMOS_W24_FETCH_X(1, 1);
+#if AMOS_W24_XAHEAD == 2
+    AMOS_W24_FETCH_X(2, 2);
+#endif
     AMOS_W24_PROLOGUE_U();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     AMOS_W24_TRANSFORM(0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     AMOS_W24_LDFRAG(fa0, 0, 0);
+#if AMOS_W24_XAHEAD == 1
     AMOS_W24_FETCH_X(2, 0);
+#else
+    AMOS_W24_FETCH_X(3, 0);
+    int rbuf = 1;  // buffer of the raw patch of stage s + 1
+#endif
     int s = 0;
     for (; s + 4 < a.stages; s += 2) {  // two stages per trip: the register names follow the stage parity
         AMOS_W24_STAGE_EVEN(s, true, true, true, AMOS_W24_LOOP_VM);
         AMOS_W24_STAGE_ODD(s + 1, true, true, true, AMOS_W24_LOOP_VM);
     }
     // the last four stages (the stage count is even and at least four: amos_mask_winograd_supported): less and less left to request
-    AMOS_W24_STAGE_EVEN(s, true, true, true, 0);
+    AMOS_W24_STAGE_EVEN(s, true, true, AMOS_W24_XAHEAD == 1, 0);
     AMOS_W24_STAGE_ODD(s + 1, true, true, false, 0);
     AMOS_W24_STAGE_EVEN(s + 2, true, false, false, 0);
     AMOS_W24_STAGE_ODD(s + 3, false, false, false, 0);
