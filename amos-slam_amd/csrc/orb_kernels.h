@@ -1456,7 +1456,10 @@ constexpr int kDescR = 18;          // |rotated offset| <= sqrt(13^2 + 13^2) = 1
 constexpr int kDescRowBytes = 48;   // columns -18 .. +29 as three 16-byte pieces
 constexpr int kDescRows = 2 * kDescR + 1;
 
-constexpr int kDescKps = 16;  // keypoints per work-group (16 lanes each): 18 KB of LDS, so several groups share a CU with FAST's tiles
+#ifndef AMOS_DESC_KPS
+#define AMOS_DESC_KPS 16
+#endif
+constexpr int kDescKps = AMOS_DESC_KPS;  // keypoints per work-group (16 lanes each): 28 KB of patches + 4 KB of pattern in LDS
 
 __global__ __launch_bounds__(kDescKps * 16) void k_describe(const uint8_t *__restrict__ blur, const Geom *__restrict__ g,
                                                            const amos_keypoint *__restrict__ lvKps,
