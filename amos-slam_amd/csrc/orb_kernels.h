@@ -464,12 +464,14 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
 }
 
 #ifndef AMOS_FAST_CAND_CAP
-#define AMOS_FAST_CAND_CAP 768
+#define AMOS_FAST_CAND_CAP 1024
 #endif
 // candidate list (uint16 entries); one phase-1 iteration appends up to 512, so the list is flushed (scored, forgotten: phase 3 then scans
 // the arc map instead) once it holds more than kFastCandCap - 512 with iterations to go.  A 30 x 30-pixel cell has 75 - 150 candidates.
 // The list shares its LDS with the overflow path's `kept` list (written only after the last candidate has its arc value): LDS per wave
-// decides how many cells a CU works on at a time (6 work-groups of four at 640 x 480, was 4 with separate 2 KB + 1.3 KB lists).
+// decides how many cells a CU works on at a time (5 work-groups of four at 640 x 480, was 4 with separate 2 KB + 1.3 KB lists).  1 024 entries:
+// with 768 a 640 x 480 frame runs the same (six work-groups) but the 59-pixel cells of 1920 x 1080 / 12 levels overflow the list more often
+// and fall back to scanning the arc map: 34.7 k against 37.7 k frames/s on BASELINE configs[4] (tools/r4_c5.sh).
 constexpr int kFastCandCap = AMOS_FAST_CAND_CAP;
 __host__ __device__ constexpr size_t fast_list_bytes(int keptCap) { return (size_t)kFastCandCap * 2 > (size_t)keptCap * 4 ? (size_t)kFastCandCap * 2 : (size_t)keptCap * 4; }
 
