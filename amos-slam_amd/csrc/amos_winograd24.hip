@@ -41,9 +41,10 @@ constexpr int kW24K = 8;          // input channels per stage
 constexpr int kW24Threads = 512;
 constexpr int kW24Pos = 24;       // 4 x 6 positions
 #ifndef AMOS_W24_GROUP
-#define AMOS_W24_GROUP 4
+#define AMOS_W24_GROUP 16
 #endif
-constexpr int kW24Group = AMOS_W24_GROUP;                 // m blocks of an XCD whose n tiles run side by side (amos_winograd.hip, map 1)
+constexpr int kW24Group = AMOS_W24_GROUP;                 // m blocks of an XCD that run one n tile before the next (amos_winograd.hip, map 1); 16: 2 - 3 % faster than
+                                                          // 1 .. 8 on the 256-channel layers and the least L2 fetch traffic (2.24 GB per launch of proto_net[8] against 2.56; tools/r4_w24_map.sh)
 constexpr int kW24StageU = kW24Pos * kW24Cout * kW24K;    // floats of one stage's U image (48 KB)
 constexpr int kW24PosV = kW24Tiles * kW24K;               // floats of one position's V block (1 KB)
 constexpr int kW24StageV = kW24Pos * kW24PosV;            // floats of one stage's V tile (24 KB)
@@ -120,8 +121,9 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     constexpr int half = kHalf;
 #define AMOS_W24_V(buf) (smem24 + (buf) * kW24StageV)
 #define AMOS_W24_R(buf) (smem24 + 2 * kW24StageV + (buf) * kW24StageR)
-    // id -> (m block, n tile): an XCD (ids are dealt round-robin over the 8 XCDs) owns a contiguous run of m blocks and runs the n tiles of
-    // kW24Group of them side by side (amos_winograd.hip, map 1: the patch of an m block is fetched from memory once per XCD)
+    // id -> (m block, n tile): an XCD (ids are dealt round-robin over the 8 XCDs) owns a contiguous run of m blocks and walks it in groups of
+    // kW24Group blocks, n tile after n tile (amos_winograd.hip, map 1: the group's patches stay in the XCD's L2 for the next n tile, and
+    // half the XCD's CUs share one weight slice at a time)
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
     const int per = kW24Group * a.nTiles, grp = seq / per, in = seq - grp * per;
     const int perXcd = (a.mBlocks + 7) >> 3, mbLocal = grp * kW24Group + in % kW24Group;
