@@ -362,6 +362,8 @@ def main():
                     help="precision of the mask network's convolutions (c3 only; fp32 is the parity configuration)")
     ap.add_argument("--mask-chunk", type=int, default=0, help="frames per network forward (default: frames per lane)")
     ap.add_argument("--match-kernel", choices=["auto", "popcount", "mfma"], default="auto", help="brute-force matcher kernel (identical results; A/B switch)")
+    ap.add_argument("--latency-frames", type=int, default=30, help="frames of the single-frame drop-in latency measurement reported as the extra key "
+                    "`drop_in_latency` (rank 0 of a one-GPU run, after every timed region; 0 = skip); never part of `value`")
     ap.add_argument("--check", action="store_true", help="verify frames of the batch against the oracle")
     ap.add_argument("--dry-run", action="store_true", help="launcher / collective rehearsal without a GPU (value null)")
     args = ap.parse_args()
@@ -630,6 +632,46 @@ def main():
                  "window_best2_ms": round(g_ms[2], 4), "queries_per_s": round(em["mean_kp"] * bl / (sum(g_ms) * 1e-3), 1),
                  "matched_within_TH_HIGH": int((d_win[:, :, 1] <= 100).sum().item())}
 
+    # The path Tracking.cc:366 / Frame.cc:480-496 really take: ONE frame at a time, host buffers in and out (PCIe inside the figure).  An extra
+    # key for the reader, measured after every timed region; the headline is the resident batch rate above, never this.
+    latency = None
+    if rank == 0 and world == 1 and args.latency_frames > 0 and (W, H) == (640, 480):
+        try:
+            n = args.latency_frames
+            lat_ext = pkg.OrbExtractor(n_features=cfg["n_features"], n_levels=cfg["n_levels"], max_width=W, max_height=H, max_batch=1, device=local_rank)
+            lat_m = pkg.OrbMatcher(device=local_rank)
+            fr = [np.ascontiguousarray(frames_np[k % len(frames_np)]) for k in range(n + 5)]
+            for f in fr[:5]:
+                lat_ext.extract(f)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for f in fr[5:]:
+                lat_ext.extract(f)
+            t1 = time.perf_counter()
+            prev = None
+            for f in fr[5:]:
+                _, dsc = lat_ext.extract(f)
+                if prev is not None:
+                    lat_m.bruteforce_best2(dsc, prev)
+                prev = dsc
+            t2 = time.perf_counter()
+            latency = {"what": "one 640x480 frame per call through the host-buffer API (upload, kernels, download; what Tracking.cc:366 / Frame.cc:480-496 call)",
+                       "frames": n, "orb_extract_ms": round((t1 - t0) / n * 1e3, 3), "orb_extract_and_match_ms": round((t2 - t1) / n * 1e3, 3)}
+            if use_mask:
+                engine.capture_graph(batch=1)  # network + detection + mask assembly of one frame as one HIP graph
+                one = (d_bgr[:1] if d_bgr is not None else d_frames[:1].unsqueeze(-1).expand(-1, -1, -1, 3)).contiguous()
+                for _ in range(3):
+                    engine.eval_bgr_graph(one)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for _ in range(n):
+                    engine.eval_bgr_graph(one)
+                torch.cuda.synchronize()
+                latency["mask_pass_one_frame_graph_ms"] = round((time.perf_counter() - t3) / n * 1e3, 3)
+                latency["frames_per_s_one_stream"] = round(1e3 / (latency["orb_extract_and_match_ms"] + latency["mask_pass_one_frame_graph_ms"]), 1)
+        except Exception as exc:  # an extra: never fail the bench line over it
+            latency = {"error": repr(exc)[:300]}
+
     if rank == 0:
         lw, lh = lanes[0].ext.level_sizes(W, H)
         out = {
@@ -740,6 +782,8 @@ def main():
             out["pipeline_roofline"] = pipeline
         if gated:
             out["gated_match"] = gated
+        if latency:
+            out["drop_in_latency"] = latency
         n_cpu = args.cpu_frames if args.cpu_frames >= 0 else (100 if W == 640 else 12)
         if world == 1 and n_cpu > 0:
             granted, quota = granted_cores()
