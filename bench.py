@@ -564,7 +564,7 @@ def main():
     mean_kp = float(np.mean(n_kp))
     digest_all = shard.gather_digests(digest, coll_dev)  # the one collective of the path
 
-    checked = None
+    checked, mask_iou = None, None
     if args.check and rank == 0:
         import oracle_binding as ob
         orc = ob.Oracle(n_features=cfg["n_features"], n_levels=cfg["n_levels"])
@@ -580,6 +580,19 @@ def main():
                 ko, do = orc.extract(frame)
             assert kg.tobytes() == ko.tobytes() and dg.tobytes() == do.tobytes(), f"lane {li} frame {f} differs from the oracle"
             checked += 1
+        if use_mask:
+            # the masks themselves: lane 0's first and last frame of the LAST timed step (made by the batch launches the headline is made of)
+            # against a one-frame eager pass of the same frame through the engine's own entry point (IoU >= 1 - 1e-3, north_star's bound)
+            mask_iou = []
+            for f in (0, Bl - 1):
+                bgr1 = lanes[0].bgr[f].cpu().numpy()
+                one = engine.eval_bgr(bgr1)
+                got = lanes[0].masks[f].cpu().numpy() > 0
+                want = (one.cpu().numpy() > 0) if one is not None else np.zeros_like(got)
+                union = int((got | want).sum())
+                iou = 1.0 if union == 0 else int((got & want).sum()) / union
+                assert iou >= 1 - 1e-3, f"lane 0 frame {f}: mask of the {Bl}-frame launch vs the one-frame pass: IoU {iou}"
+                mask_iou.append(round(iou, 6))
 
     # ---------------------------------------------------------------- mask-off extract+match leg (c3 runs) or the same leg's extras
     em = None  # dict describing the extract+match measurement the roofline refers to
@@ -699,6 +712,8 @@ def main():
         }
         if checked is not None:
             out["oracle_checked_frames"] = checked
+            if use_mask:
+                out["mask_checked_iou_vs_one_frame_pass"] = mask_iou
         import torch.distributed as dist
         if dist.is_initialized():  # under a launcher, also with one rank: the collectives above ran through this group
             out["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}

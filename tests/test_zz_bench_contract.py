@@ -53,6 +53,8 @@ def test_default_run_is_the_baseline_metric_with_the_mask(gpu_lib):
               "--cpu-cores", "2", "--check"])
     _common(d, 2, 1)
     assert "+mask" in d["metric"] and "configs[2]" in d["config"]["workload"]
+    ious = d["mask_checked_iou_vs_one_frame_pass"]   # --check on a mask-on run: lane 0's first and last mask against a one-frame eager pass
+    assert len(ious) == 2 and min(ious) >= 1 - 1e-3
     assert "fp32" in d["dtype"]
     assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 0.01      # value = frames / time
     leg = d["extract_match_leg"]
