@@ -22,17 +22,17 @@ BEST2_DTYPE = np.dtype([("best_idx", "<i4"), ("best_dist", "<i4"), ("second_idx"
 TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # ORBmatcher.cc:49-51
 
 EXPORTS = [
-    "amos_last_error", "amos_device_count", "amos_orb_geometry_probe", "amos_orb_create", "amos_orb_destroy", "amos_orb_tables",
+    "amos_last_error", "amos_device_count", "amos_current_device", "amos_build_variant", "amos_orb_tables_host", "amos_orb_geometry_probe", "amos_orb_create", "amos_orb_destroy", "amos_orb_tables",
     "amos_orb_level_sizes", "amos_orb_detect", "amos_orb_level_count", "amos_orb_level_keypoints",
     "amos_orb_set_level_keypoints", "amos_orb_level_layout", "amos_orb_fetch_levels", "amos_orb_store_levels", "amos_orb_gate", "amos_orb_closed_mask", "amos_orb_describe",
-    "amos_orb_extract", "amos_orb_level_image", "amos_orb_blurred_image", "amos_orb_level_candidates",
+    "amos_orb_extract", "amos_orb_level_image", "amos_orb_pyramid_images", "amos_orb_blurred_image", "amos_orb_level_candidates",
     "amos_orb_extract_batch_device", "amos_orb_detect_batch_device", "amos_orb_gate_batch_device",
     "amos_orb_describe_batch_device", "amos_orb_extract_batch_device_color", "amos_frame_rgbd_glue_batch_device", "amos_frame_undistort_batch_device", "amos_frame_image_bounds", "amos_frame_grid_build_batch_device", "amos_match_window_best2_batch_device",
     "amos_orb_batch_results_device", "amos_orb_batch_fetch", "amos_orb_sync",
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_corners_create", "amos_corners_destroy", "amos_corners_stream", "amos_corners_good_features_device", "amos_corners_candidate_count", "amos_corners_subpix_device", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_winograd24_weight_floats", "amos_mask_winograd24_weights_device", "amos_mask_winograd24_conv_device", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_topk_rows_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_corners_create", "amos_corners_destroy", "amos_corners_stream", "amos_corners_good_features_device", "amos_corners_candidate_count", "amos_corners_subpix_device", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_winograd24_weight_floats", "amos_mask_winograd24_weights_device", "amos_mask_winograd24_conv_device", "amos_mask_winograd24_conv_layout_device", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_topk_rows_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -64,6 +64,13 @@ def lib():
             pass
         L = C.CDLL(LIB_PATH)
         L.amos_last_error.restype = C.c_char_p
+        L.amos_build_variant.restype = C.c_char_p
+        variant = L.amos_build_variant().decode()
+        if variant != "default" and os.environ.get("AMOS_ALLOW_EXPERIMENT_BUILD") != "1":
+            # timing-experiment builds (tools/*_variants.sh) compute WRONG results by design: never load one by accident (a stale
+            # AMOS_FRONTEND_LIB export); the experiment scripts set AMOS_ALLOW_EXPERIMENT_BUILD=1 themselves
+            raise AmosError(f"{LIB_PATH} is an experiment build ({variant}): its results are wrong; unset AMOS_FRONTEND_LIB "
+                            "or set AMOS_ALLOW_EXPERIMENT_BUILD=1 for a timing run")
         L.amos_orb_stream.restype = C.c_void_p
         L.amos_match_stream.restype = C.c_void_p
         L.amos_orb_destroy.restype = None
@@ -491,6 +498,15 @@ def mask_winograd24_conv(stream_ptr, x_ptr, u_ptr, bias_ptr, residual_ptr, y_ptr
     _check(lib().amos_mask_winograd24_conv_device(C.c_void_p(stream_ptr), C.c_void_p(x_ptr), C.c_void_p(u_ptr), C.c_void_p(bias_ptr), C.c_void_p(residual_ptr),
                                                   C.c_void_p(y_ptr), C.c_int(batch), C.c_int(h), C.c_int(w), C.c_int(cin), C.c_int(cout), C.c_int(int(relu))),
            "amos_mask_winograd24_conv_device")
+
+
+def mask_winograd24_conv_layout(stream_ptr, x_ptr, u_ptr, bias_ptr, residual_ptr, y_ptr, batch, h, w, cin, cout, relu, in_blocked, out_blocked):
+    """amos_mask_winograd24_conv_layout_device: mask_winograd24_conv with the channel-blocked layout [batch][c / 8][h][w][8] on the input
+    (in_blocked) and / or on the output and residual (out_blocked); False = channels-last."""
+    _check(lib().amos_mask_winograd24_conv_layout_device(C.c_void_p(stream_ptr), C.c_void_p(x_ptr), C.c_void_p(u_ptr), C.c_void_p(bias_ptr),
+                                                         C.c_void_p(residual_ptr), C.c_void_p(y_ptr), C.c_int(batch), C.c_int(h), C.c_int(w), C.c_int(cin),
+                                                         C.c_int(cout), C.c_int(int(relu)), C.c_int(int(in_blocked)), C.c_int(int(out_blocked))),
+           "amos_mask_winograd24_conv_layout_device")
 
 
 def mask_conv_tile_mode(mode=-2):

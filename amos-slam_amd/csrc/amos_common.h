@@ -18,22 +18,31 @@ void set_error(const char *fmt, ...);
         if (_e != hipSuccess) {                                                                \
             amos::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,   \
                             __LINE__);                                                         \
+            (void)hipGetLastError(); /* reported here: it must not surface again at the next launch's check */ \
             return AMOS_ERR_DEVICE;                                                            \
         }                                                                                      \
     } while (0)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting of a kernel: a "set once" flag must be kept per device (a
 // host that opens two GPUs in one process would otherwise launch with the default 64 KB limit on the second one) and be safe to reach
-// from several threads (setting the same value twice is harmless; the flag is published only after the call succeeded).  The caller
-// must have the device of the stream it is about to launch on current (as every handle of this library does).
+// from several threads (setting the same value twice is harmless; the flag is published only after the call succeeded).  The attribute is
+// set on the CURRENT device, so the stream the launch goes to must belong to it: the bare-stream entry points (amos_mask_*_device) pass
+// their stream and get hipErrorInvalidDevice when it belongs to another device than the caller's current one (a launch there would
+// otherwise fail, or run with the 64 KB default, far from the cause).
 struct DeviceOnce {
     std::atomic<unsigned long long> done[4] = {};  // bit per device ordinal, 256 ordinals; larger ordinals are simply set every time
 };
-inline hipError_t set_max_dynamic_lds(DeviceOnce &once, const void *kernel, int bytes)
+inline hipError_t set_max_dynamic_lds(DeviceOnce &once, const void *kernel, int bytes, hipStream_t stream = nullptr)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    if (stream) {
+        hipDevice_t sdev = 0;
+        e = hipStreamGetDevice(stream, &sdev);
+        if (e != hipSuccess) return e;
+        if ((int)sdev != dev) return hipErrorInvalidDevice;
+    }
     const bool tracked = dev >= 0 && dev < 256;
     const unsigned long long bit = 1ull << (dev & 63);
     if (tracked && (once.done[dev >> 6].load(std::memory_order_acquire) & bit)) return hipSuccess;
@@ -121,4 +130,5 @@ struct amos_mask_pre;
 namespace amos {
 int mask_pre_stage_a(amos_mask_pre *p, MaskPreStageA *out);                              // tables and buffers of stage A
 int mask_pre_finish(amos_mask_pre *p, hipStream_t stream, int n_frames, float *d_out);  // stages B and C on `stream`
+const char *w24_variant_tag();  // amos_winograd24.hip: " NAME" per timing-experiment switch compiled in, "" for the product build
 }  // namespace amos

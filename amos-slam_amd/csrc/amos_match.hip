@@ -600,6 +600,11 @@ struct amos_match {
     size_t capOff = 0, capIdx = 0;
     void *dOut = nullptr;
     size_t capOut = 0;
+    // pinned host staging of the host-buffer calls: the caller's (pageable) arrays are copied here and travel as true asynchronous DMA
+    // transfers; results land here behind the kernel and are copied out after the ONE synchronisation of the call (a hipMemcpyAsync on
+    // pageable memory is a blocking staged copy of its own: six of them were most of a 0.26 ms list-distance call)
+    uint8_t *hStage = nullptr;
+    size_t capStage = 0, stageUsed = 0;
     int bfKernel = 0;  // brute-force best-2: 0 = choose by size, 1 = xor + popcount kernel, 2 = i8 MFMA kernel
 };
 
@@ -646,14 +651,62 @@ static int grow(T **p, size_t *cap, size_t need)
     return AMOS_OK;
 }
 
+// every host-buffer call ends with a stream synchronisation, so the staging buffer is free at the start of the next one
+static int stage_begin(amos_match *m, size_t bytes)
+{
+    m->stageUsed = 0;
+    bytes += 1024;  // alignment slack of the pieces
+    if (bytes <= m->capStage) return AMOS_OK;
+    if (m->hStage) {
+        (void)hipStreamSynchronize(m->stream);  // (a call that failed half way may have left a transfer reading the old buffer)
+        (void)hipHostFree(m->hStage);
+    }
+    m->hStage = nullptr;
+    m->capStage = 0;
+    const size_t n = std::max<size_t>(bytes + bytes / 2, 1 << 16);
+    if (hipHostMalloc((void **)&m->hStage, n, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipHostMalloc (matcher staging, %zu bytes) failed", n);
+        return AMOS_ERR_DEVICE;
+    }
+    m->capStage = n;
+    return AMOS_OK;
+}
+
+static uint8_t *stage_take(amos_match *m, size_t bytes)
+{
+    uint8_t *p = m->hStage + m->stageUsed;
+    m->stageUsed += (bytes + 63) & ~(size_t)63;
+    return p;  // (stage_begin sized the buffer for the sum of the call's pieces)
+}
+
+static int stage_h2d(amos_match *m, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return AMOS_OK;
+    uint8_t *p = stage_take(m, bytes);
+    std::memcpy(p, src, bytes);
+    AMOS_HIP_CHECK(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, m->stream));
+    return AMOS_OK;
+}
+
+// device -> staging now, staging -> `out` after the synchronisation (stage_finish)
+static int stage_d2h_sync(amos_match *m, void *out, const void *src, size_t bytes)
+{
+    uint8_t *p = stage_take(m, bytes);
+    AMOS_HIP_CHECK(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToHost, m->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(m->stream));
+    std::memcpy(out, p, bytes);
+    return AMOS_OK;
+}
+
 static int upload_sets(amos_match *m, const uint8_t *q, int nq, const uint8_t *t, int nt)
 {
     int rc = grow(&m->dQ, &m->capQ, (size_t)nq * 32 + 32);
     if (rc != AMOS_OK) return rc;
     rc = grow(&m->dT, &m->capT, (size_t)nt * 32 + 32);
     if (rc != AMOS_OK) return rc;
-    if (nq > 0) AMOS_HIP_CHECK(hipMemcpyAsync(m->dQ, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
-    if (nt > 0) AMOS_HIP_CHECK(hipMemcpyAsync(m->dT, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+    if (nq > 0 && (rc = stage_h2d(m, m->dQ, q, (size_t)nq * 32)) != AMOS_OK) return rc;
+    if (nt > 0 && (rc = stage_h2d(m, m->dT, t, (size_t)nt * 32)) != AMOS_OK) return rc;
     return AMOS_OK;
 }
 
@@ -669,8 +722,8 @@ static int upload_lists(amos_match *m, int nq, int nt, const int32_t *cand_off, 
     if (rc != AMOS_OK) return rc;
     rc = grow(&m->dIdx, &m->capIdx, (size_t)n + 1);
     if (rc != AMOS_OK) return rc;
-    AMOS_HIP_CHECK(hipMemcpyAsync(m->dOff, cand_off, sizeof(int) * ((size_t)nq + 1), hipMemcpyHostToDevice, m->stream));
-    if (n > 0) AMOS_HIP_CHECK(hipMemcpyAsync(m->dIdx, cand_idx, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, m->stream));
+    if ((rc = stage_h2d(m, m->dOff, cand_off, sizeof(int) * ((size_t)nq + 1))) != AMOS_OK) return rc;
+    if (n > 0 && (rc = stage_h2d(m, m->dIdx, cand_idx, sizeof(int) * (size_t)n)) != AMOS_OK) return rc;
     *total = n;
     return AMOS_OK;
 }
@@ -708,6 +761,7 @@ void amos_match_destroy(amos_match *m)
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     void *ptrs[] = {m->dQ, m->dT, m->dOff, m->dIdx, m->dOut};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (m->hStage) (void)hipHostFree(m->hStage);
     if (m->ownStream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -733,16 +787,16 @@ int amos_match_distances(amos_match *m, const uint8_t *q, int nq, const uint8_t 
     if (!m || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || (!out && nq > 0 && nt > 0)) { set_error("amos_match_distances: invalid argument"); return AMOS_ERR_INVALID; }
     if (nq == 0 || nt == 0) return AMOS_OK;
     AMOS_HIP_CHECK(hipSetDevice(m->device));
-    int rc = upload_sets(m, q, nq, t, nt);
-    if (rc != AMOS_OK) return rc;
     const size_t bytes = (size_t)nq * nt * sizeof(uint16_t);
+    int rc = stage_begin(m, ((size_t)nq + nt) * 32 + bytes);
+    if (rc != AMOS_OK) return rc;
+    rc = upload_sets(m, q, nq, t, nt);
+    if (rc != AMOS_OK) return rc;
     rc = grow_out(m, bytes);
     if (rc != AMOS_OK) return rc;
     hipLaunchKernelGGL(k_dist_dense, dim3((nt + 255) / 256, (nq + 15) / 16), dim3(256), 0, m->stream, m->dQ, nq, m->dT, nt, (uint16_t *)m->dOut);
     AMOS_HIP_CHECK(hipGetLastError());
-    AMOS_HIP_CHECK(hipMemcpyAsync(out, m->dOut, bytes, hipMemcpyDeviceToHost, m->stream));
-    AMOS_HIP_CHECK(hipStreamSynchronize(m->stream));
-    return AMOS_OK;
+    return stage_d2h_sync(m, out, m->dOut, bytes);
 }
 
 int amos_match_list_distances(amos_match *m, const uint8_t *q, int nq, const uint8_t *t, int nt, const int32_t *cand_off,
@@ -752,19 +806,20 @@ int amos_match_list_distances(amos_match *m, const uint8_t *q, int nq, const uin
     if (nq == 0) return AMOS_OK;
     AMOS_HIP_CHECK(hipSetDevice(m->device));
     int total = 0;
-    int rc = upload_lists(m, nq, nt, cand_off, cand_idx, &total);
+    const size_t nCand = cand_off[nq] > 0 ? (size_t)cand_off[nq] : 0;  // (validated by upload_lists)
+    int rc = stage_begin(m, ((size_t)nq + nt) * 32 + ((size_t)nq + 1) * 4 + nCand * 6);
     if (rc != AMOS_OK) return rc;
-    if (total == 0) return AMOS_OK;
-    if (!t || !out || !cand_idx) { set_error("amos_match_list_distances: null buffer"); return AMOS_ERR_INVALID; }
+    rc = upload_lists(m, nq, nt, cand_off, cand_idx, &total);
+    if (rc != AMOS_OK) return rc;
+    if (total == 0) { AMOS_HIP_CHECK(hipStreamSynchronize(m->stream)); return AMOS_OK; }
+    if (!t || !out || !cand_idx) { AMOS_HIP_CHECK(hipStreamSynchronize(m->stream)); set_error("amos_match_list_distances: null buffer"); return AMOS_ERR_INVALID; }
     rc = upload_sets(m, q, nq, t, nt);
     if (rc != AMOS_OK) return rc;
     rc = grow_out(m, (size_t)total * sizeof(uint16_t));
     if (rc != AMOS_OK) return rc;
     hipLaunchKernelGGL(k_list_dist, dim3((nq + 3) / 4), dim3(256), 0, m->stream, m->dQ, nq, m->dT, m->dOff, m->dIdx, (uint16_t *)m->dOut);
     AMOS_HIP_CHECK(hipGetLastError());
-    AMOS_HIP_CHECK(hipMemcpyAsync(out, m->dOut, (size_t)total * sizeof(uint16_t), hipMemcpyDeviceToHost, m->stream));
-    AMOS_HIP_CHECK(hipStreamSynchronize(m->stream));
-    return AMOS_OK;
+    return stage_d2h_sync(m, out, m->dOut, (size_t)total * sizeof(uint16_t));
 }
 
 int amos_match_list_best2(amos_match *m, const uint8_t *q, int nq, const uint8_t *t, int nt, const int32_t *cand_off,
@@ -774,18 +829,19 @@ int amos_match_list_best2(amos_match *m, const uint8_t *q, int nq, const uint8_t
     if (nq == 0) return AMOS_OK;
     AMOS_HIP_CHECK(hipSetDevice(m->device));
     int total = 0;
-    int rc = upload_lists(m, nq, nt, cand_off, cand_idx, &total);
+    const size_t nCand = cand_off[nq] > 0 ? (size_t)cand_off[nq] : 0;
+    int rc = stage_begin(m, ((size_t)nq + nt) * 32 + ((size_t)nq + 1) * 4 + nCand * 4 + (size_t)nq * sizeof(amos_best2));
     if (rc != AMOS_OK) return rc;
-    if (total > 0 && (!t || !cand_idx)) { set_error("amos_match_list_best2: null buffer"); return AMOS_ERR_INVALID; }
+    rc = upload_lists(m, nq, nt, cand_off, cand_idx, &total);
+    if (rc != AMOS_OK) return rc;
+    if (total > 0 && (!t || !cand_idx)) { AMOS_HIP_CHECK(hipStreamSynchronize(m->stream)); set_error("amos_match_list_best2: null buffer"); return AMOS_ERR_INVALID; }
     rc = upload_sets(m, q, nq, t, nt);
     if (rc != AMOS_OK) return rc;
     rc = grow_out(m, (size_t)nq * sizeof(amos_best2));
     if (rc != AMOS_OK) return rc;
     hipLaunchKernelGGL(k_list_best2, dim3((nq + 3) / 4), dim3(256), 0, m->stream, m->dQ, nq, m->dT, m->dOff, m->dIdx, init_dist, (amos_best2 *)m->dOut);
     AMOS_HIP_CHECK(hipGetLastError());
-    AMOS_HIP_CHECK(hipMemcpyAsync(out, m->dOut, (size_t)nq * sizeof(amos_best2), hipMemcpyDeviceToHost, m->stream));
-    AMOS_HIP_CHECK(hipStreamSynchronize(m->stream));
-    return AMOS_OK;
+    return stage_d2h_sync(m, out, m->dOut, (size_t)nq * sizeof(amos_best2));
 }
 
 int amos_match_bruteforce_best2(amos_match *m, const uint8_t *q, int nq, const uint8_t *t, int nt, int init_dist,
@@ -795,7 +851,9 @@ int amos_match_bruteforce_best2(amos_match *m, const uint8_t *q, int nq, const u
     if (nt > 65535) { set_error("amos_match_bruteforce_best2: at most 65535 train descriptors"); return AMOS_ERR_INVALID; }
     if (nq == 0) return AMOS_OK;
     AMOS_HIP_CHECK(hipSetDevice(m->device));
-    int rc = upload_sets(m, q, nq, t, nt);
+    int rc = stage_begin(m, ((size_t)nq + nt) * 32 + (size_t)nq * sizeof(amos_best2));
+    if (rc != AMOS_OK) return rc;
+    rc = upload_sets(m, q, nq, t, nt);
     if (rc != AMOS_OK) return rc;
     rc = grow_out(m, (size_t)nq * sizeof(amos_best2));
     if (rc != AMOS_OK) return rc;
@@ -808,9 +866,7 @@ int amos_match_bruteforce_best2(amos_match *m, const uint8_t *q, int nq, const u
             launch_bf<true>(m, mfma, gp, gm, m->dQ, m->dT, 0, nullptr, nullptr, nullptr, nq, nt, nq, init_dist, (amos_best2 *)m->dOut);
     }
     AMOS_HIP_CHECK(hipGetLastError());
-    AMOS_HIP_CHECK(hipMemcpyAsync(out, m->dOut, (size_t)nq * sizeof(amos_best2), hipMemcpyDeviceToHost, m->stream));
-    AMOS_HIP_CHECK(hipStreamSynchronize(m->stream));
-    return AMOS_OK;
+    return stage_d2h_sync(m, out, m->dOut, (size_t)nq * sizeof(amos_best2));
 }
 
 int amos_match_bruteforce_best2_batch_device(amos_match *m, const uint8_t *d_desc, size_t frame_stride_bytes,

@@ -82,6 +82,7 @@ struct amos_orb {
     uint8_t *dOutDesc = nullptr;
     uint8_t *dMask = nullptr, *dMaskTmp = nullptr, *dMaskClosed = nullptr;
     uint8_t *hStage = nullptr;  // pinned host staging for fetch_frame: count, one frame's keypoints and descriptors
+    uint8_t *hPyrStage = nullptr;  // pinned host staging for one frame's pyramid (level images to host Mats), made on first use
     double *dLabels = nullptr;
     int *dCenterIds = nullptr, *dRm = nullptr, *dNRemoved = nullptr, *dErr = nullptr;
     int capCenters = 0, capRm = 0;
@@ -495,6 +496,40 @@ int amos_device_count(void)
     return n;
 }
 
+int amos_current_device(void)
+{
+    int d = 0;
+    AMOS_HIP_CHECK(hipGetDevice(&d));
+    return d;
+}
+
+const char *amos_build_variant(void)
+{
+    // every switch that changes results is named here (and in amos_winograd24.hip through amos_w24_variant_tag)
+    static std::string tag;
+    if (tag.empty()) {
+        std::string t;
+        if (AMOS_FAST_EXP != 0) t += " AMOS_FAST_EXP=" + std::to_string(AMOS_FAST_EXP);
+        if (AMOS_FAST_LDS_PAD != 0) t += " AMOS_FAST_LDS_PAD=" + std::to_string(AMOS_FAST_LDS_PAD);
+        t += amos::w24_variant_tag();
+        tag = t.empty() ? "default" : t.substr(1);
+    }
+    return tag.c_str();
+}
+
+int amos_orb_tables_host(const amos_orb_params *params, float *scale_factor, float *inv_scale_factor, float *level_sigma2,
+                         float *inv_level_sigma2, int32_t *features_per_level, int32_t *umax)
+{
+    if (!params || params->n_levels < 1 || params->n_levels > AMOS_MAX_LEVELS || params->n_features < 1 || !(params->scale_factor > 1.0f)) {
+        set_error("amos_orb_tables_host: invalid argument");
+        return AMOS_ERR_INVALID;
+    }
+    amos_orb h;  // host fields only
+    h.p = *params;
+    build_tables(&h);
+    return amos_orb_tables(&h, scale_factor, inv_scale_factor, level_sigma2, inv_level_sigma2, features_per_level, umax);
+}
+
 int amos_orb_geometry_probe(const amos_orb_params *params, int max_width, int max_height, int width, int height, int32_t need[6], int32_t cap[6])
 {
     if (!params || max_width < 1 || max_height < 1 || width < 1 || height < 1 || params->n_levels < 1 || params->n_levels > AMOS_MAX_LEVELS ||
@@ -648,6 +683,7 @@ void amos_orb_destroy(amos_orb *h)
                     h->dNRemoved, h->dErr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->hStage) (void)hipHostFree(h->hStage);
+    if (h->hPyrStage) (void)hipHostFree(h->hPyrStage);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     if (h->streamB) { (void)hipStreamSynchronize(h->streamB); (void)hipStreamDestroy(h->streamB); }
     for (hipEvent_t e : {h->evFork, h->evJoin, h->evBlur0, h->evBlur1}) if (e) (void)hipEventDestroy(e);
@@ -869,17 +905,53 @@ int amos_orb_extract(amos_orb *h, const uint8_t *gray, size_t stride, int width,
     return fetch_frame(h, 0, kps, desc, cap, n);
 }
 
+// Level planes to host buffers.  The device plane travels as ONE contiguous copy into a pinned staging buffer (DMA at the link rate) and is
+// cut into the caller's rows on the host: a strided hipMemcpy2D into pageable memory moves row by row -- 13.6 ms for the eight planes of a
+// 640 x 480 frame (measured, tools/r5_dropin.py), where this takes ~0.15 ms.
+static int pyr_stage(amos_orb *h)
+{
+    if (h->hPyrStage) return AMOS_OK;
+    if (hipHostMalloc((void **)&h->hPyrStage, (size_t)h->capGeom.frameBytes + 4096, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipHostMalloc (pyramid staging) failed");
+        return AMOS_ERR_DEVICE;
+    }
+    return AMOS_OK;
+}
+
+static void cut_plane(const amos_orb *h, int level, const uint8_t *stagedPlane, uint8_t *dst, size_t dst_stride, int padded)
+{
+    const LevelGeom &lg = h->geom.lv[level];
+    const uint8_t *origin = stagedPlane + (size_t)kEdge * lg.stride + kPadLeft;
+    const int rows = padded ? lg.h + 2 * kEdge : lg.h, cols = padded ? lg.w + 2 * kEdge : lg.w;
+    const uint8_t *src = padded ? origin - (size_t)kEdge * lg.stride - kEdge : origin;
+    for (int y = 0; y < rows; y++) std::memcpy(dst + (size_t)y * dst_stride, src + (size_t)y * lg.stride, (size_t)cols);
+}
+
 static int copy_plane(amos_orb *h, const uint8_t *dBase, int frame, int level, uint8_t *dst, size_t dst_stride, int padded)
 {
     const Geom &g = h->geom;
     const LevelGeom &lg = g.lv[level];
-    const uint8_t *origin = dBase + (size_t)frame * g.frameBytes + lg.planeOff + (size_t)kEdge * lg.stride + kPadLeft;
-    if (padded)
-        AMOS_HIP_CHECK(hipMemcpy2DAsync(dst, dst_stride, origin - (size_t)kEdge * lg.stride - kEdge, lg.stride, lg.w + 2 * kEdge,
-                                        lg.h + 2 * kEdge, hipMemcpyDeviceToHost, h->stream));
-    else
-        AMOS_HIP_CHECK(hipMemcpy2DAsync(dst, dst_stride, origin, lg.stride, lg.w, lg.h, hipMemcpyDeviceToHost, h->stream));
+    int rc = pyr_stage(h);
+    if (rc != AMOS_OK) return rc;
+    const size_t bytes = (size_t)lg.stride * (lg.h + 2 * kEdge);
+    AMOS_HIP_CHECK(hipMemcpyAsync(h->hPyrStage, dBase + (size_t)frame * g.frameBytes + lg.planeOff, bytes, hipMemcpyDeviceToHost, h->stream));
     AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    cut_plane(h, level, h->hPyrStage, dst, dst_stride, padded);
+    return AMOS_OK;
+}
+
+int amos_orb_pyramid_images(amos_orb *h, int frame, uint8_t *const *dst, const size_t *dst_strides, int padded)
+{
+    if (!h || !dst || !dst_strides || !h->detected || frame < 0 || frame >= h->nFrames) { set_error("amos_orb_pyramid_images: invalid argument or state"); return AMOS_ERR_INVALID; }
+    AMOS_HIP_CHECK(hipSetDevice(h->device));
+    const Geom &g = h->geom;
+    int rc = pyr_stage(h);
+    if (rc != AMOS_OK) return rc;
+    AMOS_HIP_CHECK(hipMemcpyAsync(h->hPyrStage, h->dPyr + (size_t)frame * g.frameBytes, (size_t)g.frameBytes, hipMemcpyDeviceToHost, h->stream));
+    AMOS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < g.nLevels; l++)
+        if (dst[l]) cut_plane(h, l, h->hPyrStage + g.lv[l].planeOff, dst[l], dst_strides[l], padded);
     return AMOS_OK;
 }
 

@@ -470,7 +470,7 @@ int amos_mask_winograd_conv_device(void *stream, const float *d_x, const float *
     }
     static DeviceOnce ldsAttr;  // per device (amos_common.h)
     const size_t lds = (size_t)2 * (kWinoStageV + kWinoStageR) * sizeof(float);  // two V tiles + two raw patches = 128 KB
-    AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttr, reinterpret_cast<const void *>(k_winograd_conv), (int)lds));
+    AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttr, reinterpret_cast<const void *>(k_winograd_conv), (int)lds, (hipStream_t)stream));
     WinoArgs a;
     a.x = d_x; a.u = d_u; a.bias = d_bias; a.res = d_residual; a.y = d_y;
     a.B = batch; a.H = h; a.W = w; a.C = cin; a.N = cout;

@@ -69,6 +69,12 @@ struct W24Args {
     int tilesX, tilesY, tilesPerImage, totalTiles;
     int mBlocks, nTiles, stages, relu;
     unsigned xBytes;            // size of x in bytes (the buffer descriptor's range)
+    // Layouts.  x: byte strides of a pixel and of a stage (8 input channels): channels-last [b][h][w][C] has (4 C, 32), the channel-blocked
+    // form [b][C / 8][h][w][8] has (32, 32 H W) -- there the 32 bytes a stage reads of a pixel sit beside the same stage's 32 bytes of the next
+    // pixel, so a patch row is ONE contiguous run of whole cache lines used once, where channels-last hands every 128-byte line to four
+    // different stages (and L1 has lost it by the time the next one asks).  y / res: outBlocked selects [b][N / 8][h][w][8].
+    unsigned xPixelBytes, xStageBytes;
+    int outBlocked;
 };
 
 // k * a + b per component as one fused multiply-add each (the file is compiled with -ffp-contract=off)
@@ -151,7 +157,7 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
                 for (int r = 0; r < 4; r++) {
                     const int iy = 2 * ty - 1 + r;
                     if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                        xoff[r] = (int)((((unsigned)(b * a.H + iy) * a.W + ix) * a.C + 4 * quad) * 4u);
+                        xoff[r] = (int)((unsigned)b * (unsigned)(a.H * a.W) * (unsigned)a.C * 4u + (unsigned)(iy * a.W + ix) * a.xPixelBytes + 16u * quad);
                 }
             }
             if (tl >= t0 && tl < t0 + n) colBase = cb + 4 * (tl - t0);
@@ -181,7 +187,7 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
 #define AMOS_W24_FETCH_X(s, buf)                                                                                                     \
     {                                                                                                                                \
         _Pragma("unroll") for (int r = 0; r < 4; r++)                                                                                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (LdsPtr)(AMOS_W24_R(buf) + r * kW24RawRow + wave * 256), 16, xoff[r], (s) * (kW24K * 4), 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (LdsPtr)(AMOS_W24_R(buf) + r * kW24RawRow + wave * 256), 16, xoff[r], (s) * a.xStageBytes, 0, 0); \
     }
 #endif
 #ifdef AMOS_W24_U_NT   /* experiment: the weight stream with the non-temporal hint */
@@ -447,7 +453,8 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
                 for (int j = 0; j < 4; j++) {
                     const int px = 4 * tx + j;
                     if (px >= a.W) continue;
-                    const size_t o = ((size_t)(b * a.H + py) * a.W + px) * a.N + n0;
+                    const size_t o = a.outBlocked ? ((((size_t)b * (a.N >> 3) + (n0 >> 3)) * a.H + py) * a.W + px) * 8 + (n0 & 7)
+                                                  : ((size_t)(b * a.H + py) * a.W + px) * a.N + n0;
                     f32x4 v = yv[j] + bv;
                     if (a.res) v = v + *reinterpret_cast<const f32x4 *>(a.res + o);
                     if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -465,6 +472,27 @@ __global__ __launch_bounds__(kW24Threads) __attribute__((amdgpu_waves_per_eu(2, 
     extern __shared__ __align__(16) float smem24[];
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) w24_run<1>(a, smem24);
     else w24_run<0>(a, smem24);
+}
+
+const char *w24_variant_tag()
+{
+    return ""
+#ifdef AMOS_W24_EXP_NOX
+        " AMOS_W24_EXP_NOX"
+#endif
+#ifdef AMOS_W24_EXP_NOU
+        " AMOS_W24_EXP_NOU"
+#endif
+#ifdef AMOS_W24_EXP_NOT
+        " AMOS_W24_EXP_NOT"
+#endif
+#ifdef AMOS_W24_EXP_NOBAR
+        " AMOS_W24_EXP_NOBAR"
+#endif
+#ifdef AMOS_W24_EXP_NOEPI
+        " AMOS_W24_EXP_NOEPI"
+#endif
+        ;
 }
 
 }  // namespace amos
@@ -492,6 +520,12 @@ int amos_mask_winograd24_weights_device(void *stream, const float *d_w, float *d
 int amos_mask_winograd24_conv_device(void *stream, const float *d_x, const float *d_u, const float *d_bias, const float *d_residual, float *d_y,
                                      int batch, int h, int w, int cin, int cout, int relu)
 {
+    return amos_mask_winograd24_conv_layout_device(stream, d_x, d_u, d_bias, d_residual, d_y, batch, h, w, cin, cout, relu, 0, 0);
+}
+
+int amos_mask_winograd24_conv_layout_device(void *stream, const float *d_x, const float *d_u, const float *d_bias, const float *d_residual, float *d_y,
+                                            int batch, int h, int w, int cin, int cout, int relu, int in_blocked, int out_blocked)
+{
     const long long xBytes = (long long)batch * h * w * cin * 4;
     if (!d_x || !d_u || !d_y || batch < 1 || h < 1 || w < 1 || amos_mask_winograd_supported(cin, cout) != AMOS_OK || xBytes > 0x7fffffffLL - 4096 ||
         ((uintptr_t)d_x | (uintptr_t)d_u | (uintptr_t)d_y | (uintptr_t)d_bias | (uintptr_t)d_residual) % 16 != 0) {
@@ -500,7 +534,7 @@ int amos_mask_winograd24_conv_device(void *stream, const float *d_x, const float
     }
     static DeviceOnce ldsAttr;  // per device (amos_common.h)
     const size_t lds = (size_t)kW24LdsFloats * sizeof(float);  // 128 KB
-    AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttr, reinterpret_cast<const void *>(k_winograd24_conv), (int)lds));
+    AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttr, reinterpret_cast<const void *>(k_winograd24_conv), (int)lds, (hipStream_t)stream));
     W24Args a;
     a.x = d_x; a.u = d_u; a.bias = d_bias; a.res = d_residual; a.y = d_y;
     a.B = batch; a.H = h; a.W = w; a.C = cin; a.N = cout;
@@ -512,6 +546,9 @@ int amos_mask_winograd24_conv_device(void *stream, const float *d_x, const float
     a.stages = cin / kW24K;
     a.relu = relu;
     a.xBytes = (unsigned)xBytes;
+    a.xPixelBytes = in_blocked ? 32u : (unsigned)cin * 4u;
+    a.xStageBytes = in_blocked ? (unsigned)(h * w) * 32u : 32u;
+    a.outBlocked = out_blocked ? 1 : 0;
     // ids: 8 XCDs x groups of (kW24Group m blocks x nTiles); the last group may be partly empty (those work-groups return at once)
     const int perXcd = (a.mBlocks + 7) / 8, groups = (perXcd + kW24Group - 1) / kW24Group;
     const dim3 grid((unsigned)(groups * kW24Group * a.nTiles * 8)), block(kW24Threads);

@@ -50,10 +50,20 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // ROIs into padded buffers, as in the reference.  Pixel data is copied from the device after every
-    // extraction unless SetPyramidDownload(false): the RGB-D flow only reads mvImagePyramid[0].rows.
+    // ROIs into padded buffers, as in the reference; rows / cols / step are always those of the level.  The PIXELS live on the device:
+    // by default (PYRAMID_AUTO) the 4-arg operator() -- the mono / stereo Frame constructors, whose ComputeStereoMatches reads
+    // mvImagePyramid pixels (Frame.cc:1401,1434) -- copies every level back, the 3-arg operator() of the RGB-D Amos flow, which
+    // only reads mvImagePyramid[0].rows (Frame.cc:1197), does not (1.16 MB per frame saved).  SetPyramidDownload(true / false) forces
+    // either for both; DownloadPyramid() fills the Mats of the last extraction on demand.
     std::vector<cv::Mat> mvImagePyramid;
-    void SetPyramidDownload(bool on) { mbDownloadPyramid = on; }
+    enum PyramidMode { PYRAMID_AUTO = 0, PYRAMID_ALWAYS = 1, PYRAMID_NEVER = 2 };
+    void SetPyramidDownload(bool on) { mnPyramidMode = on ? PYRAMID_ALWAYS : PYRAMID_NEVER; }
+    void SetPyramidMode(PyramidMode m) { mnPyramidMode = m; }
+    void DownloadPyramid();
+    // The HIP device the handle lives on: by default the calling thread's current device at the first extraction
+    // (amos_current_device), or the one AMOS_DEVICE names; SetDevice before the first extraction overrides both.
+    void SetDevice(int device);
+    int GetDevice() const { return mnDevice; }
     // The device handle (batch API, streams): see include/amos_frontend.h.
     amos_orb *Handle() { return mpHandle; }
 
@@ -62,7 +72,7 @@ protected:
     void Detect(const cv::Mat &image);
     void FetchLevels(std::vector<std::vector<cv::KeyPoint>> &levels);
     void StoreLevels(const std::vector<std::vector<cv::KeyPoint>> &levels);
-    void UpdatePyramid(int width, int height);
+    void UpdatePyramid(int width, int height, bool download);
 
     int nfeatures;
     double scaleFactor;
@@ -77,10 +87,20 @@ protected:
     std::vector<float> mvInvLevelSigma2;
 
     amos_orb *mpHandle;
+    int mnDevice;  // -1 until chosen
     int mnHandleW, mnHandleH;
-    bool mbDownloadPyramid;
+    int mnPyramidMode;
+    std::vector<cv::Mat> mvPyramidStore;  // the padded buffers mvImagePyramid's ROIs point into, kept from frame to frame
+    bool mbPyramidOnHost;                 // the Mats hold the last extraction's pixels
     std::vector<int> mvLevelOffset, mvLevelCap;
     int mnLevelTotal;
+    // what the device-resident per-level lists hold (as last fetched or stored): a caller handing back unchanged vectors
+    // (MovingKeyPoints straight after operator(), ProcessDesp straight after MovingKeyPoints) costs no transfer
+    std::vector<int32_t> mvDeviceCounts;
+    std::vector<cv::KeyPoint> mvDeviceLists;
+    bool mbDeviceListsKnown;
+    std::vector<cv::KeyPoint> mvStage;  // marshalling scratch (level lists; keypoints of the final result)
+    std::vector<uint8_t> mvStageDesc;
 };
 
 }  // namespace ORB_SLAM2

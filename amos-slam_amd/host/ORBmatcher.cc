@@ -76,14 +76,65 @@ vector<size_t> FeatureGrid::GetFeaturesInArea(const float &x, const float &y, co
 }
 
 // ---------------------------------------------------------------------------------------------
-AMOS_VIEW_MATCHER::AMOS_VIEW_MATCHER(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri), mpMatch(nullptr)
+// The reference constructs a matcher ON THE STACK at every call site (Tracking.cc:1492,1744,1910,2378,2609,2663, LocalMapping.cc:324,669,
+// LoopClosing.cc:346,813): several per frame, from three threads.  Its constructor stores two numbers (ORBmatcher.cc:49-51), so must this
+// one: the device handle (HIP stream + scratch buffers that grow to the largest search seen) is borrowed from a process-wide pool on the
+// FIRST search of the object and handed back by the destructor -- no HIP call in either, no hipMalloc / hipFree / stream churn per frame.
+// A handle serves one matcher object at a time (it is re-entrant across objects, not within one); the pool is per device and lives as long
+// as the process (like the extractors Tracking never frees, Tracking.cc:172-185): destroying HIP objects from a static destructor after the
+// runtime has shut down is not defined.
+namespace
 {
-    Check(amos_match_create(0, nullptr, &mpMatch), "amos_match_create");
+struct MatchPool {
+    std::mutex mutex;
+    std::vector<std::vector<amos_match *> > idle;  // [device]
+    int created = 0;
+};
+MatchPool &Pool()
+{
+    static MatchPool *pool = new MatchPool();  // never deleted, see above
+    return *pool;
+}
+}  // namespace
+
+extern int AmosPickDevice();  // ORBextractor.cc: AMOS_DEVICE, else the calling thread's current HIP device
+
+amos_match *AMOS_VIEW_MATCHER::Handle()
+{
+    if (mpMatch) return mpMatch;
+    mnDevice = AmosPickDevice();
+    MatchPool &pool = Pool();
+    {
+        std::lock_guard<std::mutex> lock(pool.mutex);
+        if ((int)pool.idle.size() > mnDevice && !pool.idle[mnDevice].empty()) {
+            mpMatch = pool.idle[mnDevice].back();
+            pool.idle[mnDevice].pop_back();
+            return mpMatch;
+        }
+        pool.created++;
+    }
+    Check(amos_match_create(mnDevice, nullptr, &mpMatch), "amos_match_create");
+    return mpMatch;
+}
+
+int AMOS_VIEW_MATCHER::PoolHandlesCreated()
+{
+    MatchPool &pool = Pool();
+    std::lock_guard<std::mutex> lock(pool.mutex);
+    return pool.created;
+}
+
+AMOS_VIEW_MATCHER::AMOS_VIEW_MATCHER(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri), mpMatch(nullptr), mnDevice(-1)
+{
 }
 
 AMOS_VIEW_MATCHER::~AMOS_VIEW_MATCHER()
 {
-    if (mpMatch) amos_match_destroy(mpMatch);
+    if (!mpMatch) return;
+    MatchPool &pool = Pool();
+    std::lock_guard<std::mutex> lock(pool.mutex);
+    if ((int)pool.idle.size() <= mnDevice) pool.idle.resize(mnDevice + 1);
+    pool.idle[mnDevice].push_back(mpMatch);  // every call on a handle is synchronous: nothing of this object is in flight
 }
 
 // ORBmatcher.cc:1913-1933: one pair.  Callers use it inside host loops (MapPoint::ComputeDistinctiveDescriptors,
@@ -105,7 +156,7 @@ int AMOS_VIEW_MATCHER::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
 void AMOS_VIEW_MATCHER::DescriptorDistances(const uint8_t *q, int nq, const uint8_t *t, int nt, std::vector<uint16_t> &out)
 {
     out.resize((size_t)nq * nt);
-    Check(amos_match_distances(mpMatch, q, nq, t, nt, out.data()), "amos_match_distances");
+    Check(amos_match_distances(Handle(), q, nq, t, nt, out.data()), "amos_match_distances");
 }
 
 void AMOS_VIEW_MATCHER::ListDistances(const amos_frame_view &train, const uint8_t *queries, int nq, const std::vector<int> &off,
@@ -113,7 +164,7 @@ void AMOS_VIEW_MATCHER::ListDistances(const amos_frame_view &train, const uint8_
 {
     dist.resize(idx.size());
     if (idx.empty()) return;
-    Check(amos_match_list_distances(mpMatch, queries, nq, train.descriptors, train.n, off.data(), idx.data(), dist.data()),
+    Check(amos_match_list_distances(Handle(), queries, nq, train.descriptors, train.n, off.data(), idx.data(), dist.data()),
           "amos_match_list_distances");
 }
 
@@ -122,7 +173,7 @@ void AMOS_VIEW_MATCHER::ListDistances(const uint8_t *train, int nt, const uint8_
 {
     dist.resize(idx.size());
     if (idx.empty()) return;
-    Check(amos_match_list_distances(mpMatch, queries, nq, train, nt, off.data(), idx.data(), dist.data()), "amos_match_list_distances");
+    Check(amos_match_list_distances(Handle(), queries, nq, train, nt, off.data(), idx.data(), dist.data()), "amos_match_list_distances");
 }
 
 float AMOS_VIEW_MATCHER::RadiusByViewingCos(const float &viewCos)

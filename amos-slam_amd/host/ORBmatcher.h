@@ -138,9 +138,17 @@ protected:
     void ListDistances(const uint8_t *train, int nt, const uint8_t *queries, int nq, const std::vector<int> &off, const std::vector<int> &idx,
                        std::vector<uint16_t> &dist);
 
+    // the device handle of this object: borrowed from the process-wide pool on first use (ORBmatcher.cc), returned by the destructor
+    amos_match *Handle();
+
     float mfNNratio;
     bool mbCheckOrientation;
     amos_match *mpMatch;
+    int mnDevice;
+
+public:
+    // handles the pool has created since the process started (tests: stack-constructed matchers reuse them)
+    static int PoolHandlesCreated();
 };
 
 }  // namespace ORB_SLAM2

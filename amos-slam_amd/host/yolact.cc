@@ -4,6 +4,7 @@
 #include <Python.h>
 #include <unistd.h>
 
+#include <cstdint>
 #include <cstring>
 #include <sstream>
 
@@ -21,6 +22,8 @@ struct Gil {
 
 yolact::yolact(const std::string &pyFilePath, const std::string &modelPath, const size_t &categories)
     : mpTracker(nullptr), mbNewImgFlag(false), mSkipIndex(0), imgIndex(0), mpPyEvalModule(nullptr), mpPyEvalFunc(nullptr),
+      mpPySessionEval(nullptr), mpSessionFrame(nullptr), mpSessionMask(nullptr), mnSessionH(0), mnSessionW(0), mnSessionMaskRows(0),
+      mnSessionMaskCols(0), mbSessionUnavailable(false),
       mnCategories(categories), mbIsLEDNETInitializedOK(false), mbIsPythonInitializedOK(false), mbOwnsInterpreter(false),
       mbFinishRequested(false)
 {
@@ -70,6 +73,7 @@ yolact::~yolact()
     if (mbIsPythonInitializedOK && Py_IsInitialized()) {
         Gil gil;
         Py_XDECREF((PyObject *)mpPyEvalFunc);
+        Py_XDECREF((PyObject *)mpPySessionEval);
         Py_XDECREF((PyObject *)mpPyEvalModule);
     }
     // the interpreter is left alive: other embedders (and the reference) never finalize it either
@@ -110,15 +114,66 @@ void yolact::FetchPythonError(const std::string &context)
     mstrErrDescription = ss.str();
 }
 
+// The GPU path: the frame goes straight into the session's pinned buffer, one Python call replays the captured graph, the mask is cloned
+// out of the pinned mask buffer.  handled = false when the module has no session for this engine (CPU engine, AMOS_MASK_GRAPH=0, an
+// older module): the caller then takes the bytes path.  Called with the GIL held.
+bool yolact::evalThroughSession(const cv::Mat &inputImage, cv::Mat &confidenceImage, bool &handled)
+{
+    handled = false;
+    if (mbSessionUnavailable) return false;
+    const int h = inputImage.rows, w3 = inputImage.cols * (int)inputImage.elemSize(), w = w3 / 3;  // bytes per row: 8UC3, or rows x (3 * cols) of 8UC1
+    if (!mpSessionFrame || h != mnSessionH || w != mnSessionW) {
+        PyObject *fn = PyObject_GetAttrString((PyObject *)mpPyEvalModule, "yolact_frame_session");
+        if (!fn) { PyErr_Clear(); mbSessionUnavailable = true; return false; }
+        PyObject *ret = PyObject_CallFunction(fn, "ii", h, w);
+        Py_DECREF(fn);
+        if (!ret) { handled = true; FetchPythonError("Error occured when calling method \"yolact_frame_session\""); return false; }
+        if (ret == Py_None) { Py_DECREF(ret); mbSessionUnavailable = true; return false; }
+        unsigned long long in = 0, out = 0;
+        int rows = 0, cols = 0;
+        const bool ok = PyArg_ParseTuple(ret, "KKii", &in, &out, &rows, &cols) != 0;
+        Py_DECREF(ret);
+        if (!ok || !in || !out || rows < 1 || cols < 1) { handled = true; FetchPythonError("yolact_frame_session did not return (frame address, mask address, rows, columns)"); return false; }
+        mpSessionFrame = reinterpret_cast<unsigned char *>((uintptr_t)in);
+        mpSessionMask = reinterpret_cast<unsigned char *>((uintptr_t)out);
+        mnSessionH = h; mnSessionW = w; mnSessionMaskRows = rows; mnSessionMaskCols = cols;
+        if (!mpPySessionEval) mpPySessionEval = PyObject_GetAttrString((PyObject *)mpPyEvalModule, "yolact_eval_session");
+        if (!mpPySessionEval) { handled = true; mpSessionFrame = nullptr; FetchPythonError("Error: function \"yolact_eval_session\" NOT found."); return false; }
+    }
+    handled = true;
+    for (int y = 0; y < h; y++) std::memcpy(mpSessionFrame + (size_t)y * w3, inputImage.ptr(y), (size_t)w3);
+    PyObject *ret = PyObject_CallFunction((PyObject *)mpPySessionEval, "ii", h, w);
+    if (!ret) {
+        FetchPythonError(std::string("Error occured when calling method \"") + EVAL_PY_FUNCTION_NAME + "\" in python module \"" + mstrPyMoudleName + "\". ");
+        return false;
+    }
+    const int found = PyObject_IsTrue(ret);
+    Py_DECREF(ret);
+    if (found != 1) {  // the reference's Python raises IndexError here (masks[0] of an empty result) and evalImage returns false
+        mstrErrDescription = std::string("Error occured when calling method \"") + EVAL_PY_FUNCTION_NAME + "\" in python module \"" + mstrPyMoudleName +
+                             "\".  [no detection above the score threshold]";
+        return false;
+    }
+    cv::Mat m(mnSessionMaskRows, mnSessionMaskCols, CV_8UC1, mpSessionMask);
+    confidenceImage = m.clone();  // yolact.cc:315
+    return true;
+}
+
 bool yolact::evalImage(const cv::Mat &inputImage, cv::Mat &confidenceImage)
 {
     if (!isInitializedResult()) return false;
-    if (inputImage.empty() || inputImage.elemSize() != 1) {
+    if (inputImage.empty() || (inputImage.elemSize() != 1 && inputImage.elemSize() != 3)) {
         mstrErrDescription = "src image is empty!";
         return false;
     }
-    const int h = inputImage.rows, w3 = inputImage.cols;  // 8UC3 frames arrive as rows x (3*cols) bytes in the stand-in Mat
+    // bytes per row: an 8UC3 frame (real OpenCV), or rows x (3 * cols) bytes of 8UC1 (the stand-in Mat has no channels)
+    const int h = inputImage.rows, w3 = inputImage.cols * (int)inputImage.elemSize();
     Gil gil;
+    {
+        bool handled = false;
+        const bool ok = evalThroughSession(inputImage, confidenceImage, handled);
+        if (handled) return ok;
+    }
     if (!mpPyEvalFunc) {
         // the fused entry point (raw BGR bytes; marshalling on the GPU) of mask/yolact_interface.py
         mpPyEvalFunc = PyObject_GetAttrString((PyObject *)mpPyEvalModule, "yolact_eval_bgr_bytes");

@@ -59,7 +59,14 @@ private:
     std::string mstrPyMoudlePath;
     std::string mstrPyMoudleName;
     void *mpPyEvalModule;  // PyObject*
-    void *mpPyEvalFunc;    // PyObject*
+    void *mpPyEvalFunc;    // PyObject*: yolact_eval_bgr_bytes (the frame as bytes: engines that do not run on a GPU)
+    // the per-frame session of mask/yolact_interface.py (yolact_frame_session / yolact_eval_session): pinned host buffers the frame is
+    // written to and the mask read from, the pass between them replayed as one HIP graph
+    bool evalThroughSession(const cv::Mat &inputImage, cv::Mat &confidenceImage, bool &handled);
+    void *mpPySessionEval;  // PyObject*: yolact_eval_session
+    unsigned char *mpSessionFrame, *mpSessionMask;
+    int mnSessionH, mnSessionW, mnSessionMaskRows, mnSessionMaskCols;
+    bool mbSessionUnavailable;
     size_t mnCategories;
     bool mbIsLEDNETInitializedOK;
     bool mbIsPythonInitializedOK;

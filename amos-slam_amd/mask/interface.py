@@ -171,6 +171,17 @@ class MaskEngine:
         return self.eval_net_input_graph(self._preprocess_hip(frames))
 
     @torch.no_grad()
+    def frame_session(self, height, width):
+        """The per-frame path of `yolact::evalImage` (yolact.cc:203-318 hands over ONE frame per call, Tracking.cc:366) as a FrameSession:
+        pinned host buffers the C++ class writes the frame into / reads the mask from, and ONE HIP graph holding the three pre-processing
+        kernels, the network, the detection and the mask assembly.  Kept per frame size."""
+        key = (int(height), int(width))
+        sessions = self.__dict__.setdefault("_sessions", {})
+        if key not in sessions:
+            sessions[key] = FrameSession(self, *key)
+        return sessions[key]
+
+    @torch.no_grad()
     def eval_bgr_batch(self, frames_u8, chunk=16):
         """frames_u8: [B, H, W, 3] uint8 on the engine's device.  Returns [B, H, W] uint8 masks (zeros where
         the network finds nothing, which is what the reference's caller ends up using, Tracking.cc:305).
@@ -190,3 +201,59 @@ class MaskEngine:
             masks, _found = person_mask_batch(detect_batch(pred), 640, 480)      # eval_image resizes to 640 x 480 whatever came in
             out[b0:b0 + part.shape[0]] = masks
         return out
+
+
+class FrameSession:
+    """One frame at a time through a captured HIP graph, host buffers pinned (see MaskEngine.frame_session).
+
+    frame_in  : pinned uint8 [height, width, 3] -- the caller writes the BGR frame here (address: in_ptr)
+    mask_out  : pinned uint8 [480, 640]          -- the person mask of the last run() (address: out_ptr)
+    run()     : H2D copy, graph replay, D2H copies, one stream synchronisation; returns whether a detection passed the score threshold
+                (the reference raises IndexError otherwise and its caller keeps the pre-zeroed mask, Tracking.cc:305)."""
+
+    def __init__(self, engine, height, width):
+        if engine.device.type != "cuda":
+            raise RuntimeError("FrameSession needs the GPU")
+        from .. import MaskPreprocessor
+        dev = engine.device
+        self.engine, self.height, self.width = engine, height, width
+        self.stream = torch.cuda.Stream(device=dev)
+        self.frame_in = torch.zeros((height, width, 3), dtype=torch.uint8).pin_memory()
+        self.mask_out = torch.zeros((480, 640), dtype=torch.uint8).pin_memory()
+        self._found_host = torch.zeros(1, dtype=torch.bool).pin_memory()
+        self._d_frame = torch.zeros((1, height, width, 3), dtype=torch.uint8, device=dev)
+        self._net_in = torch.zeros((1, 3, 550, 550), dtype=torch.float32, device=dev)
+        # the pre-processing kernels issue on THIS session's stream, so the capture below records them as nodes of the graph
+        self._pre = MaskPreprocessor(width, height, 1, device=dev.index or 0, stream=self.stream.cuda_stream)
+
+        def body():
+            self._pre.run(self._d_frame.data_ptr(), 1, self._net_in.data_ptr())
+            return person_mask_batch(detect_batch(engine._forward(self._net_in)), 640, 480)
+
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            for _ in range(3):  # MIOpen picks its solvers, the allocator warms up
+                body()
+        self.stream.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, stream=self.stream):
+            self._masks, self._found = body()
+        self.stream.synchronize()
+
+    @property
+    def in_ptr(self):
+        return self.frame_in.data_ptr()
+
+    @property
+    def out_ptr(self):
+        return self.mask_out.data_ptr()
+
+    @torch.no_grad()
+    def run(self):
+        with torch.cuda.stream(self.stream):
+            self._d_frame[0].copy_(self.frame_in, non_blocking=True)
+            self._graph.replay()
+            self.mask_out.copy_(self._masks[0], non_blocking=True)
+            self._found_host.copy_(self._found, non_blocking=True)
+        self.stream.synchronize()
+        return bool(self._found_host[0])

@@ -60,7 +60,8 @@ def winograd_rule(cin, cout, kernel, stride, padding, dilation, groups, batch, h
     (amos_mask_winograd24_conv_device / amos_mask_winograd_conv_device)?  3 x 3, stride 1, pad 1, channel counts the kernel takes, an
     input below 2 GiB, and a launch of at least 256 work-groups of 256 output pixels x 64 channels (one per CU).  Measured on MI355X at 32 frames (tools/winograd_probe.py): 1.4 - 1.8 x the direct implicit GEMM on every
     such layer of the network.  AMOS_MASK_WINOGRAD=0 never, 1 by this rule (default), 2 wherever the kernel applies (tests).
-    (bench.py asks the same function which layers to count at 16 instead of 36 multiplies per 2 x 2 outputs.)"""
+    (bench.py asks the same function which layers to count at the Winograd form's multiplies -- 24 per 2 x 4 outputs for F(2 x 4), 16 per
+    2 x 2 for F(2 x 2) -- instead of the direct convolution's 9 per output.)"""
     mode = os.environ.get("AMOS_MASK_WINOGRAD", "1")
     if mode == "0" or tuple(kernel) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1) or tuple(dilation) != (1, 1) or groups != 1:
         return False
@@ -69,8 +70,8 @@ def winograd_rule(cin, cout, kernel, stride, padding, dilation, groups, batch, h
         return False
     # work-groups of 256 output pixels (64 tiles of 2 x 2; F(2 x 4)'s 32 tiles of 2 x 4 give the same count within a few per cent, and the
     # same layers run in either family: the threshold was measured per layer, tools/winograd_probe.py)
-    groups = (batch * ((height + 1) // 2) * ((width + 1) // 2) + 63) // 64
-    return mode == "2" or groups * (cout // 64) >= 256
+    n_groups = (batch * ((height + 1) // 2) * ((width + 1) // 2) + 63) // 64
+    return mode == "2" or n_groups * (cout // 64) >= 256
 
 
 def _winograd_conv(conv, x):
@@ -104,12 +105,16 @@ def _winograd_weight(conv):
     key = (w.data_ptr(), w._version, str(w.device), family)
     cached = getattr(conv, "_amos_winograd", None)
     if cached is None or cached[0] != key:
+        if torch.cuda.is_current_stream_capturing():
+            # a tensor allocated and filled inside a capture belongs to that graph's private pool and is filled only on replay: it must
+            # never be published on the module for eager passes or other graphs to read
+            raise RuntimeError("a Winograd weight would be created inside a HIP-graph capture: call MaskEngine.prepare() (or "
+                               "prepare_winograd_weights) before capture_graph / frame_session, and again after changing weights or AMOS_MASK_WINOGRAD_F")
         wl = w.detach().contiguous(memory_format=torch.channels_last)  # [cout][3][3][cin] in memory
         u = torch.empty(positions * conv.in_channels * conv.out_channels, dtype=torch.float32, device=w.device)
         stream = torch.cuda.current_stream(w.device)
         make_weights(stream.cuda_stream, wl.data_ptr(), u.data_ptr(), conv.in_channels, conv.out_channels)
-        if not torch.cuda.is_current_stream_capturing():  # (inside a capture the transform is a node of that graph, ordered by it)
-            stream.synchronize()
+        stream.synchronize()
         cached = (key, u)
         object.__setattr__(conv, "_amos_winograd", cached)
     return cached[1]

@@ -40,20 +40,40 @@ def yolact_eval(image):
     return out, out
 
 
+def _graph_path():
+    """frame-by-frame callers on a GPU: pre-processing + network + detection + mask assembly replayed as ONE captured HIP graph (2.6 instead
+    of 3.5 ms per frame on MI355X, tools/mask_latency.py; the static-shape batch path of detect.py / post.py, same masks).  The default;
+    AMOS_MASK_GRAPH=0 selects the eager pass (A/B runs, tests)."""
+    return os.environ.get("AMOS_MASK_GRAPH", "1") != "0" and model_interface.device.type == "cuda"
+
+
+def yolact_frame_session(height, width):
+    """For the C++ `yolact` class: the addresses of the pinned host buffers of the engine's per-frame session -- (frame buffer, mask buffer,
+    mask rows, mask columns) -- or None when the engine does not run on a GPU (or AMOS_MASK_GRAPH=0): the caller then hands the frame over
+    as bytes (yolact_eval_bgr_bytes).  The C++ side copies the frame straight into the frame buffer, calls yolact_eval_session() and clones
+    the mask out of the mask buffer: no PyBytes, no numpy array, no pageable copy."""
+    if not _graph_path():
+        return None
+    s = model_interface.frame_session(height, width)
+    return s.in_ptr, s.out_ptr, 480, 640
+
+
+def yolact_eval_session(height, width):
+    """Runs the session of yolact_frame_session(height, width) on the frame in its frame buffer; True when the mask buffer holds a mask, False
+    when no detection passed the score threshold (the reference raises IndexError there and evalImage returns false)."""
+    return model_interface.frame_session(height, width).run()
+
+
 def yolact_eval_bgr_bytes(buf, height, width):
     """Entry point of the C++ `yolact` class of this project: the raw BGR frame as bytes; the
     reference's C++ marshalling (resize to 480x640, /255, CHW) runs on the GPU in mask/pre.py."""
     frame = np.frombuffer(buf, np.uint8).reshape(height, width, 3)
-    if os.environ.get("AMOS_MASK_GRAPH", "0") == "1" and model_interface.device.type == "cuda":
-        # frame-by-frame callers: network + detection + mask assembly replayed as ONE captured HIP graph (2.6 instead of 3.5 ms per
-        # frame on MI355X, tools/mask_latency.py; the static-shape batch path of detect.py / post.py, same masks)
-        import torch
-        if getattr(model_interface, "_graph", None) is None or model_interface._g_batch != 1:
-            model_interface.capture_graph(batch=1)
-        masks, found = model_interface.eval_bgr_graph(torch.from_numpy(frame.copy())[None].to(model_interface.device))
-        if not bool(found[0]):
+    if _graph_path():
+        s = model_interface.frame_session(height, width)
+        s.frame_in.numpy()[...] = frame
+        if not s.run():
             raise IndexError("no detection above the score threshold")
-        out = np.ascontiguousarray(masks[0].cpu().numpy())
+        out = s.mask_out.numpy().copy()
         return out, out
     mask = model_interface.eval_bgr(frame.copy())
     if mask is None:

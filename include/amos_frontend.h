@@ -85,6 +85,15 @@ typedef struct amos_best2 {
 const char *amos_last_error(void);
 /* Number of HIP devices visible, or a negative error code. */
 int amos_device_count(void);
+/* The calling thread's current HIP device (hipGetDevice), or a negative error code.  The C++ drop-in classes
+ * (amos-slam_amd/host) create their handles on it unless AMOS_DEVICE names another: a one-process-per-GPU host
+ * that has called hipSetDevice / torch.cuda.set_device gets its objects on ITS GPU (the reference has no such
+ * notion: its extractor is CPU code, ORBextractor.cc:492). */
+int amos_current_device(void);
+/* Which build of the library this is: "default" for the product build, otherwise the names of the timing-experiment
+ * switches it was compiled with (AMOS_FAST_EXP=n, AMOS_W24_EXP_*, AMOS_FAST_LDS_PAD=n: builds whose RESULTS ARE WRONG,
+ * tools/orb_variants.sh / tools/w24_variants.sh).  bench.py and the tests refuse anything but "default". */
+const char *amos_build_variant(void);
 
 /* ---------------------------------------------------------------- ORB extractor ------------- */
 
@@ -108,6 +117,10 @@ int amos_orb_geometry_probe(const amos_orb_params *params, int max_width, int ma
 int amos_orb_tables(const amos_orb *h, float *scale_factor, float *inv_scale_factor,
                     float *level_sigma2, float *inv_level_sigma2, int32_t *features_per_level,
                     int32_t *umax);
+/* The same tables from the parameters alone: host arithmetic only, no device is touched and no handle is needed
+ * (the reference's constructor is host code too, ORBextractor.cc:492-609).  Arrays hold params->n_levels entries. */
+int amos_orb_tables_host(const amos_orb_params *params, float *scale_factor, float *inv_scale_factor,
+                         float *level_sigma2, float *inv_level_sigma2, int32_t *features_per_level, int32_t *umax);
 /* Level geometry for a w x h input: width/height per level.  Returns n_levels. */
 int amos_orb_level_sizes(const amos_orb *h, int width, int height, int32_t *level_w, int32_t *level_h);
 
@@ -154,6 +167,10 @@ int amos_orb_extract(amos_orb *h, const uint8_t *gray, size_t stride, int width,
  * border, i.e. (w+38) x (h+38)) copied to host memory. */
 int amos_orb_level_image(amos_orb *h, int frame, int level, uint8_t *dst, size_t dst_stride,
                          int padded);
+/* All level planes of one frame at once (mvImagePyramid of the C++ class): dst[l] / dst_strides[l] per level (dst[l] NULL skips the level);
+ * padded != 0 copies the (w + 38) x (h + 38) plane including the reflect-101 border, as amos_orb_level_image does.  One device-to-host
+ * transfer of the frame's pyramid through a pinned staging buffer. */
+int amos_orb_pyramid_images(amos_orb *h, int frame, uint8_t *const *dst, const size_t *dst_strides, int padded);
 /* The blurred level used by the last describe (unpadded, w x h). */
 int amos_orb_blurred_image(amos_orb *h, int frame, int level, uint8_t *dst, size_t dst_stride);
 /* FAST candidates of (frame, level) before the quad-tree, in the reference's order
@@ -384,6 +401,12 @@ size_t amos_mask_winograd24_weight_floats(int cin, int cout);
 int amos_mask_winograd24_weights_device(void *stream, const float *d_w, float *d_u, int cin, int cout);
 int amos_mask_winograd24_conv_device(void *stream, const float *d_x, const float *d_u, const float *d_bias, const float *d_residual,
                                      float *d_y, int batch, int h, int w, int cin, int cout, int relu);
+/* The same convolution with the channel-blocked activation layout on either side: in_blocked != 0 reads d_x as [batch][cin / 8][h][w][8]
+ * floats, out_blocked != 0 writes d_y (and reads d_residual) as [batch][cout / 8][h][w][8]; 0 = channels-last [batch][h][w][c] (what
+ * amos_mask_winograd24_conv_device takes).  A stage of the kernel reads 8 input channels of every pixel of its patch: blocked, those are
+ * contiguous whole cache lines used once; channels-last, a quarter of every line four times.  Same arithmetic, same bits. */
+int amos_mask_winograd24_conv_layout_device(void *stream, const float *d_x, const float *d_u, const float *d_bias, const float *d_residual,
+                                            float *d_y, int batch, int h, int w, int cin, int cout, int relu, int in_blocked, int out_blocked);
 int amos_mask_conv1x1_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual,
                              float *d_y, int batch, int in_h, int in_w, int cin, int cout, int stride, int relu);
 

@@ -1,19 +1,23 @@
 // host_capi.cc -- C entry points that drive the C++ drop-in classes (ORB_SLAM2::ORBextractor,
-// ORB_SLAM2::ORBmatcher) so that the Python parity tests can exercise the reference-shaped API
-// itself, not only the C ABI underneath it.  Test harness, not part of the drop-in surface.
+// ORB_SLAM2::ORBmatcher, ORB_SLAM2::yolact of amos-slam_amd/host/libamos_host.so) so that the Python parity
+// tests and bench.py's drop-in latency leg can exercise the reference-shaped API itself, not only the
+// C ABI underneath it.  Test harness: built as tests/host/libamos_host_test.so, links the product
+// library, never the other way round.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <exception>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/amos_host_types.h"
-#include "ORBextractor.h"
-#include "ORBmatcher.h"
-#include "ORBmatcher_adaptors.h"
-#include "../../tests/host/ref_standins.h"
-#include "yolact.h"
+#include "../../amos-slam_amd/host/ORBextractor.h"
+#include "../../amos-slam_amd/host/ORBmatcher.h"
+#include "../../amos-slam_amd/host/ORBmatcher_adaptors.h"
+#include "ref_standins.h"
+#include "../../amos-slam_amd/host/yolact.h"
 
 using namespace ORB_SLAM2;
 
@@ -94,6 +98,30 @@ int amos_host_amos_flow(const uint8_t *gray, int w, int h, int nfeatures, float 
         level_counts_after[l] = (int)mvKeysTemp[l].size();
         for (const cv::KeyPoint &kp : mvKeysTemp[l]) std::memcpy(&level_lists_after[o++], &kp, sizeof(amos_keypoint));
     }
+    return 0;
+    AMOS_HOST_CATCH
+}
+
+// mvImagePyramid under the default PYRAMID_AUTO mode after the 3-arg operator() (the RGB-D Amos flow): every level's rows / cols are
+// valid although no pixel was copied (Frame.cc:1197 reads mvImagePyramid[0].rows); DownloadPyramid() then fills them on demand.
+// rows_cols: 2 x nlevels; pyr_out: the padded plane of pyr_level after DownloadPyramid(); device_out: the extractor's device.
+int amos_host_pyramid_on_demand(const uint8_t *gray, int w, int h, int nlevels, int32_t *rows_cols, int pyr_level, uint8_t *pyr_out, int32_t *device_out)
+{
+    AMOS_HOST_TRY
+    ORBextractor ext(1000, 1.2f, nlevels, 20, 7);
+    cv::Mat image(h, w, CV_8UC1, (void *)gray, (size_t)w), none;
+    std::vector<std::vector<cv::KeyPoint> > levels;
+    ext(image, none, levels);
+    *device_out = ext.GetDevice();
+    for (int l = 0; l < nlevels; l++) {
+        rows_cols[2 * l] = ext.mvImagePyramid[l].rows;
+        rows_cols[2 * l + 1] = ext.mvImagePyramid[l].cols;
+    }
+    ext.DownloadPyramid();
+    const cv::Mat &m = ext.mvImagePyramid[pyr_level];
+    const unsigned char *origin = m.data - (size_t)AMOS_EDGE_THRESHOLD * m.step - AMOS_EDGE_THRESHOLD;
+    for (int y = 0; y < m.rows + 2 * AMOS_EDGE_THRESHOLD; y++)
+        std::memcpy(pyr_out + (size_t)y * (m.cols + 2 * AMOS_EDGE_THRESHOLD), origin + (size_t)y * m.step, m.cols + 2 * AMOS_EDGE_THRESHOLD);
     return 0;
     AMOS_HOST_CATCH
 }
@@ -702,6 +730,210 @@ int amos_host_ref_fuse_scw(const amos_test_kf *kf, const amos_test_points *point
     for (int i = 0; i < kf->n; i++) kf_points[i] = index_of(KF.mvpMapPoints[i], pts);
     for (int i = 0; i < points->n; i++) obs_after[i] = pts[i].Observations();
     return n;
+    AMOS_HOST_CATCH
+}
+
+// ---- SURVEY 8b threading: "distinct ORBextractor instances are used concurrently (stereo: two std::threads, Frame.cc:165-170); ORBmatcher
+// is re-entrant and used from the Tracking, LocalMapping and LoopClosing threads simultaneously".  n_ext extractor threads (each owns one
+// ORBextractor for its frame, as Tracking owns mpORBextractorLeft / Right, and calls the 4-arg operator() `iters` times) run beside n_match
+// matcher threads (each constructs an ORBmatcher ON THE STACK per iteration, as every reference call site does, and runs
+// SearchByProjection(CurrentFrame, LastFrame) on its own inputs).  Every iteration must reproduce the first one's result; the caller holds
+// the results to the oracle.
+
+struct amos_thread_extract_job {
+    const uint8_t *gray;
+    int32_t w, h;
+    amos_keypoint *kps;   // cap
+    uint8_t *desc;        // cap x 32
+    int32_t cap, n, rc;   // rc: 0 ok, -1 an iteration differed from the first, -100 exception
+};
+
+struct amos_thread_match_job {
+    const amos_frame_view *cur;
+    const amos_proj_query *q;
+    int32_t nq;
+    const int32_t *cur_match_in;  // cur->n
+    int32_t *cur_match_out;       // cur->n
+    const float *scale_factors;
+    int32_t nsf;
+    float mbf, th;
+    int32_t forward, backward, result, rc;
+};
+
+int amos_host_run_threads(amos_thread_extract_job *ext, int n_ext, amos_thread_match_job *mat, int n_match, int iters, int *pool_handles)
+{
+    AMOS_HOST_TRY
+    std::vector<std::thread> threads;
+    std::vector<std::string> errors(n_ext + n_match);
+    for (int t = 0; t < n_ext; t++)
+        threads.emplace_back([&, t] {
+            amos_thread_extract_job &j = ext[t];
+            try {
+                ORBextractor extractor(1000, 1.2f, 8, 20, 7);
+                j.rc = 0;
+                std::vector<cv::KeyPoint> first;
+                cv::Mat firstDesc;
+                for (int it = 0; it < iters; it++) {
+                    cv::Mat image(j.h, j.w, CV_8UC1, (void *)j.gray, (size_t)j.w), mask, descriptors;
+                    std::vector<cv::KeyPoint> keys;
+                    extractor(image, mask, keys, descriptors);
+                    if (it == 0) {
+                        first = keys;
+                        firstDesc = descriptors.clone();
+                    } else if (keys.size() != first.size() || (keys.size() && (std::memcmp(keys.data(), first.data(), sizeof(cv::KeyPoint) * keys.size()) != 0 ||
+                                                                               std::memcmp(descriptors.data, firstDesc.data, 32 * keys.size()) != 0))) {
+                        j.rc = -1;
+                    }
+                }
+                j.n = (int)first.size();
+                if (j.n > j.cap) { j.rc = -3; return; }
+                if (j.n) {
+                    std::memcpy(j.kps, first.data(), sizeof(amos_keypoint) * first.size());
+                    std::memcpy(j.desc, firstDesc.data, (size_t)32 * first.size());
+                }
+            } catch (const std::exception &e) {
+                errors[t] = e.what();
+                j.rc = -100;
+            }
+        });
+    for (int t = 0; t < n_match; t++)
+        threads.emplace_back([&, t] {
+            amos_thread_match_job &j = mat[t];
+            try {
+                FeatureGrid grid(*j.cur);
+                std::vector<amos_proj_query> pts(j.q, j.q + j.nq);
+                std::vector<float> sf(j.scale_factors, j.scale_factors + j.nsf);
+                j.rc = 0;
+                for (int it = 0; it < iters; it++) {
+                    ORBmatcher matcher(0.9f, true);  // Tracking.cc:1910
+                    std::vector<int> match(j.cur_match_in, j.cur_match_in + j.cur->n);
+                    const int r = matcher.SearchByProjection(grid, pts, match, sf, j.mbf, j.th, j.forward != 0, j.backward != 0);
+                    if (it == 0) {
+                        j.result = r;
+                        std::memcpy(j.cur_match_out, match.data(), sizeof(int) * j.cur->n);
+                    } else if (r != j.result || std::memcmp(j.cur_match_out, match.data(), sizeof(int) * j.cur->n) != 0) {
+                        j.rc = -1;
+                    }
+                }
+            } catch (const std::exception &e) {
+                errors[n_ext + t] = e.what();
+                j.rc = -100;
+            }
+        });
+    for (std::thread &th : threads) th.join();
+    if (pool_handles) *pool_handles = ORBmatcher::PoolHandlesCreated();
+    for (const std::string &e : errors)
+        if (!e.empty()) { g_host_error = e; return -100; }
+    return 0;
+    AMOS_HOST_CATCH
+}
+
+// ---- what Tracking.cc:366 + Frame.cc:480-496,633 + Tracking.cc:1910 execute per frame, through the C++ classes themselves, host buffers
+// in and out:  yolact::evalImage(bgr) -> ORBextractor::operator()(gray, Mat(), levels) -> MovingKeyPoints(mask) -> ProcessDesp ->
+// a STACK-constructed ORBmatcher(0.9, true).SearchByProjection(CurrentFrame, LastFrame, 15, false) on stand-in frames (the last frame's
+// features carry map points back-projected at 2 m; identity poses: the projection window sits on the feature's own pixel).
+// frames: n_frames gray (h x w) and, with py_file, BGR (h x w x 3) frames, used round-robin.  out_ms[6]: mean per frame of
+// {evalImage, 3-arg operator(), MovingKeyPoints, ProcessDesp, ORBmatcher ctor + SearchByProjection + dtor, whole frame};
+// out_counts[3]: keypoints and matches of the last frame, evalImage calls that returned false.
+int amos_host_frame_latency(const char *py_file, const char *weights, const uint8_t *bgr, const uint8_t *gray, int n_frames, int w, int h,
+                            int warm, int iters, int pyramid_mode /* -1: the class's default, else ORBextractor::PyramidMode */, double *out_ms,
+                            int32_t *out_counts)
+{
+    AMOS_HOST_TRY
+    using namespace amos_standins;
+    typedef std::chrono::steady_clock clk;
+    yolact *seg = nullptr;
+    if (py_file && *py_file) {
+        seg = new yolact(py_file, weights ? weights : "", 20);  // (kept alive: the Python side keeps its session, as System.cc:106 keeps its own)
+        if (!seg->isInitializedResult()) { g_host_error = seg->getErrorDescriptionString(); return -102; }
+    }
+    ORBextractor ext(1000, 1.2f, 8, 20, 7);  // Tracking.cc:172
+    if (pyramid_mode >= 0) ext.SetPyramidMode((ORBextractor::PyramidMode)pyramid_mode);
+    std::vector<float> sf = ext.GetScaleFactors();
+    const float fx = 535.4f, fy = 539.2f, cx = 320.1f, cy = 247.6f;  // TUM3.yaml
+    auto make_frame = [&](Frame &F, const std::vector<cv::KeyPoint> &keys, const cv::Mat &desc) {
+        const int n = (int)keys.size();
+        F.N = n;
+        F.mvKeys = keys;
+        F.mvKeysUn = keys;
+        F.mDescriptors = desc.empty() ? cv::Mat(1, 32, CV_8U) : desc;
+        F.mvuRight.assign(n, -1.f);
+        F.mvpMapPoints.assign(n, static_cast<MapPoint *>(NULL));
+        F.mvbOutlier.assign(n, false);
+        F.fx = fx; F.fy = fy; F.cx = cx; F.cy = cy; F.mb = 0.08f; F.mbf = 40.f;
+        F.mnMinX = 0.f; F.mnMaxX = (float)w; F.mnMinY = 0.f; F.mnMaxY = (float)h;
+        F.mTcw = cv::Mat::zeros(4, 4, CV_32F);
+        for (int i = 0; i < 4; i++) F.mTcw.at<float>(i, i) = 1.f;
+        F.mnScaleLevels = (int)sf.size();
+        F.mvScaleFactors = sf;
+        F.mfLogScaleFactor = std::log(sf.size() > 1 ? sf[1] : 1.2f);
+    };
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    int failed_masks = 0, last_kp = 0, last_matches = 0;
+    Frame Last;
+    std::vector<MapPoint> lastPoints;
+    bool haveLast = false;
+    for (int it = 0; it < warm + iters; it++) {
+        const int f = it % n_frames;
+        const bool timed = it >= warm;
+        cv::Mat imGray(h, w, CV_8UC1, (void *)(gray + (size_t)f * w * h), (size_t)w), none;
+        const clk::time_point t0 = clk::now();
+        cv::Mat SegMask = cv::Mat::zeros(h, w, CV_8UC1);  // Tracking.cc:305
+        if (seg) {
+            cv::Mat imRGB(h, w * 3, CV_8UC1, (void *)(bgr + (size_t)f * w * h * 3), (size_t)w * 3), m;
+            if (seg->evalImage(imRGB, m)) SegMask = m;
+            else failed_masks += timed;
+        }
+        const clk::time_point t1 = clk::now();
+        std::vector<std::vector<cv::KeyPoint> > mvKeysTemp;
+        ext(imGray, none, mvKeysTemp);  // Frame.cc:484
+        const clk::time_point t2 = clk::now();
+        std::vector<cv::KeyPoint> dyn = ext.MovingKeyPoints(imGray, SegMask, cv::Mat(), std::vector<center>(), std::vector<int>(), std::vector<bool>(), mvKeysTemp);  // Frame.cc:633
+        const clk::time_point t3 = clk::now();
+        std::vector<cv::KeyPoint> mvKeys;
+        cv::Mat mDescriptors;
+        ext.ProcessDesp(imGray, none, mvKeysTemp, mvKeys, mDescriptors);  // Frame.cc:496
+        const clk::time_point t4 = clk::now();
+        Frame Cur;
+        make_frame(Cur, mvKeys, mDescriptors);
+        int nmatches = 0;
+        clk::time_point t5 = t4, t6 = t4;
+        if (haveLast) {
+            t5 = clk::now();
+            RefMatcher matcher(0.9f, true);  // Tracking.cc:1910: on the stack, every frame
+            nmatches = matcher.SearchByProjection(Cur, Last, 15.f, false);  // Tracking.cc:1937
+            t6 = clk::now();
+        }
+        // the current frame becomes the last one: every feature gets a map point 2 m in front of its pixel
+        lastPoints.clear();
+        lastPoints.resize(mvKeys.size());  // (each default-constructed: a copied stand-in MapPoint would share its Mats)
+        for (size_t i = 0; i < mvKeys.size(); i++) {
+            MapPoint &p = lastPoints[i];
+            const float z = 2.f;
+            p.mWorldPos.at<float>(0, 0) = (mvKeys[i].pt.x - cx) * z / fx;
+            p.mWorldPos.at<float>(1, 0) = (mvKeys[i].pt.y - cy) * z / fy;
+            p.mWorldPos.at<float>(2, 0) = z;
+            std::memcpy(p.mDescriptor.data, mDescriptors.ptr((int)i), 32);
+            p.mnObs = 1;
+        }
+        make_frame(Last, mvKeys, mDescriptors.clone());
+        for (size_t i = 0; i < mvKeys.size(); i++) Last.mvpMapPoints[i] = &lastPoints[i];
+        haveLast = true;
+        const clk::time_point t7 = clk::now();
+        if (timed) {
+            auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            acc[0] += ms(t0, t1); acc[1] += ms(t1, t2); acc[2] += ms(t2, t3); acc[3] += ms(t3, t4); acc[4] += ms(t5, t6);
+            acc[5] += ms(t0, t4) + ms(t5, t6);  // (building the stand-in frames is the harness's work, not the path's)
+            (void)t7;
+        }
+        last_kp = (int)mvKeys.size();
+        last_matches = nmatches;
+    }
+    for (int k = 0; k < 6; k++) out_ms[k] = acc[k] / std::max(iters, 1);
+    out_counts[0] = last_kp;
+    out_counts[1] = last_matches;
+    out_counts[2] = failed_masks;
+    return 0;
     AMOS_HOST_CATCH
 }
 

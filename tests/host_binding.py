@@ -1,4 +1,4 @@
-"""ctypes binding of amos-slam_amd/host/libamos_host.so (the C++ drop-in classes' test hooks) and
+"""ctypes binding of tests/host/libamos_host_test.so (the harness over the C++ drop-in classes of amos-slam_amd/host/libamos_host.so) and
 of the oracle's gated-search restatements."""
 import ctypes as C
 import os
@@ -8,7 +8,7 @@ import numpy as np
 import oracle_binding as ob
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HOST_SO = os.path.join(ROOT, "amos-slam_amd", "host", "libamos_host.so")
+HOST_SO = os.path.join(ROOT, "tests", "host", "libamos_host_test.so")
 
 KP = ob.KP_DTYPE
 PROJ_QUERY = np.dtype([("u", "<f4"), ("v", "<f4"), ("invz", "<f4"), ("octave", "<i4"), ("angle", "<f4"), ("has_obs", "<i4"),
@@ -124,6 +124,81 @@ def host_amos_flow(gray, mask, labels=None, center_ids=None, rm=None, nf=1000, s
                                     C.c_int(0 if rm is None else len(rm)), _p(removed), C.byref(nrem), _p(kps), _p(desc), C.c_int(cap),
                                     C.byref(n), _p(lists), _p(counts)))
     return removed[:nrem.value].copy(), kps[:n.value].copy(), desc[:n.value].copy(), lists[:counts.sum()].copy(), counts
+
+
+def host_pyramid_on_demand(gray, nl=8, pyr_level=2):
+    """3-arg operator() under the default pyramid mode, then DownloadPyramid(): (rows, cols per level before any pixel copy, padded plane of
+    pyr_level afterwards, the extractor's device)."""
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    lw, lh = ob.Oracle(1000, 1.2, nl).level_sizes(w, h)
+    rc = np.zeros((nl, 2), np.int32)
+    pyr = np.zeros((int(lh[pyr_level]) + 38, int(lw[pyr_level]) + 38), np.uint8)
+    dev = C.c_int32(-7)
+    _chk(host().amos_host_pyramid_on_demand(_p(gray), C.c_int(w), C.c_int(h), C.c_int(nl), _p(rc), C.c_int(pyr_level), _p(pyr), C.byref(dev)))
+    return rc, pyr, dev.value
+
+
+class ThreadExtractJob(C.Structure):
+    _fields_ = [("gray", C.c_void_p), ("w", C.c_int32), ("h", C.c_int32), ("kps", C.c_void_p), ("desc", C.c_void_p), ("cap", C.c_int32),
+                ("n", C.c_int32), ("rc", C.c_int32)]
+
+
+class ThreadMatchJob(C.Structure):
+    _fields_ = [("cur", C.c_void_p), ("q", C.c_void_p), ("nq", C.c_int32), ("cur_match_in", C.c_void_p), ("cur_match_out", C.c_void_p),
+                ("scale_factors", C.c_void_p), ("nsf", C.c_int32), ("mbf", C.c_float), ("th", C.c_float), ("forward", C.c_int32),
+                ("backward", C.c_int32), ("result", C.c_int32), ("rc", C.c_int32)]
+
+
+def host_run_threads(frames, searches, iters=6):
+    """frames: gray images, one ORBextractor + std::thread each (4-arg operator(), `iters` times); searches: (frame view, PROJ_QUERY array,
+    cur_match, scale factors, mbf, th, forward, backward), one std::thread each constructing a stack ORBmatcher per iteration.  Returns
+    ([(kps, desc)], [(result, cur_match)], handles the matcher pool has created so far)."""
+    keep = []
+    ej = (ThreadExtractJob * len(frames))()
+    for j, g in zip(ej, frames):
+        g = np.ascontiguousarray(g, np.uint8)
+        cap = 2000 + 64 * 8
+        kps, desc = np.zeros(cap, KP), np.zeros((cap, 32), np.uint8)
+        keep.append((g, kps, desc))
+        j.gray, j.w, j.h, j.kps, j.desc, j.cap, j.n, j.rc = g.ctypes.data, g.shape[1], g.shape[0], kps.ctypes.data, desc.ctypes.data, cap, 0, -9
+    mj = (ThreadMatchJob * len(searches))()
+    outs = []
+    for j, (view, q, match0, sf, mbf, th, fwd, bwd) in zip(mj, searches):
+        q = np.ascontiguousarray(q, PROJ_QUERY)
+        m_in = np.ascontiguousarray(match0, np.int32)
+        m_out = np.zeros_like(m_in)
+        sf = np.ascontiguousarray(sf, np.float32)
+        keep.append((view, q, m_in, sf))
+        outs.append(m_out)
+        j.cur, j.q, j.nq, j.cur_match_in, j.cur_match_out = C.addressof(view), q.ctypes.data, len(q), m_in.ctypes.data, m_out.ctypes.data
+        j.scale_factors, j.nsf, j.mbf, j.th, j.forward, j.backward, j.result, j.rc = sf.ctypes.data, len(sf), mbf, th, fwd, bwd, -9, -9
+    pool = C.c_int(0)
+    _chk(host().amos_host_run_threads(ej, C.c_int(len(frames)), mj, C.c_int(len(searches)), C.c_int(iters), C.byref(pool)))
+    ext = []
+    for j, (_, kps, desc) in zip(ej, keep[:len(frames)]):
+        assert j.rc == 0, f"extractor thread: rc {j.rc}"
+        ext.append((kps[:j.n].copy(), desc[:j.n].copy()))
+    res = []
+    for j, m in zip(mj, outs):
+        assert j.rc == 0, f"matcher thread: rc {j.rc}"
+        res.append((j.result, m))
+    return ext, res, pool.value
+
+
+def host_frame_latency(gray_frames, bgr_frames=None, py_file=None, weights="", warm=5, iters=100, pyramid_mode=-1):
+    """amos_host_frame_latency: the per-frame C++ drop-in path (evalImage -> operator() -> MovingKeyPoints -> ProcessDesp -> stack ORBmatcher
+    SearchByProjection), host buffers in and out.  Returns a dict of mean milliseconds per frame and the last frame's counts."""
+    gray = np.ascontiguousarray(gray_frames, np.uint8)
+    n, h, w = gray.shape
+    bgr = None if bgr_frames is None else np.ascontiguousarray(bgr_frames, np.uint8)
+    ms, counts = np.zeros(6, np.float64), np.zeros(3, np.int32)
+    _chk(host().amos_host_frame_latency((py_file or "").encode(), (weights or "").encode(), _p(bgr), _p(gray), C.c_int(n), C.c_int(w), C.c_int(h),
+                                        C.c_int(warm), C.c_int(iters), C.c_int(pyramid_mode), _p(ms), _p(counts)))
+    keys = ("eval_image_ms", "detect_ms", "moving_keypoints_ms", "process_desp_ms", "search_by_projection_ms", "frame_ms")
+    out = {k: round(float(v), 4) for k, v in zip(keys, ms)}
+    out.update(keypoints_last_frame=int(counts[0]), matches_last_frame=int(counts[1]), eval_image_false=int(counts[2]), frames=iters)
+    return out
 
 
 def host_descriptor_distance(a, b):

@@ -520,3 +520,67 @@ def test_reference_signature_search_by_projection_local_points(hb, ob, synth):
         got_n, got = hb.ref_search_local_points(cam, k1, d1, ur, pts, in_view, bad, th)
         assert got_n == want_n and np.array_equal(got, np.where(want >= 0, src[np.maximum(want, 0)], -1))
     assert got_n > 50
+
+
+def test_pyramid_is_downloaded_on_demand_and_the_device_is_the_callers(hb, ob, synth, monkeypatch):
+    """Default pyramid mode: the 3-arg operator() (RGB-D Amos flow, Frame.cc:484) copies no pixel, yet every mvImagePyramid[l] has the level's
+    rows / cols (Frame.cc:1197 reads mvImagePyramid[0].rows); DownloadPyramid() then gives the padded planes (stereo, Frame.cc:1401,1434;
+    the 4-arg operator() does it by itself: test_extractor_call_operator).  The handle sits on the calling thread's current device; AMOS_DEVICE
+    overrides it (a device that does not exist is refused: the variable is honoured, nothing is hard-wired to device 0)."""
+    img = synth.frame(13, 5)
+    rc, pyr, dev = hb.host_pyramid_on_demand(img, pyr_level=3)
+    orc = ob.Oracle()
+    orc.extract(img)
+    lw, lh = orc.level_sizes(640, 480)
+    assert rc[:, 0].tolist() == [int(v) for v in lh] and rc[:, 1].tolist() == [int(v) for v in lw]
+    _same(pyr, orc.level_image(3, padded=True), "mvImagePyramid[3] after DownloadPyramid()")
+    import torch
+    assert dev == torch.cuda.current_device() == 0
+    monkeypatch.setenv("AMOS_DEVICE", "5")
+    with pytest.raises(RuntimeError, match="(?i)device|ordinal"):
+        hb.host_pyramid_on_demand(img)
+    monkeypatch.setenv("AMOS_DEVICE", "0")
+    assert hb.host_pyramid_on_demand(img, pyr_level=3)[2] == 0
+
+
+def test_extractors_and_matchers_on_separate_threads(hb, ob, synth):
+    """SURVEY 8b threading: two ORBextractor instances on two std::threads (stereo, Frame.cc:165-170) beside three threads that each construct
+    an ORBmatcher on the stack per search (Tracking / LocalMapping / LoopClosing), all at once: every result equals the oracle's, every
+    repetition equals the first, and the stack-constructed matchers reuse the pool's handles (3 threads x 6 constructions -> at most a few
+    handles ever created, not 18)."""
+    left, right = synth.frame(21, 3), synth.frame(22, 7)
+    k0, d0, k1, d1, sf = _two_frames(ob, synth)
+    rng = np.random.default_rng(9)
+    searches = []
+    for t in range(3):
+        ur = np.where(rng.random(len(k1)) < 0.7, k1["x"] - rng.uniform(5, 40, len(k1)).astype(np.float32), np.float32(-1)).astype(np.float32)
+        view, keep = hb.frame_view(k1, d1, ur)
+        q = np.zeros(len(k0), hb.PROJ_QUERY)
+        q["u"] = k0["x"] - 2 + rng.normal(0, 1.5, len(k0)).astype(np.float32)
+        q["v"] = k0["y"] - 1 + rng.normal(0, 1.5, len(k0)).astype(np.float32)
+        q["invz"] = rng.uniform(0.2, 2.0, len(k0)).astype(np.float32)
+        q["octave"], q["angle"], q["desc"] = k0["octave"], k0["angle"], d0
+        q["has_obs"] = rng.random(len(k0)) < 0.6
+        searches.append((view, q, np.full(len(k1), -1, np.int32), sf, 40.0, (7.0, 15.0, 11.0)[t], (0, 1, 0)[t], (0, 0, 1)[t], keep))
+    before = hb.host_run_threads([], [s[:8] for s in searches[:1]], iters=1)[2]   # (whatever earlier tests left in the pool)
+    ext, res, pool = hb.host_run_threads([left, right], [s[:8] for s in searches], iters=6)
+    for img, (kps, desc) in zip((left, right), ext):
+        ko, do = ob.Oracle().extract(img)
+        _same(kps, ko, "keypoints")
+        _same(desc, do, "descriptors")
+    for (view, q, m0, sf_, mbf, th, fwd, bwd, _), (r, m) in zip(searches, res):
+        ro, mo = hb.search_frame("oracle", view, q, m0, sf_, mbf, th, fwd, bwd)
+        assert r == ro and np.array_equal(m, mo) and r > 50
+    assert pool - before <= 3, (before, pool)   # three concurrent matchers at most: 18 constructions, <= 3 new handles
+
+
+def test_frame_latency_harness_runs_the_reference_call_sequence(hb, ob, synth):
+    """amos_host_frame_latency (bench.py's drop_in_latency.cxx_* figures) without the mask network: 3-arg operator() -> MovingKeyPoints ->
+    ProcessDesp -> stack ORBmatcher::SearchByProjection(CurrentFrame, LastFrame) on consecutive synthetic frames: the keypoint count is the
+    oracle's for the last frame (an all-zero mask gates nothing) and most features find their match."""
+    frames = np.stack([synth.frame(31, k) for k in range(4)])
+    out = hb.host_frame_latency(frames, warm=2, iters=6)   # 8 calls: the last frame processed is frame 3
+    ko, _ = ob.Oracle().extract(frames[3])
+    assert out["keypoints_last_frame"] == len(ko) and out["matches_last_frame"] > 300, out
+    assert out["eval_image_ms"] < 1.0 and out["eval_image_false"] == 0   # no network in this run
+    assert 0 < out["detect_ms"] and 0 < out["process_desp_ms"] and 0 < out["search_by_projection_ms"] and out["frame_ms"] < 50
