@@ -593,17 +593,16 @@ struct amos_match {
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
-    // grow-only device scratch for the host-pointer entry points
+    // device scratch of the host-pointer entry points: the inputs of the call in flight (pointers into dArena), the grow-only result buffer
     uint8_t *dQ = nullptr, *dT = nullptr;
-    size_t capQ = 0, capT = 0;
     int *dOff = nullptr, *dIdx = nullptr;
-    size_t capOff = 0, capIdx = 0;
     void *dOut = nullptr;
     size_t capOut = 0;
     // pinned host staging of the host-buffer calls: the caller's (pageable) arrays are copied here and travel as true asynchronous DMA
     // transfers; results land here behind the kernel and are copied out after the ONE synchronisation of the call (a hipMemcpyAsync on
     // pageable memory is a blocking staged copy of its own: six of them were most of a 0.26 ms list-distance call)
     uint8_t *hStage = nullptr;
+    uint8_t *dArena = nullptr;  // device mirror of the staging buffer's input part: the inputs of a call travel as ONE transfer (dQ / dT / dOff / dIdx point into it)
     size_t capStage = 0, stageUsed = 0;
     int bfKernel = 0;  // brute-force best-2: 0 = choose by size, 1 = xor + popcount kernel, 2 = i8 MFMA kernel
 };
@@ -657,42 +656,47 @@ static int stage_begin(amos_match *m, size_t bytes)
     m->stageUsed = 0;
     bytes += 1024;  // alignment slack of the pieces
     if (bytes <= m->capStage) return AMOS_OK;
-    if (m->hStage) {
-        (void)hipStreamSynchronize(m->stream);  // (a call that failed half way may have left a transfer reading the old buffer)
-        (void)hipHostFree(m->hStage);
-    }
-    m->hStage = nullptr;
+    if (m->hStage || m->dArena) (void)hipStreamSynchronize(m->stream);  // (a call that failed half way may have left a transfer in flight)
+    if (m->hStage) (void)hipHostFree(m->hStage);
+    if (m->dArena) (void)hipFree(m->dArena);
+    m->hStage = m->dArena = nullptr;
     m->capStage = 0;
     const size_t n = std::max<size_t>(bytes + bytes / 2, 1 << 16);
-    if (hipHostMalloc((void **)&m->hStage, n, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void **)&m->hStage, n, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&m->dArena, n) != hipSuccess) {
         (void)hipGetLastError();
-        set_error("hipHostMalloc (matcher staging, %zu bytes) failed", n);
+        set_error("matcher staging of %zu bytes (pinned host + device) could not be allocated", n);
         return AMOS_ERR_DEVICE;
     }
     m->capStage = n;
     return AMOS_OK;
 }
 
-static uint8_t *stage_take(amos_match *m, size_t bytes)
+static size_t stage_take(amos_match *m, size_t bytes)
 {
-    uint8_t *p = m->hStage + m->stageUsed;
+    const size_t o = m->stageUsed;
     m->stageUsed += (bytes + 63) & ~(size_t)63;
-    return p;  // (stage_begin sized the buffer for the sum of the call's pieces)
+    return o;  // (stage_begin sized the buffers for the sum of the call's pieces)
 }
 
-static int stage_h2d(amos_match *m, void *dst, const void *src, size_t bytes)
+// host array -> staging; returns where it will sit on the device once stage_flush has run
+template <typename T>
+static T *stage_input(amos_match *m, const void *src, size_t bytes)
 {
-    if (bytes == 0) return AMOS_OK;
-    uint8_t *p = stage_take(m, bytes);
-    std::memcpy(p, src, bytes);
-    AMOS_HIP_CHECK(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, m->stream));
+    const size_t o = stage_take(m, bytes);
+    if (bytes) std::memcpy(m->hStage + o, src, bytes);
+    return reinterpret_cast<T *>(m->dArena + o);
+}
+
+static int stage_flush(amos_match *m)
+{
+    if (m->stageUsed) AMOS_HIP_CHECK(hipMemcpyAsync(m->dArena, m->hStage, m->stageUsed, hipMemcpyHostToDevice, m->stream));
     return AMOS_OK;
 }
 
-// device -> staging now, staging -> `out` after the synchronisation (stage_finish)
+// device -> staging (behind the inputs), one synchronisation, staging -> `out`
 static int stage_d2h_sync(amos_match *m, void *out, const void *src, size_t bytes)
 {
-    uint8_t *p = stage_take(m, bytes);
+    uint8_t *p = m->hStage + stage_take(m, bytes);
     AMOS_HIP_CHECK(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToHost, m->stream));
     AMOS_HIP_CHECK(hipStreamSynchronize(m->stream));
     std::memcpy(out, p, bytes);
@@ -701,12 +705,8 @@ static int stage_d2h_sync(amos_match *m, void *out, const void *src, size_t byte
 
 static int upload_sets(amos_match *m, const uint8_t *q, int nq, const uint8_t *t, int nt)
 {
-    int rc = grow(&m->dQ, &m->capQ, (size_t)nq * 32 + 32);
-    if (rc != AMOS_OK) return rc;
-    rc = grow(&m->dT, &m->capT, (size_t)nt * 32 + 32);
-    if (rc != AMOS_OK) return rc;
-    if (nq > 0 && (rc = stage_h2d(m, m->dQ, q, (size_t)nq * 32)) != AMOS_OK) return rc;
-    if (nt > 0 && (rc = stage_h2d(m, m->dT, t, (size_t)nt * 32)) != AMOS_OK) return rc;
+    m->dQ = stage_input<uint8_t>(m, q, (size_t)nq * 32);
+    m->dT = stage_input<uint8_t>(m, t, (size_t)nt * 32);
     return AMOS_OK;
 }
 
@@ -718,12 +718,8 @@ static int upload_lists(amos_match *m, int nq, int nt, const int32_t *cand_off, 
     const int n = cand_off[nq];
     for (int k = 0; k < n; k++)
         if (cand_idx[k] < 0 || cand_idx[k] >= nt) { set_error("cand_idx[%d] = %d outside [0,%d)", k, cand_idx[k], nt); return AMOS_ERR_INVALID; }
-    int rc = grow(&m->dOff, &m->capOff, (size_t)nq + 1);
-    if (rc != AMOS_OK) return rc;
-    rc = grow(&m->dIdx, &m->capIdx, (size_t)n + 1);
-    if (rc != AMOS_OK) return rc;
-    if ((rc = stage_h2d(m, m->dOff, cand_off, sizeof(int) * ((size_t)nq + 1))) != AMOS_OK) return rc;
-    if (n > 0 && (rc = stage_h2d(m, m->dIdx, cand_idx, sizeof(int) * (size_t)n)) != AMOS_OK) return rc;
+    m->dOff = stage_input<int>(m, cand_off, sizeof(int) * ((size_t)nq + 1));
+    m->dIdx = stage_input<int>(m, cand_idx, sizeof(int) * (size_t)n);
     *total = n;
     return AMOS_OK;
 }
@@ -759,7 +755,7 @@ void amos_match_destroy(amos_match *m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    void *ptrs[] = {m->dQ, m->dT, m->dOff, m->dIdx, m->dOut};
+    void *ptrs[] = {m->dArena, m->dOut};  // (dQ / dT / dOff / dIdx point into the arena)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (m->hStage) (void)hipHostFree(m->hStage);
     if (m->ownStream && m->stream) (void)hipStreamDestroy(m->stream);
@@ -794,6 +790,8 @@ int amos_match_distances(amos_match *m, const uint8_t *q, int nq, const uint8_t 
     if (rc != AMOS_OK) return rc;
     rc = grow_out(m, bytes);
     if (rc != AMOS_OK) return rc;
+    rc = stage_flush(m);
+    if (rc != AMOS_OK) return rc;
     hipLaunchKernelGGL(k_dist_dense, dim3((nt + 255) / 256, (nq + 15) / 16), dim3(256), 0, m->stream, m->dQ, nq, m->dT, nt, (uint16_t *)m->dOut);
     AMOS_HIP_CHECK(hipGetLastError());
     return stage_d2h_sync(m, out, m->dOut, bytes);
@@ -811,11 +809,13 @@ int amos_match_list_distances(amos_match *m, const uint8_t *q, int nq, const uin
     if (rc != AMOS_OK) return rc;
     rc = upload_lists(m, nq, nt, cand_off, cand_idx, &total);
     if (rc != AMOS_OK) return rc;
-    if (total == 0) { AMOS_HIP_CHECK(hipStreamSynchronize(m->stream)); return AMOS_OK; }
-    if (!t || !out || !cand_idx) { AMOS_HIP_CHECK(hipStreamSynchronize(m->stream)); set_error("amos_match_list_distances: null buffer"); return AMOS_ERR_INVALID; }
+    if (total == 0) return AMOS_OK;
+    if (!t || !out || !cand_idx) { set_error("amos_match_list_distances: null buffer"); return AMOS_ERR_INVALID; }
     rc = upload_sets(m, q, nq, t, nt);
     if (rc != AMOS_OK) return rc;
     rc = grow_out(m, (size_t)total * sizeof(uint16_t));
+    if (rc != AMOS_OK) return rc;
+    rc = stage_flush(m);
     if (rc != AMOS_OK) return rc;
     hipLaunchKernelGGL(k_list_dist, dim3((nq + 3) / 4), dim3(256), 0, m->stream, m->dQ, nq, m->dT, m->dOff, m->dIdx, (uint16_t *)m->dOut);
     AMOS_HIP_CHECK(hipGetLastError());
@@ -834,10 +834,12 @@ int amos_match_list_best2(amos_match *m, const uint8_t *q, int nq, const uint8_t
     if (rc != AMOS_OK) return rc;
     rc = upload_lists(m, nq, nt, cand_off, cand_idx, &total);
     if (rc != AMOS_OK) return rc;
-    if (total > 0 && (!t || !cand_idx)) { AMOS_HIP_CHECK(hipStreamSynchronize(m->stream)); set_error("amos_match_list_best2: null buffer"); return AMOS_ERR_INVALID; }
+    if (total > 0 && (!t || !cand_idx)) { set_error("amos_match_list_best2: null buffer"); return AMOS_ERR_INVALID; }
     rc = upload_sets(m, q, nq, t, nt);
     if (rc != AMOS_OK) return rc;
     rc = grow_out(m, (size_t)nq * sizeof(amos_best2));
+    if (rc != AMOS_OK) return rc;
+    rc = stage_flush(m);
     if (rc != AMOS_OK) return rc;
     hipLaunchKernelGGL(k_list_best2, dim3((nq + 3) / 4), dim3(256), 0, m->stream, m->dQ, nq, m->dT, m->dOff, m->dIdx, init_dist, (amos_best2 *)m->dOut);
     AMOS_HIP_CHECK(hipGetLastError());
@@ -856,6 +858,8 @@ int amos_match_bruteforce_best2(amos_match *m, const uint8_t *q, int nq, const u
     rc = upload_sets(m, q, nq, t, nt);
     if (rc != AMOS_OK) return rc;
     rc = grow_out(m, (size_t)nq * sizeof(amos_best2));
+    if (rc != AMOS_OK) return rc;
+    rc = stage_flush(m);
     if (rc != AMOS_OK) return rc;
     {
         const bool mfma = use_mfma(m, nq, nt);

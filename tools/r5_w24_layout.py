@@ -27,24 +27,28 @@ for frames, cin, cout, hw in ((64, 256, 256, 138), (64, 256, 256, 69), (64, 256,
     ys = {}
     row = {"frames": frames, "cin": cin, "cout": cout, "hw": hw}
     flops = 2.0 * 24 * frames * ((hw + 1) // 2) * ((hw + 3) // 4) * cin * cout
-    for name, xin, ib, ob in (("nhwc_nhwc", x, 0, 0), ("blocked_nhwc", xb, 1, 0), ("blocked_blocked", xb, 1, 1), ("nhwc_blocked", x, 0, 1)):
-        y = torch.full((frames * hw * hw * cout,), float("nan"), device="cuda")
+    cfgs = (("nhwc_nhwc", x, 0, 0), ("blocked_nhwc", xb, 1, 0), ("blocked_blocked", xb, 1, 1), ("nhwc_blocked", x, 0, 1))
+    best = {c[0]: 1e9 for c in cfgs}
+    for rep in range(3):   # configurations interleaved, best of three rounds: no configuration pays for the clock ramp of the first launches
+        for name, xin, ib, ob in cfgs:
+            y = torch.full((frames * hw * hw * cout,), float("nan"), device="cuda")
 
-        def launch():
-            pkg.mask_winograd24_conv_layout(st.cuda_stream, xin.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, True, ib, ob)
-        for _ in range(3):
-            launch()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        for _ in range(10):
-            launch()
-        e1.record(st)
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / 10
-        yy = y.view(frames, cout // 8, hw, hw, 8).permute(0, 2, 3, 1, 4).reshape(frames, hw, hw, cout) if ob else y.view(frames, hw, hw, cout)
-        ys[name] = yy
-        row[name + "_ms"] = round(ms, 4)
-        row[name + "_tflops"] = round(flops / ms / 1e9, 1)
+            def launch():
+                pkg.mask_winograd24_conv_layout(st.cuda_stream, xin.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, True, ib, ob)
+            for _ in range(3):
+                launch()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(10):
+                launch()
+            e1.record(st)
+            e1.synchronize()
+            best[name] = min(best[name], e0.elapsed_time(e1) / 10)
+            yy = y.view(frames, cout // 8, hw, hw, 8).permute(0, 2, 3, 1, 4).reshape(frames, hw, hw, cout) if ob else y.view(frames, hw, hw, cout)
+            ys[name] = yy
+    for name in best:
+        row[name + "_ms"] = round(best[name], 4)
+        row[name + "_tflops"] = round(flops / best[name] / 1e9, 1)
     for k in ys:
         assert torch.equal(ys[k], ys["nhwc_nhwc"]), k
     out.append(row)
