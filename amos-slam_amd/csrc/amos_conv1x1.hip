@@ -192,14 +192,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         __builtin_amdgcn_sched_group_barrier(0x008, kMfmas, 0);                           \
         __builtin_amdgcn_sched_barrier(0);                                                \
     }
-    // The residual tile of the epilogue is requested HERE, before the main loop: on the layers that carry one (a bottleneck's expand
-    // convolution: K = 64 .. 512, two to sixteen stages) the output side moves 8 - 16 x the bytes of the operands, and a work-group that only
-    // asks for its residual after the last MFMA leaves the memory pipe idle for the whole main loop (two groups per CU, mostly in the same
-    // phase).  Same values, same order of sums: bits unchanged.  64 registers (wide tiles) / 32 (narrow) beside the 64 / 32 accumulators.
-    constexpr int kCols = BN / 4, kRowsPerPass = 256 / kCols, kPasses = BM / kRowsPerPass;  // float4 columns; rows per sweep of the group
-    const int oc = t % kCols, orow = t / kCols;
-    const int n0 = nt * BN + 4 * oc;
-    float4 rv[kPasses];
     f32x16 acc[TI][2];
 #pragma unroll
     for (int i = 0; i < TI; i++)
@@ -213,17 +205,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     AMOS_GEMM_FETCH(0);
     AMOS_GEMM_STASH(0);
     if (stages > 1) AMOS_GEMM_FETCH(1);
-    // (behind the first two operand tiles: the vector-memory counter retires in order, so only the fetch of stage 2 waits for these)
-    if (a.res) {
-#pragma unroll
-        for (int q = 0; q < kPasses; q++) {
-            const int m = min(mt * BM + q * kRowsPerPass + orow, a.M - 1);  // (rows past the end are not stored)
-            rv[q] = *reinterpret_cast<const float4 *>(a.res + (size_t)m * a.N + n0);
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < kPasses; q++) rv[q] = float4{0.f, 0.f, 0.f, 0.f};
-    }
     __syncthreads();
     AMOS_GEMM_LDFRAG(fa0, fb0, 0, 0);
     int s = 0;
@@ -259,15 +240,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             for (int r = 0; r < 16; r++)
                 smem[(wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
     __syncthreads();
+    constexpr int kCols = BN / 4, kRowsPerPass = 256 / kCols, kPasses = BM / kRowsPerPass;  // float4 columns; rows per sweep of the group
+    const int oc = t % kCols, orow = t / kCols;
+    const int n0 = nt * BN + 4 * oc;
     const float4 bv = a.bias ? *reinterpret_cast<const float4 *>(a.bias + n0) : float4{0.f, 0.f, 0.f, 0.f};
+    constexpr int kBatch = 8;  // residual loads in flight per thread
 #pragma unroll
-    for (int q = 0; q < kPasses; q++) {
-        const int row = q * kRowsPerPass + orow, m = mt * BM + row;
-        if (m >= a.M) continue;
-        float4 v = *reinterpret_cast<const float4 *>(&smem[row * BN + 4 * oc]);
-        v.x = (v.x + bv.x) + rv[q].x; v.y = (v.y + bv.y) + rv[q].y; v.z = (v.z + bv.z) + rv[q].z; v.w = (v.w + bv.w) + rv[q].w;
-        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<float4 *>(a.y + (size_t)m * a.N + n0) = v;
+    for (int p0 = 0; p0 < kPasses; p0 += kBatch) {
+        float4 rv[kBatch];
+#pragma unroll
+        for (int q = 0; q < kBatch; q++) {
+            const int m = mt * BM + (p0 + q) * kRowsPerPass + orow;
+            rv[q] = (a.res && m < a.M) ? *reinterpret_cast<const float4 *>(a.res + (size_t)m * a.N + n0) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < kBatch; q++) {
+            const int row = (p0 + q) * kRowsPerPass + orow, m = mt * BM + row;
+            if (m >= a.M) continue;
+            float4 v = *reinterpret_cast<const float4 *>(&smem[row * BN + 4 * oc]);
+            v.x = (v.x + bv.x) + rv[q].x; v.y = (v.y + bv.y) + rv[q].y; v.z = (v.z + bv.z) + rv[q].z; v.w = (v.w + bv.w) + rv[q].w;
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4 *>(a.y + (size_t)m * a.N + n0) = v;
+        }
     }
 }
 

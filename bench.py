@@ -852,6 +852,10 @@ def main():
                                "frac": (round(achieved / HBM_PEAK_GBS, 5) if achieved is not None else None), "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
                                "launches_per_pass": launches[dominant],
+                               "avg_launch_ms_is": "a HIP-event INTERVAL on the launching stream (lane 0) inside the timed region: with several lanes running it "
+                                                   "includes the time the launch waits behind / shares CUs with the other lanes' kernels, so it is longer than the "
+                                                   "kernel duration rocprofv3 reports for the same launches (profiles/*_steady_mask_off_kernel_stats.csv); the same "
+                                                   "launch alone on the chip is roofline_lane_alone",
                                "measured_in": "extract_match_leg timed region (HIP events on lane 0's streams)" if use_mask else "the timed region (HIP events on lane 0's streams)"}
             pipeline = {"algorithmic_bytes_per_frame": int(total_alg), "achieved_GBs": round(total_alg * em_fps / world / 1e9, 2),
                         "frac": round(total_alg * em_fps / world / 1e9 / HBM_PEAK_GBS, 5)}
