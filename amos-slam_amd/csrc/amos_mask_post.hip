@@ -186,24 +186,45 @@ __global__ __launch_bounds__(256) void k_topk_rows(const float *__restrict__ x, 
         for (int b = t; b < kTopkBins; b += 256) hist[b] = 0;
         __syncthreads();
         const unsigned prefix = sPrefix, mask = sMask, need = sNeed;
-        for (int i0 = 0; i0 < n; i0 += 256) {
+        // a row is mostly ONE value (-1 for priors under the threshold): when every participating lane of the wave has the same
+        // bin, one lane adds the count instead of 64 atomics on one address
+#define AMOS_TOPK_COUNT(in, bin)                                                                                          \
+        {                                                                                                                 \
+            const unsigned long long m = __ballot(in);                                                                    \
+            if (m) {                                                                                                      \
+                const unsigned b0 = __builtin_amdgcn_readfirstlane((in) ? (bin) : __shfl((bin), __builtin_ctzll(m), 64)); \
+                const bool same = __ballot((in) && (bin) != b0) == 0ull;                                                  \
+                if (same) {                                                                                               \
+                    if (lane == (int)__builtin_ctzll(m)) atomicAdd(&hist[b0], (unsigned)__popcll(m));                     \
+                } else if (in) {                                                                                          \
+                    atomicAdd(&hist[(bin)], 1u);                                                                          \
+                }                                                                                                         \
+            }                                                                                                             \
+        }
+        // the histogram does not care about the order of the elements: four per thread and trip through one 16-byte load when the row
+        // allows it (four independent loads in flight instead of one: the scan is a chain of load -> ballot -> LDS atomic latencies)
+        const bool vec = (n & 3) == 0 && ((uintptr_t)row & 15) == 0;
+        const int nVec = vec ? n : 0;
+        for (int i0 = 0; i0 < nVec; i0 += 1024) {
+            const int i = i0 + 4 * t;
+            const bool have = i < n;
+            const float4 v = have ? *reinterpret_cast<const float4 *>(row + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned k0 = topk_key(v.x), k1 = topk_key(v.y), k2 = topk_key(v.z), k3 = topk_key(v.w);
+            const bool in0 = have && (k0 & mask) == prefix, in1 = have && (k1 & mask) == prefix, in2 = have && (k2 & mask) == prefix, in3 = have && (k3 & mask) == prefix;
+            const unsigned b0_ = (k0 >> shift) & (bins - 1), b1_ = (k1 >> shift) & (bins - 1), b2_ = (k2 >> shift) & (bins - 1), b3_ = (k3 >> shift) & (bins - 1);
+            AMOS_TOPK_COUNT(in0, b0_)
+            AMOS_TOPK_COUNT(in1, b1_)
+            AMOS_TOPK_COUNT(in2, b2_)
+            AMOS_TOPK_COUNT(in3, b3_)
+        }
+        for (int i0 = nVec; i0 < n; i0 += 256) {
             const int i = i0 + t;
             const unsigned key = i < n ? topk_key(row[i]) : 0u;
             const bool in = i < n && (key & mask) == prefix;
             const unsigned bin = (key >> shift) & (bins - 1);
-            // a row is mostly ONE value (-1 for priors under the threshold): when every participating lane of the wave has the same
-            // bin, one lane adds the count instead of 64 atomics on one address
-            const unsigned long long m = __ballot(in);
-            if (m) {
-                const unsigned b0 = __builtin_amdgcn_readfirstlane(in ? bin : __shfl(bin, __builtin_ctzll(m), 64));
-                const bool same = __ballot(in && bin != b0) == 0ull;
-                if (same) {
-                    if (lane == (int)__builtin_ctzll(m)) atomicAdd(&hist[b0], (unsigned)__popcll(m));
-                } else if (in) {
-                    atomicAdd(&hist[bin], 1u);
-                }
-            }
+            AMOS_TOPK_COUNT(in, bin)
         }
+#undef AMOS_TOPK_COUNT
         __syncthreads();
         {  // partial sums of 8 bins per thread
             unsigned p = 0;
@@ -283,6 +304,171 @@ __global__ __launch_bounds__(256) void k_topk_rows(const float *__restrict__ x, 
     }
 }
 
+
+// ---- the rest of Detect + postprocess + prep_display for the static-shape batch path (mask/detect.py detect_batch, mask/post.py
+// person_mask_batch), fused: PyTorch spends ~75 small launches per pass on these steps (box decoding, two gathers, where / topk / gathers of
+// the best 100 and then the best 15, `_sanitize` and the crop mask op by op, an einsum and a sigmoid) -- at one frame per pass that is a
+// fifth of the whole mask pass (0.6 of 3.0 ms, tools/r5_one_frame_trace.sh).  Here: four kernels.
+
+// SSD box decoding with variances (0.1, 0.2), layers/box_utils.py decode as detect_batch evaluates it, operation by operation in float32:
+//   centre = prior_xy + (loc_xy * 0.1) * prior_wh;  size = prior_wh * exp(loc_wh * 0.2);  x1y1 = centre - size / 2;  x2y2 = x1y1 + size.
+// grid = ceil(B * P / 256), block = 256.
+__global__ __launch_bounds__(256) void k_decode_boxes(const float4 *__restrict__ loc, const float4 *__restrict__ priors, float4 *__restrict__ boxes, int P, int total)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const float4 l = loc[e], p = priors[e % P];
+    const float cx = __fadd_rn(p.x, __fmul_rn(__fmul_rn(l.x, 0.1f), p.z)), cy = __fadd_rn(p.y, __fmul_rn(__fmul_rn(l.y, 0.1f), p.w));
+    const float sw = __fmul_rn(p.z, expf(__fmul_rn(l.z, 0.2f))), sh = __fmul_rn(p.w, expf(__fmul_rn(l.w, 0.2f)));
+    const float x1 = __fsub_rn(cx, __fmul_rn(sw, 0.5f)), y1 = __fsub_rn(cy, __fmul_rn(sh, 0.5f));
+    boxes[e] = make_float4(x1, y1, __fadd_rn(x1, sw), __fadd_rn(y1, sh));
+}
+
+// Fast NMS on one class list (k score-sorted candidates, given as prior indices): k_nms_column_max's suppression term on boxes gathered
+// here, then detect_batch's `alive = (term <= thresh) & (score > 0)`; out = alive ? score : -1.  grid = B * C lists, block = 256 (k <= 256).
+__global__ __launch_bounds__(256) void k_nms_alive(const float4 *__restrict__ boxes, const long long *__restrict__ idx, const float *__restrict__ scores,
+                                                  float *__restrict__ out, int k, int P, int C, float thresh)
+{
+    __shared__ float4 sb[256];
+    __shared__ float sarea[256];
+    const int j = threadIdx.x, list = blockIdx.x, b = list / C;
+    float4 me = {0.f, 0.f, 0.f, 0.f};
+    float myArea = 0.f;
+    if (j < k) {
+        me = boxes[(size_t)b * P + (size_t)idx[(size_t)list * k + j]];
+        myArea = __fmul_rn(__fsub_rn(me.z, me.x), __fsub_rn(me.w, me.y));
+        sb[j] = me;
+        sarea[j] = myArea;
+    }
+    __syncthreads();
+    if (j >= k) return;
+    float best = 0.f;
+    bool nan = false;
+    for (int i = 0; i < j; i++) {
+        const float4 o = sb[i];
+        float w = __fsub_rn(fminf(o.z, me.z), fmaxf(o.x, me.x)), h = __fsub_rn(fminf(o.w, me.w), fmaxf(o.y, me.y));
+        w = w < 0.f ? 0.f : w;
+        h = h < 0.f ? 0.f : h;
+        const float inter = __fmul_rn(w, h);
+        const float uni = __fsub_rn(__fadd_rn(sarea[i], myArea), inter);
+        const float iou = (float)((double)inter / (double)uni);
+        nan = nan || iou != iou;
+        best = iou > best ? iou : best;
+    }
+    const float sc = scores[(size_t)list * k + j];
+    out[(size_t)list * k + j] = (!nan && best <= thresh && sc > 0.f) ? sc : -1.f;  // (a NaN term compares false in torch too)
+}
+
+// The detections the reference displays: the nDisplay best of a frame's C * k surviving scores (detect_batch's best 100 followed by
+// person_mask_batch's best 15 of those: the same set; order: score descending, equal scores lowest flat index first, as k_topk_rows
+// orders them) that exceed the score threshold.  For each: its class (flat index / k), its box as the crop rectangle of box_utils.crop
+// on the prototype grid (`_sanitize`: scale, order, pad by 1, clamp), its 32 mask coefficients, and the flag "valid and a person".
+// found[b] = some score exceeds the threshold.  grid = B, block = 256.
+__global__ __launch_bounds__(256) void k_select_display(const float *__restrict__ alive, const long long *__restrict__ idx, const float4 *__restrict__ boxes,
+                                                       const float *__restrict__ coef, float *__restrict__ selCoef, float4 *__restrict__ selRect,
+                                                       uint8_t *__restrict__ flags, uint8_t *__restrict__ found, int n, int k, int P, int D, int nDisplay,
+                                                       float scoreThresh, int personClass, int pw, int ph)
+{
+    // Only scores above the threshold can be displayed: they are first compacted into a list of (score key, ~flat index) in LDS (a frame
+    // has a few hundred at most: Fast NMS has already thinned 80 x 200 candidates), and the nDisplay rounds of "largest key below the last
+    // one" run over that list.  A frame with more than kSelectList of them (never seen; possible in principle) selects over the whole row.
+    constexpr int kSelectList = 4096;
+    __shared__ unsigned long long list[kSelectList];
+    __shared__ unsigned long long sWave[4], sSel[32];
+    __shared__ unsigned sCount;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
+    const float *row = alive + (size_t)b * n;
+    if (t == 0) sCount = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 256) {
+        const float v = row[i];
+        if (v > scoreThresh) {
+            const unsigned slot = atomicAdd(&sCount, 1u);
+            if (slot < (unsigned)kSelectList) list[slot] = ((unsigned long long)topk_key(v) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    const unsigned count = sCount;
+    const bool listed = count <= (unsigned)kSelectList;
+    unsigned long long prev = ~0ull;
+    for (int r = 0; r < nDisplay; r++) {
+        unsigned long long best = 0ull;
+        if (listed) {
+            for (unsigned i = t; i < count; i += 256) {
+                const unsigned long long key = list[i];
+                best = (key < prev && key > best) ? key : best;
+            }
+        } else {
+            for (int i = t; i < n; i += 256) {
+                const float v = row[i];
+                const unsigned long long key = v > scoreThresh ? (((unsigned long long)topk_key(v) << 32) | (unsigned)(0xffffffffu - (unsigned)i)) : 0ull;
+                best = (key < prev && key > best) ? key : best;
+            }
+        }
+        for (int d = 32; d > 0; d >>= 1) {
+            const unsigned long long o = __shfl_xor(best, d, 64);
+            best = o > best ? o : best;
+        }
+        if (lane == 0) sWave[wave] = best;
+        __syncthreads();
+        unsigned long long m = sWave[0];
+        for (int w = 1; w < 4; w++) m = sWave[w] > m ? sWave[w] : m;
+        if (t == 0) sSel[r] = m;
+        prev = m ? m : 1ull;  // (nothing left: every later round finds nothing either)
+        __syncthreads();
+    }
+    if (t < nDisplay) {
+        const unsigned long long key = sSel[t];
+        const float score = topk_value((unsigned)(key >> 32));
+        const int flat = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+        const bool valid = key != 0ull && score > scoreThresh;
+        const int cls = valid ? flat / k : 0;
+        const long long prior = valid ? idx[(size_t)b * n + flat] : 0;
+        const float4 bx = boxes[(size_t)b * P + (size_t)prior];
+        // _sanitize(x1, x2, pw, padding = 1): a = x1 * size, b = x2 * size; clamp(min(a, b) - 1, min = 0), clamp(max(a, b) + 1, max = size)
+        const float ax = __fmul_rn(bx.x, (float)pw), bxx = __fmul_rn(bx.z, (float)pw), ay = __fmul_rn(bx.y, (float)ph), by = __fmul_rn(bx.w, (float)ph);
+        float4 rc;
+        rc.x = fmaxf(__fsub_rn(fminf(ax, bxx), 1.f), 0.f);
+        rc.y = fminf(__fadd_rn(fmaxf(ax, bxx), 1.f), (float)pw);
+        rc.z = fmaxf(__fsub_rn(fminf(ay, by), 1.f), 0.f);
+        rc.w = fminf(__fadd_rn(fmaxf(ay, by), 1.f), (float)ph);
+        selRect[(size_t)b * nDisplay + t] = rc;  // (x1, x2, y1, y2)
+        flags[(size_t)b * nDisplay + t] = (valid && cls == personClass) ? 1 : 0;
+        if (t == 0) found[b] = valid ? 1 : 0;
+        sSel[t] = (unsigned long long)prior;  // for the coefficient copy below
+    }
+    __syncthreads();
+    for (int e = t; e < nDisplay * D; e += 256) {
+        const int r = e / D, c = e - r * D;
+        selCoef[((size_t)b * nDisplay + r) * D + c] = coef[((size_t)b * P + (size_t)sSel[r]) * D + c];
+    }
+}
+
+// masks[b][n][y][x] = inside(rect n) ? sigmoid(proto[b][y][x][:] . coef[b][n][:]) : 0 for the flagged detections (k_person_mask reads no
+// other): postprocess's `sigmoid(proto @ coef^T)` + crop.  Sum in channel order with fused multiply-adds (the BLAS kernel PyTorch calls
+// for the einsum fuses too, in an order of its own: the two agree to float32 rounding of a 32-term sum); sigmoid as PyTorch's
+// 1 / (1 + exp(-x)) in float32.  grid = (ceil(ph * pw / 256), nDisplay, B), block = 256.
+__global__ __launch_bounds__(256) void k_assemble_masks(const float *__restrict__ proto, const float *__restrict__ selCoef, const float4 *__restrict__ selRect,
+                                                       const uint8_t *__restrict__ flags, float *__restrict__ masks, int ph, int pw, int D, int nDisplay)
+{
+    const int n = blockIdx.y, b = blockIdx.z, pix = blockIdx.x * 256 + threadIdx.x;
+    if (!flags[(size_t)b * nDisplay + n] || pix >= ph * pw) return;  // (the flag is uniform over the work-group)
+    const int y = pix / pw, x = pix - y * pw;
+    const float4 rc = selRect[(size_t)b * nDisplay + n];
+    float v = 0.f;
+    if ((float)x >= rc.x && (float)x < rc.y && (float)y >= rc.z && (float)y < rc.w) {
+        const float4 *pp = reinterpret_cast<const float4 *>(proto + ((size_t)b * ph * pw + pix) * D);
+        const float4 *cc = reinterpret_cast<const float4 *>(selCoef + ((size_t)b * nDisplay + n) * D);
+        float acc = 0.f;
+        for (int q = 0; q < D / 4; q++) {
+            const float4 a = pp[q], c = cc[q];
+            acc = __fmaf_rn(a.x, c.x, acc); acc = __fmaf_rn(a.y, c.y, acc); acc = __fmaf_rn(a.z, c.z, acc); acc = __fmaf_rn(a.w, c.w, acc);
+        }
+        v = 1.f / (1.f + expf(-acc));
+    }
+    masks[((size_t)b * nDisplay + n) * ph * pw + pix] = v;
+}
+
 }  // namespace amos
 
 using namespace amos;
@@ -349,6 +535,73 @@ int amos_mask_topk_rows_device(void *stream, const float *d_x, float *d_values, 
     hipLaunchKernelGGL(k_topk_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, d_x, d_values, d_indices, n, k);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
+}
+
+
+// ---- the whole post-processing chain as one call (seven launches on `stream`)
+namespace {
+struct PostLayout {
+    size_t boxes, cls, topv, topi, alive, selCoef, selRect, flags, masks, total;
+};
+inline size_t post_align(size_t v) { return (v + 255) & ~(size_t)255; }
+PostLayout post_layout(int B, int P, int C1, int D, int ph, int pw)
+{
+    const size_t C = (size_t)C1 - 1, k = AMOS_MASK_NMS_TOP_K, nd = AMOS_MASK_TOP_K_DISPLAY;
+    PostLayout l;
+    size_t o = 0;
+    l.boxes = o; o += post_align((size_t)B * P * 16);
+    l.cls = o; o += post_align((size_t)B * C * P * 4);
+    l.topv = o; o += post_align((size_t)B * C * k * 4);
+    l.topi = o; o += post_align((size_t)B * C * k * 8);
+    l.alive = o; o += post_align((size_t)B * C * k * 4);
+    l.selCoef = o; o += post_align((size_t)B * nd * D * 4);
+    l.selRect = o; o += post_align((size_t)B * nd * 16);
+    l.flags = o; o += post_align((size_t)B * nd);
+    l.masks = o; o += post_align((size_t)B * nd * ph * pw * 4);
+    l.total = o;
+    return l;
+}
+}  // namespace
+
+size_t amos_mask_post_workspace_bytes(int batch, int n_priors, int n_classes_with_background, int mask_dim, int proto_h, int proto_w)
+{
+    if (batch < 1 || n_priors < AMOS_MASK_NMS_TOP_K || n_classes_with_background < 2 || mask_dim < 4 || proto_h < 1 || proto_w < 1) return 0;
+    return post_layout(batch, n_priors, n_classes_with_background, mask_dim, proto_h, proto_w).total;
+}
+
+int amos_mask_person_masks_device(void *stream, const float *d_loc, const float *d_conf, const float *d_coef, const float *d_priors, const float *d_proto,
+                                  int batch, int n_priors, int n_classes_with_background, int mask_dim, int proto_h, int proto_w, int out_h, int out_w,
+                                  void *d_workspace, size_t workspace_bytes, uint8_t *d_masks, uint8_t *d_found)
+{
+    const int B = batch, P = n_priors, C1 = n_classes_with_background, C = C1 - 1, D = mask_dim, k = AMOS_MASK_NMS_TOP_K, nd = AMOS_MASK_TOP_K_DISPLAY;
+    if (!d_loc || !d_conf || !d_coef || !d_priors || !d_proto || !d_workspace || !d_masks || !d_found || B < 1 || B > 65535 || P < k || C1 < 2 || C1 > 200 ||
+        D < 4 || D % 4 != 0 || proto_h < 1 || proto_w < 1 || out_h < 1 || out_w < 1 || (size_t)C * k * 4 > 64 * 1024 ||
+        ((uintptr_t)d_loc | (uintptr_t)d_priors | (uintptr_t)d_proto | (uintptr_t)d_coef | (uintptr_t)d_workspace) % 16 != 0) {
+        set_error("amos_mask_person_masks_device: invalid argument (16-byte aligned tensors, mask_dim %% 4 == 0, at most %d class lists of %d)", 16384 / k, k);
+        return AMOS_ERR_INVALID;
+    }
+    const PostLayout l = post_layout(B, P, C1, D, proto_h, proto_w);
+    if (workspace_bytes < l.total) { set_error("amos_mask_person_masks_device: workspace of %zu bytes, %zu needed", workspace_bytes, l.total); return AMOS_ERR_CAPACITY; }
+    uint8_t *ws = (uint8_t *)d_workspace;
+    float4 *boxes = (float4 *)(ws + l.boxes);
+    float *cls = (float *)(ws + l.cls), *topv = (float *)(ws + l.topv), *alive = (float *)(ws + l.alive), *selCoef = (float *)(ws + l.selCoef);
+    long long *topi = (long long *)(ws + l.topi);
+    float4 *selRect = (float4 *)(ws + l.selRect);
+    uint8_t *flags = ws + l.flags;
+    float *masks = (float *)(ws + l.masks);
+    hipStream_t st = (hipStream_t)stream;
+    const int total = B * P;
+    hipLaunchKernelGGL(k_decode_boxes, dim3((total + 255) / 256), dim3(256), 0, st, (const float4 *)d_loc, (const float4 *)d_priors, boxes, P, total);
+    int rc = amos_mask_class_scores_device(stream, d_conf, cls, B, P, C1, AMOS_MASK_CONF_THRESH);
+    if (rc != AMOS_OK) return rc;
+    rc = amos_mask_topk_rows_device(stream, cls, topv, topi, B * C, P, k);
+    if (rc != AMOS_OK) return rc;
+    hipLaunchKernelGGL(k_nms_alive, dim3(B * C), dim3(256), 0, st, boxes, topi, topv, alive, k, P, C, AMOS_MASK_NMS_THRESH);
+    hipLaunchKernelGGL(k_select_display, dim3(B), dim3(256), 0, st, alive, topi, boxes, d_coef, selCoef, selRect, flags, d_found, C * k, k,
+                       P, D, nd, AMOS_MASK_SCORE_THRESHOLD, AMOS_MASK_PERSON_CLASS, proto_w, proto_h);
+    hipLaunchKernelGGL(k_assemble_masks, dim3((proto_h * proto_w + 255) / 256, nd, B), dim3(256), 0, st, d_proto, selCoef, selRect, flags, masks, proto_h, proto_w, D, nd);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return amos_mask_person_mask_device(stream, masks, flags, d_masks, B, nd, proto_h, proto_w, out_h, out_w);
 }
 
 }  // extern "C"

@@ -10,7 +10,7 @@ import torch
 
 from .detect import detect, detect_batch
 from .net import YolactR50
-from .post import person_mask, person_mask_batch
+from .post import person_mask, person_mask_batch, person_masks_fused
 from .pre import cxx_marshalling, fast_base_transform, resize_f32_cv
 
 
@@ -114,6 +114,12 @@ class MaskEngine:
         frame = torch.as_tensor(bgr_u8, dtype=torch.uint8, device=self.device)
         return self.eval_chw(cxx_marshalling(frame))
 
+    @staticmethod
+    def _person_masks(pred, width, height):
+        """(masks uint8 [B, height, width], found bool [B]) of a forward's outputs: the fused library call on the GPU, the torch ops elsewhere"""
+        fused = person_masks_fused(pred, width, height)
+        return fused if fused is not None else person_mask_batch(detect_batch(pred), width, height)
+
     @torch.no_grad()
     def eval_net_input_batch(self, x, chunk=16, height=480, width=640):
         """x: [B, 3, 550, 550] float32 network input already on the engine's device (amos_orb_detect_color_with_mask_pre_batch_device
@@ -122,7 +128,7 @@ class MaskEngine:
         out = torch.zeros((B, height, width), dtype=torch.uint8, device=self.device)
         for b0 in range(0, B, chunk):
             pred = self._forward(x[b0:b0 + chunk])
-            masks, _found = person_mask_batch(detect_batch(pred), width, height)
+            masks, _found = self._person_masks(pred, width, height)
             out[b0:b0 + masks.shape[0]] = masks
         return out
 
@@ -138,7 +144,7 @@ class MaskEngine:
         self._g_in = torch.zeros((batch, 3, 550, 550), dtype=torch.float32, device=self.device)
 
         def body():
-            return person_mask_batch(detect_batch(self._forward(self._g_in)), 640, 480)
+            return self._person_masks(self._forward(self._g_in), 640, 480)
 
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -198,7 +204,7 @@ class MaskEngine:
                 imgs = resize_f32_cv(chw.permute(0, 2, 3, 1) * 255, 640, 480)    # [b, 480, 640, 3]
                 x = fast_base_transform(imgs)
             pred = self._forward(x)
-            masks, _found = person_mask_batch(detect_batch(pred), 640, 480)      # eval_image resizes to 640 x 480 whatever came in
+            masks, _found = self._person_masks(pred, 640, 480)                  # eval_image resizes to 640 x 480 whatever came in
             out[b0:b0 + part.shape[0]] = masks
         return out
 
@@ -228,7 +234,7 @@ class FrameSession:
 
         def body():
             self._pre.run(self._d_frame.data_ptr(), 1, self._net_in.data_ptr())
-            return person_mask_batch(detect_batch(engine._forward(self._net_in)), 640, 480)
+            return engine._person_masks(engine._forward(self._net_in), 640, 480)
 
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.stream):

@@ -454,6 +454,26 @@ int amos_mask_head_outputs_device(void *stream, const float *d_raw, const float 
  * values the lower index comes first (torch leaves that order unspecified).  1 <= k <= min(256, n). */
 int amos_mask_topk_rows_device(void *stream, const float *d_x, float *d_values, long long *d_indices, int rows, int n, int k);
 
+/* ---- the post-processing of the mask pass as ONE call: Detect (box decoding, per-class top 200, Fast NMS at IoU 0.5, class-confidence
+ * threshold 0.05; layers/functions/detection.py:27-170, layers/box_utils.py:268-312) + postprocess / prep_display (score threshold 0.15, the
+ * 15 best detections, masks = sigmoid(proto . coefficients) cropped to the box with 1 px padding, bilinear to the frame, > 0.5, the persons
+ * summed, x 255 modulo 256; yolact_interface.py:678-779, 806-832) in the static-shape form of mask/detect.py detect_batch and mask/post.py
+ * person_mask_batch.  Inputs (float32, device): loc [batch][P][4], conf [batch][P][classes incl. background] (softmax output), coef
+ * [batch][P][mask_dim], priors [P][4], proto [batch][proto_h][proto_w][mask_dim].  Outputs: masks uint8 [batch][out_h][out_w], found uint8
+ * [batch] (0: no detection above the score threshold -- the reference raises there and its caller keeps an all-zero mask).
+ * d_workspace: amos_mask_post_workspace_bytes(...) bytes of device scratch (16-byte aligned).  Seven launches on `stream`. */
+#define AMOS_MASK_NMS_TOP_K 200
+#define AMOS_MASK_NMS_THRESH 0.5f
+#define AMOS_MASK_CONF_THRESH 0.05f
+#define AMOS_MASK_SCORE_THRESHOLD 0.15f
+#define AMOS_MASK_TOP_K_DISPLAY 15
+#define AMOS_MASK_PERSON_CLASS 0
+size_t amos_mask_post_workspace_bytes(int batch, int n_priors, int n_classes_with_background, int mask_dim, int proto_h, int proto_w);
+int amos_mask_person_masks_device(void *stream, const float *d_loc, const float *d_conf, const float *d_coef, const float *d_priors,
+                                  const float *d_proto, int batch, int n_priors, int n_classes_with_background, int mask_dim, int proto_h,
+                                  int proto_w, int out_h, int out_w, void *d_workspace, size_t workspace_bytes, uint8_t *d_masks,
+                                  uint8_t *d_found);
+
 
 /* ---------------------------------------------------------------- SLIC superpixels (8f-2) ---- */
 

@@ -910,6 +910,54 @@ def test_topk_rows_kernel_against_torch_topk(mask, gpu_lib):
 
 
 @pytest.mark.gpu
+def test_fused_post_processing_equals_the_torch_ops_path(mask, gpu_lib, monkeypatch):
+    """amos_mask_person_masks_device (Detect + postprocess + prep_display in seven launches) against the torch-op chain it replaces
+    (detect_batch + person_mask_batch, themselves held to the reference-order path by test_static_shape_batch_post_equals_reference_order_post)
+    on real network outputs -- the golden frames of weight set seed0, plain and mirrored -- and on edited outputs: nothing above the score
+    threshold (found False, zero mask), a class list with equal scores, more displayed candidates than 15.  Same `found`, same detections,
+    masks within a handful of boundary pixels (the 32-term prototype sums are rounded in another order)."""
+    post = importlib.import_module("amos_slam_amd.mask.post")
+    det_mod = importlib.import_module("amos_slam_amd.mask.detect")
+    eng = _engine(mask, "cuda:0", "seed0").prepare()
+    frames = np.stack([mask_cases.frame(c) for c in ("seed0", "ref122_w0", "tum_w0")] * 2)
+    frames[3:] = frames[3:, :, ::-1]
+    x = eng._preprocess_hip(torch.from_numpy(np.ascontiguousarray(frames)).cuda())
+    with torch.no_grad():
+        pred = eng._forward(x)
+
+    def both(p):
+        fused = post.person_masks_fused(p, 640, 480)
+        assert fused is not None
+        want = post.person_mask_batch(det_mod.detect_batch(p), 640, 480)
+        torch.cuda.synchronize()
+        return fused, want
+
+    (m, f), (mw, fw) = both(pred)
+    assert m.shape == mw.shape == (6, 480, 640) and m.dtype == torch.uint8 and torch.equal(f, fw) and bool(f.all())
+    assert int((mw > 0).sum()) > 6 * 5000
+    for k in range(6):
+        assert int((m[k] != mw[k]).sum()) <= 40 and _iou((m[k] > 0).cpu().numpy(), (mw[k] > 0).cpu().numpy()) >= 1 - 1e-3, k
+    # a batch whose class scores are all below the threshold
+    quiet = dict(pred)
+    quiet["conf"] = torch.zeros_like(pred["conf"])
+    quiet["conf"][..., 0] = 1.0
+    (m, f), (mw, fw) = both(quiet)
+    assert not bool(f.any()) and not bool(fw.any()) and int(m.sum()) == 0 and int(mw.sum()) == 0
+    # equal scores inside a class list and 40 strong person candidates on a grid (more than the 15 displayed): same selection both ways
+    tied = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in pred.items()}
+    tied["conf"].zero_()
+    tied["conf"][..., 0] = 1.0
+    pick = torch.arange(40, device="cuda") * 431 + 7
+    tied["conf"][:, pick, 1] = 0.9
+    tied["conf"][:, pick, 0] = 0.1
+    tied["conf"][:, pick[:20], 1] = torch.linspace(0.99, 0.91, 20, device="cuda")   # twenty distinct leaders (the displayed 15 among them), then 20 tied at 0.9
+    (m, f), (mw, fw) = both(tied)                                                    # (torch.topk leaves the order of EQUAL scores open: the ties sit behind the displayed ones)
+    assert bool(f.all()) and torch.equal(f, fw)
+    for k in range(6):
+        assert _iou((m[k] > 0).cpu().numpy(), (mw[k] > 0).cpu().numpy()) >= 1 - 1e-3, k
+
+
+@pytest.mark.gpu
 def test_mask_pass_as_one_hip_graph_equals_the_eager_pass(mask, gpu_lib):
     """MaskEngine.capture_graph / eval_bgr_graph: network + detection + mask assembly of a fixed batch replayed as one HIP graph give the
     masks of the eager pass on different frames (two replays), and refuse another batch size."""
