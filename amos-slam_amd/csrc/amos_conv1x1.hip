@@ -21,6 +21,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "../../include/amos_frontend.h"
 #include "amos_common.h"
 
@@ -40,6 +42,12 @@ struct ConvGemmArgs {
     int outW, outHW, inW, inH;   // row(m): b = m / outHW, (oy, ox) of the rest; tap (dy, dx) reads input pixel (oy * stride - pad + dy, ox * stride - pad + dx)
     int stride, relu, mTiles, nTiles;
     int kh, kw, pad;             // kTaps == false: 1, 1, 0
+    // split-K (small launches: one frame per pass): blockIdx.y = split, each split runs stagesPerSplit stages of the k loop and leaves its
+    // tile in `partial`; the LAST work-group to arrive at a tile (tile counter) adds the splits' tiles in split order -- the same bits
+    // whichever group that is -- and runs the epilogue.  splits == 1: none of this.
+    int splits, stagesPerSplit;
+    float *partial;              // [splits][mTiles * nTiles][BM * BN]
+    unsigned *counters;          // [mTiles * nTiles], zero before the launch and after it
 };
 
 // kTaps: a kh x kw convolution as an implicit GEMM.  The weight is [cout][kh][kw][cin] (a channels-last Conv2d weight), so the W tile
@@ -56,8 +64,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     float(*Xs)[kStage] = reinterpret_cast<float(*)[kStage]>(smem);
     float(*Ws)[kStage] = reinterpret_cast<float(*)[kStage]>(smem + BM * kGemmPitch);
     // id -> (m tile, n tile): ids are dealt round-robin over the 8 XCDs; within an XCD consecutive work-groups walk the n tiles of one m tile
+    // (split-K launches are small: there blockIdx.x IS the tile, so that consecutive tiles go to consecutive XCDs -- three m tiles would
+    // otherwise put all work on three of the eight -- and the splits of a tile, blockIdx.y, still share one)
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-    const int nt = seq % a.nTiles, mt = (seq / a.nTiles) * 8 + xcd;
+    const int nt = a.splits > 1 ? (int)blockIdx.x % a.nTiles : seq % a.nTiles;
+    const int mt = a.splits > 1 ? (int)blockIdx.x / a.nTiles : (seq / a.nTiles) * 8 + xcd;
     if (mt >= a.mTiles) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -87,7 +98,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     // kTaps: the tap / channel-block of the NEXT fetch, advanced after every fetch (stages are fetched in order); a row whose tap falls
     // outside the image reads 16 bytes of zeros instead (a select on the ADDRESS: the load itself stays unconditional, so the stage
     // remains one scheduling region)
+    const int stagesAll = (a.K / kGemmBK) * a.kh * a.kw;
+    const int sBegin = a.splits > 1 ? (int)blockIdx.y * a.stagesPerSplit : 0;
+    const int sEnd = a.splits > 1 ? min(sBegin + a.stagesPerSplit, stagesAll) : stagesAll;
     int fKc = 0, fDy = 0, fDx = 0;
+    if (kTaps && sBegin > 0) {  // the tap / channel block of this split's first stage
+        const int kcPerTap0 = a.K / kGemmBK, tap = sBegin / kcPerTap0;
+        fKc = sBegin - tap * kcPerTap0;
+        fDy = tap / a.kw;
+        fDx = tap - fDy * a.kw;
+    }
     // (the select is made on integers and the result read through a global-address-space pointer: a select of two C++ pointers of
     // different provenance becomes a FLAT load, which also counts as an LDS operation and would be waited for at the barrier)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -201,25 +221,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     const int xoff = (wm * 32 * TI + (lane & 31)) * kGemmPitch + 4 * (lane >> 5);
     const int woff = (wn * 64 + (lane & 31)) * kGemmPitch + 4 * (lane >> 5);
-    const int stages = kcPerTap * a.kh * a.kw;
-    AMOS_GEMM_FETCH(0);
+    // stages [sBegin, sEnd) of the k loop (all of them without split-K); `s` counts from 0 for the buffer parity, the fetches name the
+    // absolute stage
+    const int stages = sEnd - sBegin;
+    AMOS_GEMM_FETCH(sBegin);
     AMOS_GEMM_STASH(0);
-    if (stages > 1) AMOS_GEMM_FETCH(1);
+    if (stages > 1) AMOS_GEMM_FETCH(sBegin + 1);
     __syncthreads();
     AMOS_GEMM_LDFRAG(fa0, fb0, 0, 0);
     int s = 0;
     for (; s + 2 < stages; s++) {
         const int buf = s & 1;
-        AMOS_GEMM_STAGE(s, buf, true, true, true);
+        AMOS_GEMM_STAGE(sBegin + s, buf, true, true, true);
     }
     if (s + 1 < stages) {  // the last but one: nothing left to request
         const int buf = s & 1;
-        AMOS_GEMM_STAGE(s, buf, true, false, true);
+        AMOS_GEMM_STAGE(sBegin + s, buf, true, false, true);
         s++;
     }
     {
         const int buf = s & 1;
-        AMOS_GEMM_STAGE(s, buf, false, false, false);
+        AMOS_GEMM_STAGE(sBegin + s, buf, false, false, false);
     }
 #undef AMOS_GEMM_FETCH
 #undef AMOS_GEMM_TAPSRC
@@ -243,6 +265,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     constexpr int kCols = BN / 4, kRowsPerPass = 256 / kCols, kPasses = BM / kRowsPerPass;  // float4 columns; rows per sweep of the group
     const int oc = t % kCols, orow = t / kCols;
     const int n0 = nt * BN + 4 * oc;
+    if (a.splits > 1) {
+        // this split's tile -> partial[split][tile] (tile-contiguous: every store instruction writes whole lines); the last group to arrive
+        // sums the splits in order into the LDS tile and falls through to the ordinary epilogue.
+        // Visibility.  The 8 XCDs of the chip have an L2 each, so a device-wide release / acquire pair (__threadfence) writes an L2 back and
+        // invalidates one: ~50 us per launch, measured -- more than the launches this path serves.  All splits of a tile share blockIdx.x,
+        // and work-groups are dealt to XCDs by linear id modulo 8 (gridDim.x is a multiple of 8), so they run on ONE XCD and meet in ITS
+        // L2: stores are write-through to it (complete at vmcnt(0)) and the reader's loads miss its L1.  That the
+        // dealing really is what this assumes is CHECKED by every group (the XCC_ID hardware register against blockIdx.x % 8); a group that
+        // finds itself elsewhere falls back to the device-wide fences and says so in the tile counter, and the reader then does too.
+        __shared__ unsigned sArrived;
+        const int tile = mt * a.nTiles + nt, nTilesAll = a.mTiles * a.nTiles;
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;  // HW_REG_XCC_ID[3:0]
+        const bool home = xcc == (blockIdx.x & 7u);
+        float *mine = a.partial + ((size_t)blockIdx.y * nTilesAll + tile) * (BM * BN);
+#pragma unroll
+        for (int q = 0; q < kPasses; q++) {
+            const int e = (q * kRowsPerPass + orow) * BN + 4 * oc;
+            *reinterpret_cast<float4 *>(mine + e) = *reinterpret_cast<const float4 *>(&smem[e]);
+        }
+        if (home) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile is in this XCD's L2
+        else __threadfence();                                        // ... or written back for everybody
+        __syncthreads();
+        if (t == 0) sArrived = atomicAdd(&a.counters[tile], home ? 1u : 0x10001u);  // low half: arrivals; high half: groups away from home
+        __syncthreads();
+        const unsigned arrived = sArrived;
+        if ((arrived & 0xffffu) != (unsigned)(a.splits - 1)) return;
+        if (!home || (arrived >> 16) != 0) __threadfence();
+#pragma unroll
+        for (int q = 0; q < kPasses; q++) {
+            const int e = (q * kRowsPerPass + orow) * BN + 4 * oc;
+            float4 sum = {0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < a.splits; sp++) {
+                // (plain loads: this CU's L1 was invalidated when the kernel started and has never held these lines since -- nobody reads a
+                // partial tile but its last group -- so they come from the L2 the splits wrote to; an agent-scope load would go PAST that L2)
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+                const f32x4v v = *reinterpret_cast<const volatile f32x4v *>(a.partial + ((size_t)sp * nTilesAll + tile) * (BM * BN) + e);
+                sum.x = sp ? sum.x + v.x : v.x; sum.y = sp ? sum.y + v.y : v.y; sum.z = sp ? sum.z + v.z : v.z; sum.w = sp ? sum.w + v.w : v.w;
+            }
+            *reinterpret_cast<float4 *>(&smem[e]) = sum;  // (each thread rewrites exactly the pieces it reads below)
+        }
+        if (t == 0) atomicExch(&a.counters[tile], 0u);  // for the next launch
+    }
     const float4 bv = a.bias ? *reinterpret_cast<const float4 *>(a.bias + n0) : float4{0.f, 0.f, 0.f, 0.f};
     constexpr int kBatch = 8;  // residual loads in flight per thread
 #pragma unroll
@@ -321,8 +385,41 @@ int amos_mask_conv_supported(int cin, int cout, int kh, int kw, int stride, int 
             pad >= 0 && pad < kh && pad < kw) ? AMOS_OK : AMOS_ERR_INVALID;
 }
 
+// Split-K plan of a launch: small launches (one frame per pass: 3 - 150 work-groups on 256 CUs, up to 72 stages each) are cut along k so
+// that about a chip's worth of work-groups runs, every split keeping at least four stages.  1 = no split.
+static const int kSplitCounterBytes = 16384;  // 4 096 tile counters at the head of the workspace
+static int gemm_splits(long long M, int cout, int stages, bool wide)
+{
+    static const int minTiles = getenv("AMOS_GEMM_SPLIT_BELOW") ? atoi(getenv("AMOS_GEMM_SPLIT_BELOW")) : 192;   // experiment knobs
+    static const int target = getenv("AMOS_GEMM_SPLIT_TARGET") ? atoi(getenv("AMOS_GEMM_SPLIT_TARGET")) : 256;
+    const long long tiles = ((M + 127) / 128) * (cout / (wide ? 128 : 64));
+    if (tiles >= minTiles || stages < 8 || tiles > kSplitCounterBytes / 4) return 1;
+    long long s = (target + tiles - 1) / tiles;
+    s = std::min<long long>(s, stages / 4);
+    s = std::min<long long>(s, 16);
+    return (int)std::max<long long>(s, 1);
+}
+
+size_t amos_mask_conv_workspace_bytes(int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride, int pad)
+{
+    if (batch < 1 || in_h < 1 || in_w < 1 || amos_mask_conv_supported(cin, cout, kh, kw, stride, pad) != AMOS_OK || in_h + 2 * pad < kh || in_w + 2 * pad < kw) return 0;
+    const int oh = (in_h + 2 * pad - kh) / stride + 1, ow = (in_w + 2 * pad - kw) / stride + 1;
+    const long long M = (long long)batch * oh * ow;
+    const bool wide = gemm_wide_tiles(M, cout);
+    const int stages = (cin / kGemmBK) * kh * kw, splits = gemm_splits(M, cout, stages, wide);
+    if (splits <= 1) return 0;
+    const long long tiles = ((M + 127) / 128) * (cout / (wide ? 128 : 64));
+    return (size_t)kSplitCounterBytes + (size_t)splits * tiles * 128 * (wide ? 128 : 64) * sizeof(float);
+}
+
 int amos_mask_conv_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual, float *d_y, int batch,
                           int in_h, int in_w, int cin, int cout, int kh, int kw, int stride, int pad, int relu)
+{
+    return amos_mask_conv_ws_device(stream, d_x, d_w, d_bias, d_residual, d_y, batch, in_h, in_w, cin, cout, kh, kw, stride, pad, relu, nullptr, 0);
+}
+
+int amos_mask_conv_ws_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual, float *d_y, int batch,
+                             int in_h, int in_w, int cin, int cout, int kh, int kw, int stride, int pad, int relu, void *d_workspace, size_t workspace_bytes)
 {
     if (!d_x || !d_w || !d_y || batch < 1 || in_h < 1 || in_w < 1 || amos_mask_conv_supported(cin, cout, kh, kw, stride, pad) != AMOS_OK ||
         in_h + 2 * pad < kh || in_w + 2 * pad < kw || ((uintptr_t)d_x | (uintptr_t)d_w | (uintptr_t)d_y | (uintptr_t)d_bias | (uintptr_t)d_residual) % 16 != 0) {
@@ -341,7 +438,22 @@ int amos_mask_conv_device(void *stream, const float *d_x, const float *d_w, cons
     const int BM = 128, BN = wide ? 128 : 64;
     a.mTiles = (int)((M + BM - 1) / BM);
     a.nTiles = cout / BN;
-    const dim3 grid((unsigned)(((a.mTiles + 7) / 8) * 8 * a.nTiles)), block(256);
+    a.splits = 1;
+    a.stagesPerSplit = 0;
+    a.partial = nullptr;
+    a.counters = nullptr;
+    if (d_workspace) {  // split-K when the plan for this shape says so and the caller brought the scratch for it
+        const int stages = (cin / kGemmBK) * kh * kw, splits = gemm_splits(M, cout, stages, wide);
+        const size_t need = (size_t)kSplitCounterBytes + (size_t)splits * a.mTiles * a.nTiles * BM * BN * sizeof(float);
+        if (splits > 1) {
+            if (workspace_bytes < need || (uintptr_t)d_workspace % 16 != 0) { set_error("amos_mask_conv_ws_device: workspace of %zu bytes, %zu needed (16-byte aligned)", workspace_bytes, need); return AMOS_ERR_CAPACITY; }
+            a.stagesPerSplit = (stages + splits - 1) / splits;
+            a.splits = (stages + a.stagesPerSplit - 1) / a.stagesPerSplit;  // no empty split
+            a.counters = (unsigned *)d_workspace;
+            a.partial = (float *)((uint8_t *)d_workspace + kSplitCounterBytes);
+        }
+    }
+    const dim3 grid(a.splits > 1 ? (unsigned)((a.mTiles * a.nTiles + 7) / 8 * 8) : (unsigned)(((a.mTiles + 7) / 8) * 8 * a.nTiles), (unsigned)a.splits), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (wide && taps) hipLaunchKernelGGL((k_conv_gemm<2, 2, 2, true>), grid, block, 0, st, a);
     else if (wide) hipLaunchKernelGGL((k_conv_gemm<2, 2, 2, false>), grid, block, 0, st, a);

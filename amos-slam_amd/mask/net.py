@@ -48,11 +48,18 @@ def _gemm_conv(conv, x):
             # strided layers (the stride-1 ones belong to the Winograd kernel): the 128 x 64 tiles the library then runs tie with MIOpen + the
             # epilogue pass from 1 024 work-groups on (256 ch, 69 -> 35 at 32 frames: 0.417 against 0.422 ms, tools/conv_gemm_probe.py)
             groups = ((m + 127) // 128) * (conv.out_channels // 64)
-        return mode3 != "0" and (groups >= 1024 or mode3 == "2") and conv.weight.is_contiguous(memory_format=torch.channels_last)
+        # (one frame per pass: the 64-channel 3 x 3 layers at 138 x 138 -- 149 groups of 18 k-stages, too few tiles for the Winograd rule --
+        # run 25.9 us here against 32.1 for the library kernel + the bias pass, tools/r5_small_gemm_probe.py)
+        small = s == 1 and conv.in_channels <= 64 and groups >= 128
+        return mode3 != "0" and (groups >= 1024 or small or mode3 == "2") and conv.weight.is_contiguous(memory_format=torch.channels_last)
     mode = os.environ.get("AMOS_MASK_CONV1X1", "auto")
     if mode in ("0", "1"):
         return mode == "1"
-    return groups >= 600
+    # small launches (one frame per pass; tools/r5_small_gemm_probe.py, 128 x 64 tiles): with at most 512 input channels (16 k-stages) the
+    # GEMM with its fused epilogue beats the library kernel + the bias pass from ~100 work-groups on (64 -> 256 + residual at 138 x 138:
+    # 16.6 against 24.4 us, 256 -> 1024 + residual at 35 x 35: 13.7 / 17.0, 512 -> 256 at 69 x 69: 21.6 / 25.1); deeper k with so few
+    # groups stays with the library (1024 -> 256 at 35 x 35, 40 groups: 35.9 / 19.7 -- and 27 us cut along k, amos_mask_conv_ws_device)
+    return groups >= 600 or (groups >= 100 and conv.in_channels <= 512)
 
 
 def winograd_rule(cin, cout, kernel, stride, padding, dilation, groups, batch, height, width):

@@ -368,6 +368,16 @@ int amos_mask_conv_supported(int cin, int cout, int kh, int kw, int stride, int 
 int amos_mask_conv_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual,
                           float *d_y, int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride, int pad,
                           int relu);
+/* The same convolution with split-K for SMALL launches (one frame per pass: a 1 x 1 layer at 35 x 35 or 18 x 18 is 3 - 40 work-groups of up
+ * to 64 k-stages on 256 CUs): the k loop is cut into splits, one work-group per (tile, split); every split leaves its tile in the workspace
+ * and the last work-group to arrive at a tile adds the splits in split order (the same bits whichever group that is) and applies bias,
+ * residual and ReLU -- one launch, no zero fill, no reduction pass.  amos_mask_conv_workspace_bytes: scratch this shape wants (0: the plan
+ * for it is an ordinary launch; d_workspace may then be NULL).  The first 16 KB of the workspace are tile counters: ZERO before the first
+ * use, left zero by every launch; launches that share a workspace must be ordered on one stream. */
+size_t amos_mask_conv_workspace_bytes(int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride, int pad);
+int amos_mask_conv_ws_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual, float *d_y,
+                             int batch, int in_h, int in_w, int cin, int cout, int kh, int kw, int stride, int pad, int relu,
+                             void *d_workspace, size_t workspace_bytes);
 /* Work-group tile of amos_mask_conv_device: -1 = automatic (128 x 128 outputs unless that leaves fewer than 1 024 work-groups or
  * cout % 128 != 0, then 128 x 64), 0 = 128 x 128 wherever cout allows, 1 = always 128 x 64.  Returns the mode in force before
  * the call; any other argument only queries.  The environment's AMOS_GEMM_NARROW (0 / 1) is the initial mode, read once.

@@ -465,15 +465,19 @@ def test_mfma_conv1x1_against_float64(mask, gpu_lib, monkeypatch):
     bound = 1e-5 * F.conv2d(x.double().abs(), wgt.double().abs(), None, 1, 1) + 1e-6
     assert bool(((y.double() - exact).abs() <= bound).all())
     monkeypatch.delenv("AMOS_MASK_CONV1X1")
-    # the rule of the automatic choice: large launches with <= 512 input channels
+    # the rule of the automatic choice: large launches; one-frame launches of at least ~100 work-groups with <= 512 input channels
     big, small = torch.empty(32, 64, 138, 138, device="meta"), torch.empty(1, 64, 138, 138, device="meta")
     c = torch.nn.Conv2d(64, 256, 1)
-    assert net_mod._gemm_conv(c, big) and not net_mod._gemm_conv(c, small)
+    assert net_mod._gemm_conv(c, big) and net_mod._gemm_conv(c, small)                                            # 149 x 4 groups of 2 k-stages
+    assert net_mod._gemm_conv(torch.nn.Conv2d(256, 1024, 1), torch.empty(1, 256, 35, 35, device="meta"))          # 10 x 16
+    assert not net_mod._gemm_conv(torch.nn.Conv2d(1024, 256, 1), torch.empty(1, 1024, 35, 35, device="meta"))    # 10 x 4 groups of 32 k-stages: the library's
+    assert not net_mod._gemm_conv(torch.nn.Conv2d(512, 2048, 1), torch.empty(1, 512, 18, 18, device="meta"))     # 3 x 32
     assert net_mod._gemm_conv(torch.nn.Conv2d(1024, 256, 1), torch.empty(32, 1024, 35, 35, device="meta"))       # 614 work-groups
     assert net_mod._gemm_conv(torch.nn.Conv2d(2048, 512, 1), torch.empty(32, 2048, 18, 18, device="meta"))       # 324 wide = 648 narrow
     assert not net_mod._gemm_conv(torch.nn.Conv2d(2048, 256, 1), torch.empty(32, 2048, 18, 18, device="meta"))   # 324 narrow
     c3 = torch.nn.Conv2d(64, 64, 3, padding=1).to(memory_format=cl)
-    assert net_mod._gemm_conv(c3, big) and not net_mod._gemm_conv(c3, small)
+    assert net_mod._gemm_conv(c3, big) and net_mod._gemm_conv(c3, small)   # one frame: 149 groups of 18 k-stages beat the library kernel + the bias pass
+    assert not net_mod._gemm_conv(torch.nn.Conv2d(128, 128, 3, padding=1).to(memory_format=cl), torch.empty(1, 128, 69, 69, device="meta"))   # 38 x 2
     assert not net_mod._gemm_conv(torch.nn.Conv2d(256, 243, 3, padding=1).to(memory_format=cl), torch.empty(32, 256, 69, 69, device="meta"))  # 243 channels
     s2 = torch.nn.Conv2d(256, 256, 3, padding=1, stride=2).to(memory_format=cl)
     assert net_mod._gemm_conv(s2, torch.empty(32, 256, 69, 69, device="meta"))          # strided: 307 x 4 work-groups of 128 x 64
@@ -483,6 +487,53 @@ def test_mfma_conv1x1_against_float64(mask, gpu_lib, monkeypatch):
     monkeypatch.delenv("AMOS_MASK_CONV3X3")
     with pytest.raises(RuntimeError):
         gpu_lib.mask_conv1x1(st, 0, 0, None, None, 0, 1, 8, 8, 64, 64, 1, True)
+
+
+@pytest.mark.gpu
+def test_split_k_gemm_small_launches(mask, gpu_lib):
+    """amos_mask_conv_ws_device: the k loop of a small launch cut into splits, the last work-group to arrive at a tile adding the splits in
+    split order and running the fused epilogue (one launch; the splits of a tile meet in one XCD's L2, which every group verifies from its
+    XCC_ID).  One-frame shapes of the network from 3 to 152 tiles, 1 x 1 / 3 x 3 / strided, with and without residual: against a float64
+    convolution to the direct kernel's bound, twenty launches bit-identical (the sum does not depend on which group arrives last), the
+    tile counters left zero, and the same library call without a workspace (no split) within float32 rounding."""
+    F = torch.nn.functional
+    cl = torch.channels_last
+    torch.manual_seed(31)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
+    n_split = 0
+    for ci, co, k, s, H, res in ((2048, 512, 1, 1, 18, 0), (1024, 256, 1, 1, 35, 1), (512, 2048, 1, 1, 18, 1), (256, 256, 3, 1, 35, 0), (256, 256, 3, 2, 18, 0),
+                                 (256, 384, 3, 1, 18, 0), (512, 128, 1, 1, 69, 0), (256, 256, 3, 1, 69, 1), (1024, 2048, 1, 2, 35, 0), (64, 64, 1, 1, 138, 0)):
+        pad = k // 2
+        x = torch.randn(1, ci, H, H, device="cuda").contiguous(memory_format=cl)
+        w = (torch.randn(co, ci, k, k, device="cuda") / (ci * k * k) ** 0.5).contiguous(memory_format=cl)
+        b = torch.randn(co, device="cuda")
+        Ho = (H + 2 * pad - k) // s + 1
+        r = torch.randn(1, co, Ho, Ho, device="cuda").contiguous(memory_format=cl) if res else None
+        need = gpu_lib.mask_conv_workspace_bytes(1, H, H, ci, co, k, k, s, pad)
+        assert need <= ws.numel()
+        n_split += need > 0
+        outs = []
+        for _ in range(20):
+            y = torch.full((1, co, Ho, Ho), float("nan"), device="cuda").contiguous(memory_format=cl)
+            gpu_lib.mask_conv_ws(st, x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(), 1, H, H, ci, co, k, k, s, pad, True,
+                                 ws.data_ptr(), ws.numel())
+            outs.append(y)
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]), (ci, co, k, s, H)
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0, "tile counters must be left zero"
+        want = F.conv2d(x.double(), w.double(), b.double(), s, pad) + (r.double() if res else 0)
+        bound = 1e-5 * (F.conv2d(x.double().abs(), w.double().abs(), None, s, pad) + 1)
+        assert bool(((outs[0].double() - want.relu()).abs() <= bound).all()), (ci, co, k, s, H)
+        plain = torch.empty_like(outs[0])
+        gpu_lib.mask_conv(st, x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, plain.data_ptr(), 1, H, H, ci, co, k, k, s, pad, True)
+        torch.cuda.synchronize()
+        assert float((plain - outs[0]).abs().max()) <= 1e-4 * max(float(plain.abs().max()), 1.0)
+        if need == 0:
+            assert torch.equal(plain, outs[0])   # the plan for this shape is an ordinary launch
+    assert n_split >= 8
+    with pytest.raises(gpu_lib.AmosError):   # a workspace too small for the plan is refused, not overrun
+        gpu_lib.mask_conv_ws(st, x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), 1, 18, 18, 2048, 512, 1, 1, 1, 0, True, ws.data_ptr(), 20000)
 
 
 @pytest.mark.gpu
