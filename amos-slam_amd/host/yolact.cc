@@ -122,7 +122,9 @@ bool yolact::evalThroughSession(const cv::Mat &inputImage, cv::Mat &confidenceIm
     handled = false;
     if (mbSessionUnavailable) return false;
     const int h = inputImage.rows, w3 = inputImage.cols * (int)inputImage.elemSize(), w = w3 / 3;  // bytes per row: 8UC3, or rows x (3 * cols) of 8UC1
-    if (!mpSessionFrame || h != mnSessionH || w != mnSessionW) {
+    {
+        // asked for on every frame (a dictionary hit on the Python side): the buffers belong to the engine the module holds NOW -- another
+        // yolact object's yolact_init may have replaced it since the last frame
         PyObject *fn = PyObject_GetAttrString((PyObject *)mpPyEvalModule, "yolact_frame_session");
         if (!fn) { PyErr_Clear(); mbSessionUnavailable = true; return false; }
         PyObject *ret = PyObject_CallFunction(fn, "ii", h, w);
