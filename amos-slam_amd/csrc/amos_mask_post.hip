@@ -50,27 +50,71 @@ __global__ __launch_bounds__(256) void k_class_scores(const float *__restrict__ 
     }
 }
 
-// grid = (ceil(W / 64), ceil(H / 4), B), block = (64, 4).
+// grid = (ceil(W / 64), ceil(H / 16), B), block = (64, 4).  The 64 x 16 output pixels of a work-group read a source window of at most
+// kPmCols x kPmRows mask pixels (the masks are upsampled: 138 -> 640 is 0.216 source pixels per output pixel); the window of every flagged
+// detection is staged in LDS by a few coalesced loads, and the four taps of a pixel come from there -- per-thread global gathers (4 per
+// detection and pixel) made this kernel vector-memory-issue bound: 0.39 ms per 64 frames for 20 MB of output.  Windows larger than the
+// staging area (downsampling, or upsampling by less than ~3.7 x) take the gathers as before.  Same arithmetic either way.
+constexpr int kPmCols = 20, kPmRows = 6, kPmDet = 16, kPmTileH = 16;  // a work-group: 64 x 16 output pixels, four rows per thread
 __global__ __launch_bounds__(256) void k_person_mask(const float *__restrict__ masks, const uint8_t *__restrict__ flags, uint8_t *__restrict__ out, int n,
                                                     int ph, int pw, int H, int W, float scaleH, float scaleW)
 {
-    const int ox = blockIdx.x * 64 + threadIdx.x, oy = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
-    if (ox >= W || oy >= H) return;
-    float fy = __fsub_rn(__fmul_rn(scaleH, __fadd_rn((float)oy, 0.5f)), 0.5f), fx = __fsub_rn(__fmul_rn(scaleW, __fadd_rn((float)ox, 0.5f)), 0.5f);
-    fy = fy < 0.f ? 0.f : fy;
-    fx = fx < 0.f ? 0.f : fx;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < ph - 1 ? 1 : 0), x1 = x0 + (x0 < pw - 1 ? 1 : 0);
-    const float ly = __fsub_rn(fy, (float)y0), lx = __fsub_rn(fx, (float)x0), hy = __fsub_rn(1.f, ly), hx = __fsub_rn(1.f, lx);
-    unsigned count = 0;
-    for (int i = 0; i < n; i++) {
-        if (!flags[b * n + i]) continue;  // uniform over the work-group
-        const float *m = masks + ((size_t)b * n + i) * ph * pw;
-        const float p = m[y0 * pw + x0], r = m[y0 * pw + x1], s = m[y1 * pw + x0], u = m[y1 * pw + x1];
-        const float v = __fadd_rn(__fmul_rn(hy, __fadd_rn(__fmul_rn(hx, p), __fmul_rn(lx, r))), __fmul_rn(ly, __fadd_rn(__fmul_rn(hx, s), __fmul_rn(lx, u))));
-        count += v > 0.5f ? 1u : 0u;
+    __shared__ float win[kPmDet][kPmRows][kPmCols];
+    __shared__ int sList[kPmDet], sCount;
+    const int ox = blockIdx.x * 64 + threadIdx.x, b = blockIdx.z, t = threadIdx.y * 64 + threadIdx.x;
+    auto src = [](float scale, int o) {
+        const float f = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)o, 0.5f)), 0.5f);
+        return f < 0.f ? 0.f : f;
+    };
+    // the work-group's source window (its first and last output pixel inside the image bound it: the map is monotone)
+    const int ox0 = blockIdx.x * 64, ox1 = min(ox0 + 63, W - 1), oy0 = blockIdx.y * kPmTileH, oy1 = min(oy0 + kPmTileH - 1, H - 1);
+    const int wx0 = (int)src(scaleW, ox0), wx1 = min((int)src(scaleW, ox1) + 1, pw - 1), wy0 = (int)src(scaleH, oy0), wy1 = min((int)src(scaleH, oy1) + 1, ph - 1);
+    const int wc = wx1 - wx0 + 1, wr = wy1 - wy0 + 1;
+    const bool staged = wc <= kPmCols && wr <= kPmRows && n <= kPmDet;  // uniform over the work-group
+    if (staged) {
+        if (t < 64) {  // the flagged detections, in order (wave 0: a ballot and its prefix counts)
+            const bool f = t < n && flags[b * n + t] != 0;
+            const unsigned long long m = __ballot(f);
+            if (f) sList[__popcll(m & ((1ull << t) - 1ull))] = t;
+            if (t == 0) sCount = (int)__popcll(m);
+        }
+        __syncthreads();
+        const int cnt = sCount, per = wr * wc;
+        for (int e = t; e < cnt * per; e += 256) {
+            const int d = e / per, rem = e - d * per, r = rem / wc, c = rem - r * wc;
+            win[d][r][c] = masks[((size_t)b * n + sList[d]) * ph * pw + (size_t)(wy0 + r) * pw + wx0 + c];
+        }
+        __syncthreads();
     }
-    out[((size_t)b * H + oy) * W + ox] = (uint8_t)((count * 255u) & 0xffu);
+    if (ox >= W) return;
+    const float fx = src(scaleW, ox);
+    const int x0 = (int)fx, x1 = x0 + (x0 < pw - 1 ? 1 : 0);
+    const float lx = __fsub_rn(fx, (float)x0), hx = __fsub_rn(1.f, lx);
+    for (int ry = threadIdx.y; ry < kPmTileH; ry += 4) {
+        const int oy = oy0 + ry;
+        if (oy >= H) break;
+        const float fy = src(scaleH, oy);
+        const int y0 = (int)fy, y1 = y0 + (y0 < ph - 1 ? 1 : 0);
+        const float ly = __fsub_rn(fy, (float)y0), hy = __fsub_rn(1.f, ly);
+        unsigned count = 0;
+        if (staged) {
+            const int cnt = sCount, ry0 = y0 - wy0, ry1 = y1 - wy0, cx0 = x0 - wx0, cx1 = x1 - wx0;
+            for (int d = 0; d < cnt; d++) {
+                const float p = win[d][ry0][cx0], r = win[d][ry0][cx1], s2 = win[d][ry1][cx0], u = win[d][ry1][cx1];
+                const float v = __fadd_rn(__fmul_rn(hy, __fadd_rn(__fmul_rn(hx, p), __fmul_rn(lx, r))), __fmul_rn(ly, __fadd_rn(__fmul_rn(hx, s2), __fmul_rn(lx, u))));
+                count += v > 0.5f ? 1u : 0u;
+            }
+        } else {
+            for (int i = 0; i < n; i++) {
+                if (!flags[b * n + i]) continue;  // uniform over the work-group
+                const float *m = masks + ((size_t)b * n + i) * ph * pw;
+                const float p = m[y0 * pw + x0], r = m[y0 * pw + x1], s2 = m[y1 * pw + x0], u = m[y1 * pw + x1];
+                const float v = __fadd_rn(__fmul_rn(hy, __fadd_rn(__fmul_rn(hx, p), __fmul_rn(lx, r))), __fmul_rn(ly, __fadd_rn(__fmul_rn(hx, s2), __fmul_rn(lx, u))));
+                count += v > 0.5f ? 1u : 0u;
+            }
+        }
+        out[((size_t)b * H + oy) * W + ox] = (uint8_t)((count * 255u) & 0xffu);
+    }
 }
 
 // The prediction head's outputs for one pyramid level (yolact.py PredictionModule.forward + Yolact.forward's cat / softmax, as mask/net.py
@@ -169,14 +213,110 @@ __device__ __forceinline__ unsigned topk_key(float f)  // monotone: a < b  <=>  
 }
 __device__ __forceinline__ float topk_value(unsigned key) { return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key); }
 
-__global__ __launch_bounds__(256) void k_topk_rows(const float *__restrict__ x, float *__restrict__ values, long long *__restrict__ indices, int n, int k)
+// Sparse rows (round 5).  The class-score rows this kernel exists for are almost entirely ONE value -- `fill` = -1, the priors under the
+// confidence threshold -- with a few hundred live scores above it.  With `fill` given (not NaN) the row is scanned ONCE: everything above
+// `fill` is compacted into an LDS list of (key, ~index) and sorted there (bitonic, padded to a power of two); if the list holds fewer
+// than k, the rest of the result is `fill` at its first indices, found by a scan from the row's start that stops as soon as it has
+// them.  Exactly the generic result (value descending, index ascending).  The generic five-scan path below still serves: no `fill`, more
+// than kTopkList live values, or values BELOW `fill` in a row whose list is short of k.
+constexpr int kTopkList = 1024;   // (8 KB of LDS: a larger list costs the generic path, which lives on occupancy, more than it saves)
+__global__ __launch_bounds__(256) void k_topk_rows(const float *__restrict__ x, float *__restrict__ values, long long *__restrict__ indices, int n, int k, float fill)
 {
     __shared__ unsigned hist[kTopkBins];
     __shared__ unsigned part[256];
     __shared__ unsigned long long sel[256];
     __shared__ unsigned sPrefix, sMask, sNeed, sCountAbove, sWaveEq[4];
+    __shared__ unsigned long long list[kTopkList];
+    __shared__ unsigned sLive, sBelow;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const float *row = x + (size_t)blockIdx.x * n;  // read five times; after the first pass it comes from L2
+    const float *row = x + (size_t)blockIdx.x * n;  // generic path: read five times; after the first pass it comes from L2
+    if (fill == fill) {
+        const unsigned fk = topk_key(fill);
+        if (t == 0) { sLive = 0; sBelow = 0; }
+        __syncthreads();
+        const bool vec = (n & 3) == 0 && ((uintptr_t)row & 15) == 0;
+        const int nVec = vec ? n : 0;
+        // (one LDS atomic per wave and element slot: the lanes' positions come from a ballot)
+#define AMOS_TOPK_TAKE(have, v, i)                                                                                        \
+        {                                                                                                                 \
+            const unsigned key = topk_key(v);                                                                             \
+            const bool up = (have) && key > fk;                                                                           \
+            const unsigned long long m = __ballot(up);                                                                    \
+            if (m) {                                                                                                      \
+                unsigned base = 0;                                                                                        \
+                if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&sLive, (unsigned)__popcll(m));                     \
+                base = __shfl(base, (int)__builtin_ctzll(m), 64);                                                         \
+                const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));                             \
+                if (up && slot < (unsigned)kTopkList) list[slot] = ((unsigned long long)key << 32) | (unsigned)(0xffffffffu - (unsigned)(i)); \
+            }                                                                                                             \
+            if ((have) && key < fk) sBelow = 1u;                                                                          \
+        }
+        for (int i0 = 0; i0 < nVec; i0 += 1024) {
+            if (*reinterpret_cast<volatile unsigned *>(&sLive) > (unsigned)kTopkList) break;  // a dense row: no point in finishing the scan (a hint: the barrier below decides)
+            const int i = i0 + 4 * t;
+            const bool have = i < n;
+            const float4 v = have ? *reinterpret_cast<const float4 *>(row + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            AMOS_TOPK_TAKE(have, v.x, i)
+            AMOS_TOPK_TAKE(have, v.y, i + 1)
+            AMOS_TOPK_TAKE(have, v.z, i + 2)
+            AMOS_TOPK_TAKE(have, v.w, i + 3)
+        }
+        for (int i0 = nVec; i0 < n; i0 += 256) {
+            const int i = i0 + t;
+            const bool have = i < n;
+            const float v = have ? row[i] : 0.f;
+            AMOS_TOPK_TAKE(have, v, i)
+        }
+#undef AMOS_TOPK_TAKE
+        __syncthreads();
+        const unsigned live = sLive;
+        if (live <= (unsigned)kTopkList && (live >= (unsigned)k || !sBelow)) {  // uniform over the work-group
+            unsigned n2 = 256;
+            while (n2 < live) n2 <<= 1;
+            for (unsigned i = live + t; i < n2; i += 256) list[i] = 0ull;  // padding sorts last
+            __syncthreads();
+            for (unsigned size = 2; size <= n2; size <<= 1)
+                for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (unsigned i = t; i < n2 / 2; i += 256) {  // pair (lo, lo + stride) of the bitonic network, descending overall
+                        const unsigned lo = ((i / stride) * stride * 2) + (i % stride), hi = lo + stride;
+                        const unsigned long long a = list[lo], b = list[hi];
+                        const bool descending = (lo & size) == 0;
+                        if (descending ? a < b : a > b) { list[lo] = b; list[hi] = a; }
+                    }
+                    __syncthreads();
+                }
+            const unsigned take = live < (unsigned)k ? live : (unsigned)k;
+            if ((unsigned)t < take) {
+                const unsigned long long v = list[t];
+                values[(size_t)blockIdx.x * k + t] = topk_value((unsigned)(v >> 32));
+                indices[(size_t)blockIdx.x * k + t] = (long long)(0xffffffffu - (unsigned)(v & 0xffffffffu));
+            }
+            // the rest: `fill` at its first indices (every element that is not live equals `fill` here)
+            unsigned have = take;  // uniform
+            for (int i0 = 0; i0 < n && have < (unsigned)k; i0 += 256) {
+                const int i = i0 + t;
+                const bool eq = i < n && topk_key(row[i]) == fk;
+                const unsigned long long m = __ballot(eq);
+                if (lane == 0) sWaveEq[wave] = (unsigned)__popcll(m);
+                __syncthreads();
+                unsigned base = have, total = 0;
+                for (int w = 0; w < 4; w++) {
+                    const unsigned c = sWaveEq[w];
+                    if (w < wave) base += c;
+                    total += c;
+                }
+                const unsigned rank = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                if (eq && rank < (unsigned)k) {
+                    values[(size_t)blockIdx.x * k + rank] = fill;
+                    indices[(size_t)blockIdx.x * k + rank] = (long long)i;
+                }
+                have += total;
+                __syncthreads();
+            }
+            return;
+        }
+        __syncthreads();
+    }
     if (t == 0) { sPrefix = 0; sMask = 0; sNeed = (unsigned)k; sCountAbove = 0; }
     __syncthreads();
     // ---- radix select of the k-th largest key
@@ -492,14 +632,14 @@ int amos_mask_class_scores_device(void *stream, const float *d_conf, float *d_sc
 int amos_mask_person_mask_device(void *stream, const float *d_masks, const uint8_t *d_flags, uint8_t *d_out, int batch, int n_det, int mask_h, int mask_w,
                                  int out_h, int out_w)
 {
-    if (!d_masks || !d_flags || !d_out || batch < 0 || n_det < 0 || mask_h < 1 || mask_w < 1 || out_h < 1 || out_w < 1 || batch > 65535 || out_h > 4 * 65535) {
+    if (!d_masks || !d_flags || !d_out || batch < 0 || n_det < 0 || mask_h < 1 || mask_w < 1 || out_h < 1 || out_w < 1 || batch > 65535 || out_h > 16 * 65535) {
         set_error("amos_mask_person_mask_device: invalid argument");
         return AMOS_ERR_INVALID;
     }
     if (batch == 0) return AMOS_OK;
     // PyTorch's area_pixel_compute_scale for a given output size: input / output in float32
     const float sh = (float)mask_h / (float)out_h, sw = (float)mask_w / (float)out_w;
-    hipLaunchKernelGGL(k_person_mask, dim3((out_w + 63) / 64, (out_h + 3) / 4, batch), dim3(64, 4), 0, (hipStream_t)stream, d_masks, d_flags, d_out, n_det, mask_h,
+    hipLaunchKernelGGL(k_person_mask, dim3((out_w + 63) / 64, (out_h + kPmTileH - 1) / kPmTileH, batch), dim3(64, 4), 0, (hipStream_t)stream, d_masks, d_flags, d_out, n_det, mask_h,
                        mask_w, out_h, out_w, sh, sw);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
@@ -532,7 +672,19 @@ int amos_mask_topk_rows_device(void *stream, const float *d_x, float *d_values, 
         return AMOS_ERR_INVALID;
     }
     if (rows == 0) return AMOS_OK;
-    hipLaunchKernelGGL(k_topk_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, d_x, d_values, d_indices, n, k);
+    hipLaunchKernelGGL(k_topk_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, d_x, d_values, d_indices, n, k, __builtin_nanf(""));
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_mask_topk_rows_sparse_device(void *stream, const float *d_x, float *d_values, long long *d_indices, int rows, int n, int k, float fill)
+{
+    if (!d_x || !d_values || !d_indices || rows < 0 || n < 1 || k < 1 || k > 256 || k > n) {
+        set_error("amos_mask_topk_rows_sparse_device: invalid argument (1 <= k <= min(256, n))");
+        return AMOS_ERR_INVALID;
+    }
+    if (rows == 0) return AMOS_OK;
+    hipLaunchKernelGGL(k_topk_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, d_x, d_values, d_indices, n, k, fill);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }
@@ -594,7 +746,7 @@ int amos_mask_person_masks_device(void *stream, const float *d_loc, const float 
     hipLaunchKernelGGL(k_decode_boxes, dim3((total + 255) / 256), dim3(256), 0, st, (const float4 *)d_loc, (const float4 *)d_priors, boxes, P, total);
     int rc = amos_mask_class_scores_device(stream, d_conf, cls, B, P, C1, AMOS_MASK_CONF_THRESH);
     if (rc != AMOS_OK) return rc;
-    rc = amos_mask_topk_rows_device(stream, cls, topv, topi, B * C, P, k);
+    rc = amos_mask_topk_rows_sparse_device(stream, cls, topv, topi, B * C, P, k, -1.f);  // (k_class_scores writes -1 for every prior under the threshold)
     if (rc != AMOS_OK) return rc;
     hipLaunchKernelGGL(k_nms_alive, dim3(B * C), dim3(256), 0, st, boxes, topi, topv, alive, k, P, C, AMOS_MASK_NMS_THRESH);
     hipLaunchKernelGGL(k_select_display, dim3(B), dim3(256), 0, st, alive, topi, boxes, d_coef, selCoef, selRect, flags, d_found, C * k, k,

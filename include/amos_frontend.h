@@ -463,6 +463,12 @@ int amos_mask_head_outputs_device(void *stream, const float *d_raw, const float 
  * [rows][n] -> d_values [rows][k], d_indices [rows][k] (int64, as torch.topk returns them).  Values equal torch.topk's; among equal
  * values the lower index comes first (torch leaves that order unspecified).  1 <= k <= min(256, n). */
 int amos_mask_topk_rows_device(void *stream, const float *d_x, float *d_values, long long *d_indices, int rows, int n, int k);
+/* The same result for rows that are mostly ONE value `fill` with everything of interest above it (the class-score rows: -1 for the priors
+ * under the confidence threshold): one scan of the row instead of five -- the values above `fill` are compacted and sorted in LDS, a
+ * result short of k is completed with `fill` at its first indices.  Rows that do not fit the assumption (more than 1 024 values above
+ * `fill`, or values below it when the list is short of k) take the generic path inside the same launch: always amos_mask_topk_rows_device's
+ * result. */
+int amos_mask_topk_rows_sparse_device(void *stream, const float *d_x, float *d_values, long long *d_indices, int rows, int n, int k, float fill);
 
 /* ---- the post-processing of the mask pass as ONE call: Detect (box decoding, per-class top 200, Fast NMS at IoU 0.5, class-confidence
  * threshold 0.05; layers/functions/detection.py:27-170, layers/box_utils.py:268-312) + postprocess / prep_display (score threshold 0.15, the
