@@ -30,6 +30,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "../../include/amos_frontend.h"
 #include "amos_common.h"
 
@@ -75,6 +77,7 @@ struct W24Args {
     // different stages (and L1 has lost it by the time the next one asks).  y / res: outBlocked selects [b][N / 8][h][w][8].
     unsigned xPixelBytes, xStageBytes;
     int outBlocked;
+    int virtualBlocks;          // ids of the (tile block, channel tile) map; the persistent form walks them with a stride of gridDim.x
 };
 
 // k * a + b per component as one fused multiply-add each (the file is compiled with -ffp-contract=off)
@@ -121,7 +124,16 @@ __global__ __launch_bounds__(256) void k_winograd24_weights(const float *__restr
 // The whole work of one wave, compiled once per half of the position row (kHalf = wave & 1): the two halves combine the patch columns
 // differently, and a run-time branch on that inside a stage would split the stage's basic block -- the interleaving of the transform
 // with the MFMAs (sched_group_barrier) only works inside one.  Every wave of a work-group passes the same barriers in either copy.
-template <int kHalf>
+//
+// kPersist (round 5): ONE work-group per CU walks the ids blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8, so an id's XCD
+// is the group's).  A CU holds one group at a time (128 KB of LDS, 512 x 256 registers), so with one id per group nothing overlaps a group's
+// prologue -- two raw patches and four U fragments fetched from L2 / HBM, then the first transform: ~10 k of a group's ~140 k cycles -- or its
+// epilogue.  Here the LAST stages of an id request the NEXT id's first two raw patches in the very slots the steady state uses for
+// "stage s + 3" (the buffers are free by then) and the epilogue requests its four prologue U fragments half way, so they travel under the last
+// MFMAs and the epilogue; what is left between two ids is one wait, the first transform and two barriers.  For that the epilogue's exchange
+// image may not overlay the raw patches: it is 64 KB (the V tiles + the 16 KB tail of the allocation) and takes four rounds of 16 tiles x 32
+// channels instead of two of 32 x 32; same sums in the same order, same bits.
+template <int kHalf, bool kPersist>
 __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
 {
     constexpr int half = kHalf;
@@ -130,25 +142,38 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     // id -> (m block, n tile): an XCD (ids are dealt round-robin over the 8 XCDs) owns a contiguous run of m blocks and walks it in groups of
     // kW24Group blocks, n tile after n tile (amos_winograd.hip, map 1: the group's patches stay in the XCD's L2 for the next n tile, and
     // half the XCD's CUs share one weight slice at a time)
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-    const int per = kW24Group * a.nTiles, grp = seq / per, in = seq - grp * per;
-    const int perXcd = (a.mBlocks + 7) >> 3, mbLocal = grp * kW24Group + in % kW24Group;
-    const int nt = in / kW24Group, mb = xcd * perXcd + mbLocal;
-    if (mbLocal >= perXcd || mb >= a.mBlocks) return;
+    const int perXcd = (a.mBlocks + 7) >> 3;
+    auto decode = [&](int id, int &mbOut, int &ntOut) -> bool {
+        const int xcd = id & 7, seq = id >> 3;
+        const int per = kW24Group * a.nTiles, grp = seq / per, in = seq - grp * per;
+        const int mbLocal = grp * kW24Group + in % kW24Group;
+        ntOut = in / kW24Group;
+        mbOut = xcd * perXcd + mbLocal;
+        return mbLocal < perXcd && mbOut < a.mBlocks;
+    };
+    auto next_valid = [&](int id, int &mbOut, int &ntOut) -> int {  // the first valid id >= id of this group's walk, or -1
+        for (; id < a.virtualBlocks; id += (int)gridDim.x)
+            if (decode(id, mbOut, ntOut)) return id;
+        return -1;
+    };
+    int mb = 0, nt = 0;
+    int id = kPersist ? next_valid((int)blockIdx.x, mb, nt) : (decode((int)blockIdx.x, mb, nt) ? (int)blockIdx.x : -1);
+    if (id < 0) return;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
-    // ---- geometry of the work-group's tile run: segments of tiles of one tile row.  This thread is (a) the loader of raw-patch column
+    // ---- geometry of an id's tile run: segments of tiles of one tile row.  This thread is (a) the loader of raw-patch column
     // `col` (block `wave`, lane order [column % 4][column / 4][quad]) for all four patch rows and (b) the transformer of tile `tl`, channel quad
     // `quad`, position row `prow`, position columns 3 * half .. + 2.
     const int quad = lane & 1, tl = lane >> 1, prow = wave >> 1;
     const int col = 32 * wave + 4 * ((lane >> 1) & 7) + (lane >> 4);  // lane l fills unit l of its block: w24_raw_unit(col, lane & 1) == 64 * wave + l
-    int xoff[4];     // loader: byte offset of (patch row r, column col, channel quad) in x, or the buffer's size (zeros) when there is no such pixel
-    int colBase = 0; // transformer: first patch column of tile tl
-    {
-        const int T0 = mb * kW24Tiles, nT = min(kW24Tiles, a.totalTiles - T0);
+    // xo[r]: loader: byte offset of (patch row r, column col, channel quad) in x, or the buffer's size (zeros) when there is no such pixel;
+    // cbase: transformer: first patch column of tile tl
+    auto geometry = [&](int mbi, int (&xo)[4], int &cbase) {
+        const int T0 = mbi * kW24Tiles, nT = min(kW24Tiles, a.totalTiles - T0);
         int b = T0 / a.tilesPerImage, rem = T0 - b * a.tilesPerImage, ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+        cbase = 0;
 #pragma unroll
-        for (int r = 0; r < 4; r++) xoff[r] = (int)a.xBytes;
+        for (int r = 0; r < 4; r++) xo[r] = (int)a.xBytes;
         for (int t0 = 0, cb = 0; t0 < nT;) {  // (b, ty, tx) = the segment's first tile, t0 its index in the run, cb its first column
             const int n = min(a.tilesX - tx, nT - t0);
             if (col >= cb && col < cb + 4 * n + 2) {
@@ -157,53 +182,59 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
                 for (int r = 0; r < 4; r++) {
                     const int iy = 2 * ty - 1 + r;
                     if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                        xoff[r] = (int)((unsigned)b * (unsigned)(a.H * a.W) * (unsigned)a.C * 4u + (unsigned)(iy * a.W + ix) * a.xPixelBytes + 16u * quad);
+                        xo[r] = (int)((unsigned)b * (unsigned)(a.H * a.W) * (unsigned)a.C * 4u + (unsigned)(iy * a.W + ix) * a.xPixelBytes + 16u * quad);
                 }
             }
-            if (tl >= t0 && tl < t0 + n) colBase = cb + 4 * (tl - t0);
+            if (tl >= t0 && tl < t0 + n) cbase = cb + 4 * (tl - t0);
             t0 += n;
             cb += 4 * n + 2;
             tx = 0;
             if (++ty == a.tilesY) { ty = 0; b++; }
         }
-        if (tl >= nT) colBase = 0;  // tiles past the end of the tensor: any valid patch position (their results are not stored)
-    }
+        if (tl >= nT) cbase = 0;  // tiles past the end of the tensor: any valid patch position (their results are not stored)
+    };
+    int xoff[4], colBase = 0;
+    geometry(mb, xoff, colBase);
+    int xoffN[4] = {0, 0, 0, 0}, colBaseN = 0, mbN = 0, ntN = 0, idN = -1;  // the next id of a persistent group (tail of the stage loop)
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.xBytes, 0x00020000);
     typedef __attribute__((address_space(3))) void *LdsPtr;
     // the transformer's ten reads: rows (r0, r1) of B2^T d row `prow` (0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3), columns colBase + half + c, c = 0 .. 4
     const int r0 = prow == 0 ? 0 : (prow == 2 ? 2 : 1), r1 = prow == 0 ? 2 : (prow == 1 ? 2 : (prow == 2 ? 1 : 3));
     int rsrc0[5];  // float offsets inside a raw patch of (row r0, column colBase + half + c); row r1 is (r1 - r0) * kW24RawRow further
-#pragma unroll
-    for (int c = 0; c < 5; c++) rsrc0[c] = r0 * kW24RawRow + w24_raw_unit(colBase + half + c, quad) * 4;
+#define AMOS_W24_SET_RSRC() { _Pragma("unroll") for (int c = 0; c < 5; c++) rsrc0[c] = r0 * kW24RawRow + w24_raw_unit(colBase + half + c, quad) * 4; }
+    AMOS_W24_SET_RSRC()
     const int rdelta = (r1 - r0) * kW24RawRow;
     const float sgn = prow == 1 ? 1.f : -1.f;                 // the row's second term is added (row 1) or subtracted
     const int vdst = (3 * wave) * kW24PosV + w24_swz(tl, quad);  // + p * kW24PosV for position 3 * wave + p
     // U fragments of this wave's three positions: [position of the triple][cout block] x 16 bytes per lane and stage
-    const float *usrc = a.u + (size_t)nt * a.stages * kW24StageU + (size_t)(wave * 3) * 512 + lane * 4;
+    const float *const ubase = a.u + (size_t)(wave * 3) * 512 + lane * 4;
+    const float *usrc = ubase + (size_t)nt * a.stages * kW24StageU, *usrcN = usrc;
 
 #ifdef AMOS_W24_EXP_NOX  /* timing experiments (results are wrong): tools/w24_variants.sh */
-#define AMOS_W24_FETCH_X(s, buf) {}
+#define AMOS_W24_FETCH_XO(xo, s, buf) {}
 #else
-#define AMOS_W24_FETCH_X(s, buf)                                                                                                     \
+#define AMOS_W24_FETCH_XO(xo, s, buf)                                                                                                \
     {                                                                                                                                \
         _Pragma("unroll") for (int r = 0; r < 4; r++)                                                                                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (LdsPtr)(AMOS_W24_R(buf) + r * kW24RawRow + wave * 256), 16, xoff[r], (s) * a.xStageBytes, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (LdsPtr)(AMOS_W24_R(buf) + r * kW24RawRow + wave * 256), 16, xo[r], (s) * a.xStageBytes, 0, 0); \
     }
 #endif
+#define AMOS_W24_FETCH_X(s, buf) AMOS_W24_FETCH_XO(xoff, s, buf)
 #ifdef AMOS_W24_U_NT   /* experiment: the weight stream with the non-temporal hint */
 #define AMOS_W24_ULOAD(p) __builtin_nontemporal_load(p)
 #else
 #define AMOS_W24_ULOAD(p) (*(p))
 #endif
 #ifdef AMOS_W24_EXP_NOU
-#define AMOS_W24_FETCH_U(fb, s, p) { _Pragma("unroll") for (int j = 0; j < 2; j++) fb[j] = f32x4{(float)(s), (float)lane, 1.f, (float)(p)}; }
+#define AMOS_W24_FETCH_UP(fb, up, s, p) { _Pragma("unroll") for (int j = 0; j < 2; j++) fb[j] = f32x4{(float)(s), (float)lane, 1.f, (float)(p)}; }
 #else
-#define AMOS_W24_FETCH_U(fb, s, p)                                                                                                   \
+#define AMOS_W24_FETCH_UP(fb, up, s, p)                                                                                              \
     {                                                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                                \
-            fb[j] = AMOS_W24_ULOAD(reinterpret_cast<const f32x4 *>(usrc + (size_t)(s) * kW24StageU + ((p) * 2 + j) * 256));          \
+            fb[j] = AMOS_W24_ULOAD(reinterpret_cast<const f32x4 *>((up) + (size_t)(s) * kW24StageU + ((p) * 2 + j) * 256));          \
     }
 #endif
+#define AMOS_W24_FETCH_U(fb, s, p) AMOS_W24_FETCH_UP(fb, usrc, s, p)
     // raw patch (buffer rb) -> this thread's half row of B2^T d B4 -> the wave's V blocks (buffer vb).  s_c = d[r0][c] +- d[r1][c] for the five
     // columns; half 0: V0 = 4 s0 - 5 s2 + s4, V1 = (s4 - 4 s2) + (s3 - 4 s1), V2 = (s4 - 4 s2) - (s3 - 4 s1);
     // half 1 (s = t1 .. t5): V3 = (s3 - s1) + 2 (s2 - s0), V4 = (s3 - s1) - 2 (s2 - s0), V5 = 4 s0 - 5 s2 + s4.
@@ -238,12 +269,11 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
 #endif
 
     f32x16 acc[3][2];  // [position of the triple][cout block]
-#pragma unroll
-    for (int p = 0; p < 3; p++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[p][j][r] = 0.f;
+#define AMOS_W24_ZERO_ACC()                                                              \
+    _Pragma("unroll") for (int p = 0; p < 3; p++)                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; j++)                                    \
+            _Pragma("unroll") for (int r = 0; r < 16; r++) acc[p][j][r] = 0.f;
+    AMOS_W24_ZERO_ACC()
     const int foff = w24_swz(lane & 31, lane >> 5);  // this lane's 4 floats inside a position's block
     f32x4 fa0, fa1, fa2, fbE0[2], fbE1[2], fbE2[2], fbO0[2], fbO1[2], fbO2[2];
 #define AMOS_W24_LDFRAG(fa, buf, p) fa = *reinterpret_cast<const f32x4 *>(AMOS_W24_V(buf) + (wave * 3 + (p)) * kW24PosV + foff);
@@ -319,6 +349,41 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
 #define AMOS_W24_LOOP_VM 2
 
 #else
+/* the stage with every request's source spelt out: (kT) transform + next fragment; (kU1, u1, s1) U of positions 1, 2 of stage s1 from u1;
+   (kU0, u0, s0) U of position 0 of stage s0 from u0; (kX, xo, sx) the raw patch of stage sx from xo -- the steady state and the tail, where
+   a persistent group's requests go to its NEXT id */
+#define AMOS_W24_STAGE_G(vb, fbC0, fbC1, fbC2, fbN1, fbN2, kT, kU1, u1, s1, kU0, u0, s0, kX, xo, sx, kVm) \
+    {                                                                                     \
+        AMOS_W24_LDFRAG(fa1, vb, 1);                                                      \
+        AMOS_W24_LDFRAG(fa2, vb, 2);                                                      \
+        if (kT) AMOS_W24_TRANSFORM(AMOS_W24_RB_READ(vb), (vb) ^ 1);                       \
+        if (kU1) AMOS_W24_FETCH_UP(fbN1, u1, s1, 1);                                      \
+        if (kU1) AMOS_W24_FETCH_UP(fbN2, u1, s1, 2);                                      \
+        AMOS_W24_MFMAS(fa0, fbC0, 0);                                                     \
+        AMOS_W24_INTERLEAVE(3, 4, 0, 0, 0);                                               \
+        if (kT) {                                                                         \
+            AMOS_W24_INTERLEAVE(2, 0, 12, 0, 1);                                          \
+            AMOS_W24_INTERLEAVE(2, 0, 10, 1, 1);                                          \
+            AMOS_W24_INTERLEAVE(1, 0, 4, 1, 0);                                           \
+        }                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        AMOS_W24_BARRIER(kVm)                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (kT) AMOS_W24_LDFRAG(fa0, (vb) ^ 1, 0);                                        \
+        if (kU0) AMOS_W24_FETCH_UP(fbC0, u0, s0, 0);                                      \
+        if (kX) AMOS_W24_FETCH_XO(xo, sx, AMOS_W24_RB_READ(vb));                          \
+        AMOS_W24_MFMAS(fa1, fbC1, 1);                                                     \
+        AMOS_W24_MFMAS(fa2, fbC2, 2);                                                     \
+        AMOS_W24_INTERLEAVE(1, 1, 0, 0, 0);                                               \
+        _Pragma("unroll") for (int q = 0; q < 6; q++) {                                   \
+            __builtin_amdgcn_sched_group_barrier(0x008, AMOS_W24_VM_EVERY, 0);            \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                            \
+        }                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                               \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        AMOS_W24_RB_ADVANCE();                                                            \
+    }
 #define AMOS_W24_STAGE(s, vb, fbC0, fbC1, fbC2, fbN1, fbN2, kNext, kNext2, kNext3, kVm)   \
     {                                                                                     \
         AMOS_W24_LDFRAG(fa1, vb, 1);                                                      \
@@ -356,6 +421,8 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     }
 #define AMOS_W24_STAGE_EVEN(s, n1, n2, n3, vm) AMOS_W24_STAGE(s, 0, fbE0, fbE1, fbE2, fbO1, fbO2, n1, n2, n3, vm)
 #define AMOS_W24_STAGE_ODD(s, n1, n2, n3, vm) AMOS_W24_STAGE(s, 1, fbO0, fbO1, fbO2, fbE1, fbE2, n1, n2, n3, vm)
+#define AMOS_W24_STAGE_EVEN_G(...) AMOS_W24_STAGE_G(0, fbE0, fbE1, fbE2, fbO1, fbO2, __VA_ARGS__)
+#define AMOS_W24_STAGE_ODD_G(...) AMOS_W24_STAGE_G(1, fbO0, fbO1, fbO2, fbE1, fbE2, __VA_ARGS__)
 #define AMOS_W24_PROLOGUE_U() { AMOS_W24_FETCH_U(fbE0, 0, 0); AMOS_W24_FETCH_U(fbE1, 0, 1); AMOS_W24_FETCH_U(fbE2, 0, 2); AMOS_W24_FETCH_U(fbO0, 1, 0); }
 #if AMOS_W24_XAHEAD == 1
 #define AMOS_W24_LOOP_VM 4
@@ -385,32 +452,72 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     AMOS_W24_FETCH_X(3, 0);
     int rbuf = 1;  // buffer of the raw patch of stage s + 1
 #endif
+#if AMOS_W24_SPLIT == 0 || AMOS_W24_XAHEAD != 1
+    static_assert(!kPersist, "the persistent form is written for the default stage shape");
+#endif
+    for (;;) {  // one trip per id (a persistent group: until its walk ends)
     int s = 0;
     for (; s + 4 < a.stages; s += 2) {  // two stages per trip: the register names follow the stage parity
         AMOS_W24_STAGE_EVEN(s, true, true, true, AMOS_W24_LOOP_VM);
         AMOS_W24_STAGE_ODD(s + 1, true, true, true, AMOS_W24_LOOP_VM);
     }
-    // the last four stages (the stage count is even and at least four: amos_mask_winograd_supported): less and less left to request
-    AMOS_W24_STAGE_EVEN(s, true, true, AMOS_W24_XAHEAD == 1, 0);
-    AMOS_W24_STAGE_ODD(s + 1, true, true, false, 0);
-    AMOS_W24_STAGE_EVEN(s + 2, true, false, false, 0);
-    AMOS_W24_STAGE_ODD(s + 3, false, false, false, 0);
+    // the last four stages (the stage count is even and at least four: amos_mask_winograd_supported): less and less left to request for
+    // THIS id -- a persistent group fills the free slots with the first requests of its next one
+    bool haveNext = false;
+    if (kPersist) {
+        idN = next_valid(id + (int)gridDim.x, mbN, ntN);
+        haveNext = idN >= 0;  // uniform over the work-group
+        if (haveNext) {
+            geometry(mbN, xoffN, colBaseN);
+            usrcN = ubase + (size_t)ntN * a.stages * kW24StageU;
+        }
+    }
+#if AMOS_W24_SPLIT == 1 && AMOS_W24_XAHEAD == 1
+    if (kPersist) {
+        //                 transform | U 1,2 of stage  | U 0 of stage      | raw patch of stage       | younger requests the barrier lets be
+        AMOS_W24_STAGE_EVEN_G(true,    true, usrc, s + 1, true, usrc, s + 2,  true, xoff, s + 3,           4);
+        AMOS_W24_STAGE_ODD_G(true,     true, usrc, s + 2, true, usrc, s + 3,  haveNext, xoffN, 0,          4);
+        AMOS_W24_STAGE_EVEN_G(true,    true, usrc, s + 3, false, usrc, 0,     haveNext, xoffN, 1,          8);   // (the next id's first patch + this part's four U loads)
+        AMOS_W24_STAGE_ODD_G(false,    false, usrc, 0,    false, usrc, 0,     false, xoffN, 0,             63);  // (nothing of this id is awaited any more)
+    } else
+#endif
+    {
+        AMOS_W24_STAGE_EVEN(s, true, true, AMOS_W24_XAHEAD == 1, 0);
+        AMOS_W24_STAGE_ODD(s + 1, true, true, false, 0);
+        AMOS_W24_STAGE_EVEN(s + 2, true, false, false, 0);
+        AMOS_W24_STAGE_ODD(s + 3, false, false, false, 0);
+    }
 
     // ---- epilogue.  This wave holds M[pr][pc] for pr = wave >> 1, pc = 3 * half + p.  Along A4's columns (M A4)[pr][j] = sum_pc M[pr][pc] A4^T[j][pc]:
     // half 0 contributes (M0 + M1 + M2, M1 - M2, M1 + M2, M1 - M2), half 1 (M3 + M4, 2 (M3 - M4), 4 (M3 + M4), 8 (M3 - M4) + M5).  Exchange image:
-    // [wave][j][tile 32][cout 32] floats, one cout block of 32 per round.  Accumulator register r of lane l is tile row
-    // (r & 3) + 8 (r >> 2) + 4 (l >> 5), channel l & 31 of its 32 x 32 block.
+    // [wave][j][tile 32][cout 32] floats, one cout block of 32 per round (persistent form: [wave][j][tile 16][cout 32], 16 tiles of a cout
+    // block per round, in the V tiles' LDS + the allocation's last 16 KB: the raw patches hold the next id's requests).  Accumulator register r
+    // of lane l is tile row (r & 3) + 8 (r >> 2) + 4 (l >> 5), channel l & 31 of its 32 x 32 block.
 #ifdef AMOS_W24_EXP_NOEPI
     if (acc[0][0][0] == 12345.f && acc[1][1][3] == 5.f && acc[2][0][7] == 1.f) a.y[t] = acc[0][1][1] + acc[1][0][2] + acc[2][1][3];  // keeps the accumulators alive
     return;
 #endif
-    __syncthreads();  // every wave is done with the V tiles and the raw patches
-    const int oq = t & 7, otl = (t >> 3) & 31, oy = t >> 8;  // finishing thread: channel quad of the round, tile, output row of the tile
+    // (raw barriers: a __syncthreads() would also wait for the next id's requests in flight)
+#define AMOS_W24_EPI_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    AMOS_W24_EPI_BARRIER()  // every wave is done with the V tiles (and, one id per group, with the raw patches)
+    constexpr int kRounds = kPersist ? 4 : 2, kRoundTiles = kPersist ? 16 : 32;
+    // finishing thread: channel quad of the round, tile of the round, output row of the tile (persistent form: + which two of the four pixels)
+    const int oq = t & 7, otl = kPersist ? (t >> 3) & 15 : (t >> 3) & 31, oy = kPersist ? (t >> 7) & 1 : t >> 8, jp = kPersist ? t >> 8 : 0;
+    auto exch = [&](int w) -> float * {  // wave w's part of the exchange image
+        return kPersist ? smem24 + (w < 6 ? w * (4 * 16 * 32) : (2 * kW24StageV + 2 * kW24StageR) + (w - 6) * (4 * 16 * 32)) : smem24 + w * (4 * 32 * 32);
+    };
 #pragma unroll
-    for (int jb = 0; jb < 2; jb++) {
-        if (jb) __syncthreads();  // the previous round's readers are done
+    for (int rd = 0; rd < kRounds; rd++) {
+        const int jb = kPersist ? rd >> 1 : rd, th = kPersist ? rd & 1 : 0;
+        if (rd) AMOS_W24_EPI_BARRIER()  // the previous round's readers are done
+        // the next id's four prologue U fragments: requested once half of the accumulators are dead (with them live through the whole
+        // epilogue the kernel spilled), two rounds of exchange + stores ahead of their use
+        if (kPersist && rd == 2 && haveNext) {
+            AMOS_W24_FETCH_UP(fbE0, usrcN, 0, 0); AMOS_W24_FETCH_UP(fbE1, usrcN, 0, 1); AMOS_W24_FETCH_UP(fbE2, usrcN, 0, 2); AMOS_W24_FETCH_UP(fbO0, usrcN, 1, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
+            if (kPersist && (r >> 3) != th) continue;  // this round's 16 tiles: rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) with r >> 3 == th
             const float m0 = acc[0][jb][r], m1 = acc[1][jb][r], m2 = acc[2][jb][r];
             float c0, c1, c2, c3;
             if (half == 0) {
@@ -420,37 +527,39 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
                 const float dlt = m0 - m1, sm = m0 + m1;
                 c0 = sm; c1 = 2.f * dlt; c2 = 4.f * sm; c3 = 8.f * dlt + m2;
             }
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), cc = lane & 31;
-            float *dst = smem24 + ((wave * 4) * 32 + row) * 32 + cc;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) - (kPersist ? 16 * th : 0), cc = lane & 31;
+            float *dst = exch(wave) + row * 32 + cc;
             dst[0] = c0;
-            dst[1 * 32 * 32] = c1;
-            dst[2 * 32 * 32] = c2;
-            dst[3 * 32 * 32] = c3;
+            dst[1 * kRoundTiles * 32] = c1;
+            dst[2 * kRoundTiles * 32] = c2;
+            dst[3 * kRoundTiles * 32] = c3;
         }
-        __syncthreads();
+        AMOS_W24_EPI_BARRIER()
         // S[pr][j] = (M A4)[pr][j];  Y[0][j] = S[0][j] + S[1][j] + S[2][j];  Y[1][j] = S[1][j] - S[2][j] - S[3][j]
         const int n0 = nt * kW24Cout + jb * 32 + 4 * oq;
         const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 yv[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+            if (kPersist && (j >> 1) != jp) continue;  // (persistent form: this thread finishes two of the four pixels)
             f32x4 sp[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int pr = oy + k;  // rows 0, 1, 2 for the upper output row, 1, 2, 3 for the lower one
-                const f32x4 lo = *reinterpret_cast<const f32x4 *>(&smem24[(((pr * 2 + 0) * 4 + j) * 32 + otl) * 32 + 4 * oq]);
-                const f32x4 hi = *reinterpret_cast<const f32x4 *>(&smem24[(((pr * 2 + 1) * 4 + j) * 32 + otl) * 32 + 4 * oq]);
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(exch(pr * 2 + 0) + (j * kRoundTiles + otl) * 32 + 4 * oq);
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(exch(pr * 2 + 1) + (j * kRoundTiles + otl) * 32 + 4 * oq);
                 sp[k] = lo + hi;
             }
             yv[j] = oy == 0 ? (sp[0] + sp[1]) + sp[2] : (sp[0] - sp[1]) - sp[2];
         }
-        const int T = mb * kW24Tiles + otl;
+        const int T = mb * kW24Tiles + (kPersist ? 16 * th : 0) + otl;
         if (T < a.totalTiles) {
             const int b = T / a.tilesPerImage, rem = T - b * a.tilesPerImage, ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
             const int py = 2 * ty + oy;
             if (py < a.H) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
+                    if (kPersist && (j >> 1) != jp) continue;
                     const int px = 4 * tx + j;
                     if (px >= a.W) continue;
                     const size_t o = a.outBlocked ? ((((size_t)b * (a.N >> 3) + (n0 >> 3)) * a.H + py) * a.W + px) * 8 + (n0 & 7)
@@ -463,6 +572,21 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
             }
         }
     }
+    if (!kPersist || !haveNext) break;
+    // ---- the next id: its first two raw patches and its four prologue U fragments were requested above
+    id = idN; mb = mbN; nt = ntN;
+#pragma unroll
+    for (int r = 0; r < 4; r++) xoff[r] = xoffN[r];
+    colBase = colBaseN;
+    usrc = usrcN;
+    AMOS_W24_SET_RSRC()
+    AMOS_W24_ZERO_ACC()
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the patches have landed; the last round's readers are done with the V tiles
+    AMOS_W24_TRANSFORM(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    AMOS_W24_LDFRAG(fa0, 0, 0);
+    AMOS_W24_FETCH_X(2, 0);
+    }  // ids
 #undef AMOS_W24_V
 #undef AMOS_W24_R
 }
@@ -470,8 +594,16 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
 __global__ __launch_bounds__(kW24Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_winograd24_conv(const W24Args a)
 {
     extern __shared__ __align__(16) float smem24[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) w24_run<1>(a, smem24);
-    else w24_run<0>(a, smem24);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) w24_run<1, false>(a, smem24);
+    else w24_run<0, false>(a, smem24);
+}
+
+// one work-group per CU walking the ids (see w24_run): grid = a multiple of 8 work-groups, at most one per CU
+__global__ __launch_bounds__(kW24Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_winograd24_conv_persistent(const W24Args a)
+{
+    extern __shared__ __align__(16) float smem24[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) w24_run<1, true>(a, smem24);
+    else w24_run<0, true>(a, smem24);
 }
 
 const char *w24_variant_tag()
@@ -499,7 +631,25 @@ const char *w24_variant_tag()
 
 using namespace amos;
 
+// -1 automatic (by launch size), 0 never, 1 always: AMOS_W24_PERSIST in the environment is the initial value, amos_mask_winograd24_persistent_mode sets it
+static int g_w24_persist = -2;
+static int w24_persist_mode()
+{
+    if (g_w24_persist == -2) {
+        const char *env = getenv("AMOS_W24_PERSIST");
+        g_w24_persist = env && (env[0] == '0' || env[0] == '1') ? env[0] - '0' : -1;
+    }
+    return g_w24_persist;
+}
+
 extern "C" {
+
+int amos_mask_winograd24_persistent_mode(int mode)
+{
+    const int before = w24_persist_mode();
+    if (mode >= -1 && mode <= 1) g_w24_persist = mode;
+    return before;
+}
 
 size_t amos_mask_winograd24_weight_floats(int cin, int cout)
 {
@@ -532,7 +682,7 @@ int amos_mask_winograd24_conv_layout_device(void *stream, const float *d_x, cons
         set_error("amos_mask_winograd24_conv_device: invalid argument (cin %% 16 == 0, cin >= 32, cout %% 64 == 0, input below 2 GiB, 16-byte aligned channels-last tensors)");
         return AMOS_ERR_INVALID;
     }
-    static DeviceOnce ldsAttr;  // per device (amos_common.h)
+    static DeviceOnce ldsAttr, ldsAttrP;  // per device (amos_common.h)
     const size_t lds = (size_t)kW24LdsFloats * sizeof(float);  // 128 KB
     AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttr, reinterpret_cast<const void *>(k_winograd24_conv), (int)lds, (hipStream_t)stream));
     W24Args a;
@@ -551,8 +701,30 @@ int amos_mask_winograd24_conv_layout_device(void *stream, const float *d_x, cons
     a.outBlocked = out_blocked ? 1 : 0;
     // ids: 8 XCDs x groups of (kW24Group m blocks x nTiles); the last group may be partly empty (those work-groups return at once)
     const int perXcd = (a.mBlocks + 7) / 8, groups = (perXcd + kW24Group - 1) / kW24Group;
-    const dim3 grid((unsigned)(groups * kW24Group * a.nTiles * 8)), block(kW24Threads);
-    hipLaunchKernelGGL(k_winograd24_conv, grid, block, lds, (hipStream_t)stream, a);
+    a.virtualBlocks = groups * kW24Group * a.nTiles * 8;
+    const dim3 block(kW24Threads);
+    // Persistent form (one work-group per CU walking the ids, the next id's first requests under the current one's last stages and
+    // epilogue); AMOS_W24_PERSIST=1 / amos_mask_winograd24_persistent_mode(1) selects it (A/B runs, tests)
+    const int forced = w24_persist_mode();
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount / 8 * 8;
+        if (cus < 8) cus = 256;
+    }
+    // MEASURED (tools/r5_w24_persist.py, 64 frames, interleaved A/B, same bits): the persistent form is 3.5 - 5 % SLOWER on the large layers
+    // (256 ch at 138 x 138: 4.74 against 4.58 ms) and 36 % slower where a CU gets only a few ids (512 ch at 18 x 18): what it hides of the
+    // prologue it loses to the four-round epilogue, to the wait for the last stores before the next first transform (the vector-memory counter
+    // retires in order) and to a static walk instead of the dispatcher's "next id to the first free CU".  So the automatic choice is the one
+    // work-group per id form; the persistent one stays selectable (mode 1) and under test.
+    const bool persist = forced == 1 && a.virtualBlocks > cus;
+    if (persist) {
+        AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttrP, reinterpret_cast<const void *>(k_winograd24_conv_persistent), (int)lds, (hipStream_t)stream));
+        hipLaunchKernelGGL(k_winograd24_conv_persistent, dim3((unsigned)std::min(cus, a.virtualBlocks)), block, lds, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(k_winograd24_conv, dim3((unsigned)a.virtualBlocks), block, lds, (hipStream_t)stream, a);
+    }
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }

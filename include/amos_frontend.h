@@ -417,6 +417,12 @@ int amos_mask_winograd24_conv_device(void *stream, const float *d_x, const float
  * contiguous whole cache lines used once; channels-last, a quarter of every line four times.  Same arithmetic, same bits. */
 int amos_mask_winograd24_conv_layout_device(void *stream, const float *d_x, const float *d_u, const float *d_bias, const float *d_residual,
                                             float *d_y, int batch, int h, int w, int cin, int cout, int relu, int in_blocked, int out_blocked);
+/* Which launch form the F(2 x 4) kernel takes: -1 automatic and 0: one work-group per (tile block, channel tile) id (the default form);
+ * 1: the PERSISTENT form -- one work-group per CU walking the ids, the next id's first requests travelling under the current id's last
+ * stages and epilogue.  Measured 3.5 - 5 % slower on the network's large layers (tools/r5_w24_persist.py), hence not the automatic choice;
+ * kept selectable and under test.  Returns the previous mode (-2 or anything else out of range: query only).  Same bits either way;
+ * AMOS_W24_PERSIST=0 / 1 in the environment is the initial value. */
+int amos_mask_winograd24_persistent_mode(int mode);
 int amos_mask_conv1x1_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual,
                              float *d_y, int batch, int in_h, int in_w, int cin, int cout, int stride, int relu);
 

@@ -632,6 +632,8 @@ def test_winograd_conv3x3_against_float64(mask, gpu_lib, family):
     Gc, npos, make_weights, run_conv = ((G2, 16, gpu_lib.mask_winograd_weights, gpu_lib.mask_winograd_conv) if family == "22" else
                                         (G4, 24, gpu_lib.mask_winograd24_weights, gpu_lib.mask_winograd24_conv))
     worst = 0.0
+    # F(2 x 4): both launch forms (one work-group per id / the persistent walk), forced in turn; every output of the second form must equal the first's
+    forms = (0, 1) if family == "24" else (None,)
     for b, cin, cout, h, w in ((1, 32, 64, 6, 6), (2, 64, 64, 21, 17), (1, 32, 128, 9, 9), (3, 256, 64, 5, 5), (3, 48, 192, 12, 7), (2, 32, 64, 1, 1),
                                (1, 64, 128, 2, 37), (5, 80, 64, 7, 3), (40, 32, 64, 2, 4), (70, 32, 64, 2, 2), (3, 32, 64, 1, 1), (2, 128, 256, 35, 35), (1, 256, 384, 69, 69),
                                (2, 32, 64, 3, 130), (1, 32, 64, 9, 127), (33, 32, 64, 4, 1),
@@ -650,16 +652,28 @@ def test_winograd_conv3x3_against_float64(mask, gpu_lib, family):
         exact = F.conv2d(x.double(), wgt.double(), None, 1, 1)
         bound = 1e-5 * F.conv2d(x.double().abs(), wgt.double().abs(), None, 1, 1) + 1e-6
         for use_bias, use_res, relu in ((True, True, True), (True, False, True), (False, True, False), (False, False, False), (True, False, False)):
-            y = torch.full((b, cout, h, w), float("nan"), device="cuda").contiguous(memory_format=cl)
-            run_conv(st, x.data_ptr(), u.data_ptr(), bias.data_ptr() if use_bias else None, res.data_ptr() if use_res else None, y.data_ptr(),
-                     b, h, w, cin, cout, relu)
-            torch.cuda.synchronize()
-            want = exact + (bias.double().view(1, -1, 1, 1) if use_bias else 0) + (res.double() if use_res else 0)
-            if relu:
-                want = want.relu()
-            err = (y.double() - want).abs()
-            assert torch.isfinite(y).all() and bool((err <= bound).all()), (family, b, cin, cout, h, w, use_bias, use_res, relu, err.max().item())
-            worst = max(worst, float((err / bound).max()))
+            first = None
+            for form in forms:
+                if form is not None:
+                    gpu_lib.mask_winograd24_persistent_mode(form)
+                y = torch.full((b, cout, h, w), float("nan"), device="cuda").contiguous(memory_format=cl)
+                try:
+                    run_conv(st, x.data_ptr(), u.data_ptr(), bias.data_ptr() if use_bias else None, res.data_ptr() if use_res else None, y.data_ptr(),
+                             b, h, w, cin, cout, relu)
+                    torch.cuda.synchronize()
+                finally:
+                    if form is not None:
+                        gpu_lib.mask_winograd24_persistent_mode(-1)
+                want = exact + (bias.double().view(1, -1, 1, 1) if use_bias else 0) + (res.double() if use_res else 0)
+                if relu:
+                    want = want.relu()
+                err = (y.double() - want).abs()
+                assert torch.isfinite(y).all() and bool((err <= bound).all()), (family, form, b, cin, cout, h, w, use_bias, use_res, relu, err.max().item())
+                worst = max(worst, float((err / bound).max()))
+                if first is None:
+                    first = y
+                else:
+                    assert torch.equal(y, first), ("launch forms differ", b, cin, cout, h, w, use_bias, use_res, relu)
     print("winograd family", family, "worst error / bound", worst)
     assert worst < (0.2 if family == "22" else 0.6)   # F(2 x 2): measured 0.02 (the transforms cost less rounding than the 9-tap sums save); F(2 x 4): a few times that
     if family == "24":
@@ -707,6 +721,16 @@ def test_winograd_conv3x3_at_the_headline_launch_size(mask, gpu_lib, family):
         bound = 1e-5 * F.conv2d(xf.abs(), wgt.double().abs(), None, 1, 1) + 1e-6
         err = (y[f:f + 1].double() - want).abs()
         assert bool((err <= bound).all()), (family, f, float((err / bound).max()))
+    if family == "24":   # the other launch form on the whole launch: the same bits
+        assert gpu_lib.mask_winograd24_persistent_mode(1) == -1   # (automatic until here: one work-group per id; now the persistent walk)
+        try:
+            y0 = torch.full((b, cout, h, w), float("nan"), device="cuda").contiguous(memory_format=cl)
+            run_conv(st, x.data_ptr(), u.data_ptr(), bias.data_ptr(), None, y0.data_ptr(), b, h, w, cin, cout, True)
+            torch.cuda.synchronize()
+        finally:
+            gpu_lib.mask_winograd24_persistent_mode(-1)
+        assert torch.equal(y0, y)
+        del y0
     part = torch.empty((8, cout, h, w), device="cuda").contiguous(memory_format=cl)
     for f0 in range(0, b, 8):
         part.fill_(float("nan"))
