@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_workspace_bytes", "amos_mask_conv_ws_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_corners_create", "amos_corners_destroy", "amos_corners_stream", "amos_corners_good_features_device", "amos_corners_candidate_count", "amos_corners_subpix_device", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_winograd24_weight_floats", "amos_mask_winograd24_weights_device", "amos_mask_winograd24_conv_device", "amos_mask_winograd24_conv_layout_device", "amos_mask_winograd24_persistent_mode", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_topk_rows_device", "amos_mask_topk_rows_sparse_device", "amos_mask_post_workspace_bytes", "amos_mask_person_masks_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_flow_fundamental_score_device", "amos_flow_pnp_score_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_workspace_bytes", "amos_mask_conv_ws_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_corners_create", "amos_corners_destroy", "amos_corners_stream", "amos_corners_good_features_device", "amos_corners_candidate_count", "amos_corners_subpix_device", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_winograd24_weight_floats", "amos_mask_winograd24_weights_device", "amos_mask_winograd24_conv_device", "amos_mask_winograd24_conv_layout_device", "amos_mask_winograd24_persistent_mode", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_topk_rows_device", "amos_mask_topk_rows_sparse_device", "amos_mask_post_workspace_bytes", "amos_mask_person_masks_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -447,6 +447,20 @@ def flow_scene_flow(stream, d_depth_last, last_stride, d_depth_cur, cur_stride, 
     _check(lib().amos_flow_scene_flow_device(C.c_void_p(stream), C.c_void_p(d_depth_last), C.c_size_t(last_stride), C.c_void_p(d_depth_cur),
                                              C.c_size_t(cur_stride), C.c_void_p(d_match_pre), C.c_void_p(d_match_cur), C.c_int(n), C.byref(cam),
                                              C.c_void_p(d_out)), "amos_flow_scene_flow_device")
+
+
+def flow_fundamental_score(stream, d_F, n_hyp, d_p1, d_p2, n, threshold, d_err, d_inliers, d_mask):
+    """amos_flow_fundamental_score_device: error / inlier test / inlier count of n correspondences under n_hyp fundamental matrices (device pointers)."""
+    _check(lib().amos_flow_fundamental_score_device(C.c_void_p(stream), C.c_void_p(d_F), C.c_int(n_hyp), C.c_void_p(d_p1), C.c_void_p(d_p2), C.c_int(n),
+                                                    C.c_double(threshold), C.c_void_p(d_err), C.c_void_p(d_inliers), C.c_void_p(d_mask)),
+           "amos_flow_fundamental_score_device")
+
+
+def flow_pnp_score(stream, d_Rt, n_hyp, d_obj, d_img, n, fx, fy, cx, cy, reprojection_error, d_err, d_inliers, d_mask):
+    """amos_flow_pnp_score_device: reprojection error / inlier test / inlier count of n 3-D -> 2-D correspondences under n_hyp poses (device pointers)."""
+    _check(lib().amos_flow_pnp_score_device(C.c_void_p(stream), C.c_void_p(d_Rt), C.c_int(n_hyp), C.c_void_p(d_obj), C.c_void_p(d_img), C.c_int(n), C.c_double(fx),
+                                            C.c_double(fy), C.c_double(cx), C.c_double(cy), C.c_double(reprojection_error), C.c_void_p(d_err), C.c_void_p(d_inliers),
+                                            C.c_void_p(d_mask)), "amos_flow_pnp_score_device")
 
 
 def mask_bias_relu_maxpool(stream_ptr, x_ptr, bias_ptr, y_ptr, n, in_h, in_w, channels):

@@ -55,6 +55,88 @@ __global__ __launch_bounds__(256) void k_epipolar(const double *__restrict__ F, 
     dd[i] = __ddiv_rn(num, __dsqrt_rn(__dadd_rn(__dmul_rn(A, A), __dmul_rn(B, B))));
 }
 
+// ---- hypothesis scoring for the RANSACs of GetSceneFlowObj (Tracking.cc:927, 945: cv::findFundamentalMat(..., FM_RANSAC, 0.1, 0.99);
+// :1006: cv::solvePnPRansac(..., 500, 0.4, 0.98, inliers, SOLVEPNP_P3P)).  The minimal solvers, the sampling and the iteration-count
+// update stay with the caller; what the device takes is the part that touches every point: the error of every
+// correspondence under every hypothesis, the inlier test and the inlier counts -- one work-group per hypothesis, counts by a reduction
+// (no atomics: deterministic, nothing to zero).
+//
+// Fundamental matrix: OpenCV 4.5's FMEstimatorCallback::computeError (modules/calib3d/src/fundam.cpp) restated: in doubles, left to right,
+//   a = F0 x1 + F1 y1 + F2, b = F3 x1 + F4 y1 + F5, c = F6 x1 + F7 y1 + F8;  s2 = 1 / (a a + b b);  d2 = x2 a + y2 b + c;
+//   a = F0 x2 + F3 y2 + F6, b = F1 x2 + F4 y2 + F7, c = F2 x2 + F5 y2 + F8;  s1 = 1 / (a a + b b);  d1 = x1 a + y1 b + c;
+//   err = (float) max(d1 d1 s1, d2 d2 s2);  inlier <=> err <= (float)(threshold * threshold)   (RANSACPointSetRegistrator::findInliers).
+// OpenCV-derived, hence parity unpinned like the other OpenCV stages; the GPU tests hold it to the numpy restatement bit for bit.
+__global__ __launch_bounds__(256) void k_fundamental_score(const double *__restrict__ Fs, const FlowPoint *__restrict__ p1, const FlowPoint *__restrict__ p2, int n,
+                                                          float thresh2, float *__restrict__ err, int *__restrict__ inliers, uint8_t *__restrict__ mask)
+{
+    __shared__ int sCount[4];
+    const int h = blockIdx.x, t = threadIdx.x;
+    const double *F = Fs + (size_t)h * 9;
+    const double F0 = F[0], F1 = F[1], F2 = F[2], F3 = F[3], F4 = F[4], F5 = F[5], F6 = F[6], F7 = F[7], F8 = F[8];
+    int count = 0;
+    for (int i = t; i < n; i += 256) {
+        const double x1 = p1[i].x, y1 = p1[i].y, x2 = p2[i].x, y2 = p2[i].y;
+        double a = __dadd_rn(__dadd_rn(__dmul_rn(F0, x1), __dmul_rn(F1, y1)), F2);
+        double b = __dadd_rn(__dadd_rn(__dmul_rn(F3, x1), __dmul_rn(F4, y1)), F5);
+        double c = __dadd_rn(__dadd_rn(__dmul_rn(F6, x1), __dmul_rn(F7, y1)), F8);
+        const double s2 = __ddiv_rn(1.0, __dadd_rn(__dmul_rn(a, a), __dmul_rn(b, b)));
+        const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(x2, a), __dmul_rn(y2, b)), c);
+        a = __dadd_rn(__dadd_rn(__dmul_rn(F0, x2), __dmul_rn(F3, y2)), F6);
+        b = __dadd_rn(__dadd_rn(__dmul_rn(F1, x2), __dmul_rn(F4, y2)), F7);
+        c = __dadd_rn(__dadd_rn(__dmul_rn(F2, x2), __dmul_rn(F5, y2)), F8);
+        const double s1 = __ddiv_rn(1.0, __dadd_rn(__dmul_rn(a, a), __dmul_rn(b, b)));
+        const double d1 = __dadd_rn(__dadd_rn(__dmul_rn(x1, a), __dmul_rn(y1, b)), c);
+        const double e1 = __dmul_rn(__dmul_rn(d1, d1), s1), e2 = __dmul_rn(__dmul_rn(d2, d2), s2);
+        const float e = (float)(e1 > e2 ? e1 : (e2 > e1 ? e2 : (e1 != e1 ? e2 : e1)));  // std::max(a, b) = (a < b) ? b : a
+        const bool in = e <= thresh2;
+        if (err) err[(size_t)h * n + i] = e;
+        if (mask) mask[(size_t)h * n + i] = in ? 1 : 0;
+        count += in ? 1 : 0;
+    }
+    for (int d = 32; d > 0; d >>= 1) count += __shfl_xor(count, d, 64);
+    if ((t & 63) == 0) sCount[t >> 6] = count;
+    __syncthreads();
+    if (t == 0) inliers[h] = sCount[0] + sCount[1] + sCount[2] + sCount[3];
+}
+
+// Pose hypotheses (R | t): OpenCV's PnPRansacCallback::computeError restated for zero distortion: the object point goes through
+// cv::projectPoints' arithmetic in doubles -- X = R00 x + R01 y + R02 z + t0 (left to right) ..., x' = X / Z, y' = Y / Z (as X * (1 / Z)),
+// u = fx x' + cx, v = fy y' + cy, stored as float -- and err = (float) ||image point - (u, v)||^2 in float (Matx21f norm L2SQR);
+// inlier <=> err <= (float)(reprojectionError * reprojectionError).
+__global__ __launch_bounds__(256) void k_pnp_score(const double *__restrict__ Rts, const float *__restrict__ obj, const FlowPoint *__restrict__ img, int n, double fx,
+                                                  double fy, double cx, double cy, float thresh2, float *__restrict__ err, int *__restrict__ inliers,
+                                                  uint8_t *__restrict__ mask)
+{
+    __shared__ int sCount[4];
+    const int h = blockIdx.x, t = threadIdx.x;
+    const double *M = Rts + (size_t)h * 12;
+    double R[9], T[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = M[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) T[k] = M[9 + k];
+    int count = 0;
+    for (int i = t; i < n; i += 256) {
+        const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+        const double xc = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R[0], X), __dmul_rn(R[1], Y)), __dmul_rn(R[2], Z)), T[0]);
+        const double yc = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R[3], X), __dmul_rn(R[4], Y)), __dmul_rn(R[5], Z)), T[1]);
+        double zc = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R[6], X), __dmul_rn(R[7], Y)), __dmul_rn(R[8], Z)), T[2]);
+        zc = zc != 0.0 ? __ddiv_rn(1.0, zc) : 1.0;  // cvProjectPoints2: z = z ? 1. / z : 1
+        const double xn = __dmul_rn(xc, zc), yn = __dmul_rn(yc, zc);
+        const float u = (float)__dadd_rn(__dmul_rn(xn, fx), cx), v = (float)__dadd_rn(__dmul_rn(yn, fy), cy);
+        const float dx = __fsub_rn(img[i].x, u), dy = __fsub_rn(img[i].y, v);
+        const float e = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+        const bool in = e <= thresh2;
+        if (err) err[(size_t)h * n + i] = e;
+        if (mask) mask[(size_t)h * n + i] = in ? 1 : 0;
+        count += in ? 1 : 0;
+    }
+    for (int d = 32; d > 0; d >>= 1) count += __shfl_xor(count, d, 64);
+    if ((t & 63) == 0) sCount[t >> 6] = count;
+    __syncthreads();
+    if (t == 0) inliers[h] = sCount[0] + sCount[1] + sCount[2] + sCount[3];
+}
+
 struct SceneFlowArgs {
     float cx, cy, invfx, invfy;
     float Rwl[9], twl[3];  // last camera -> world (Rlw^T, -Rlw^T tlw as floats, Tracking.cc:970-973)
@@ -333,6 +415,28 @@ int amos_flow_epipolar_device(void *stream, const double *d_F, const float *d_pr
     if (n == 0) return AMOS_OK;
     hipLaunchKernelGGL(k_epipolar, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_F, (const FlowPoint *)d_pre_xy, (const FlowPoint *)d_next_xy,
                        d_state, n, d_dd);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_flow_fundamental_score_device(void *stream, const double *d_F, int n_hypotheses, const float *d_points1_xy, const float *d_points2_xy, int n,
+                                       double threshold, float *d_err, int32_t *d_inliers, uint8_t *d_mask)
+{
+    if (!d_F || !d_points1_xy || !d_points2_xy || !d_inliers || n < 0 || n_hypotheses < 0 || !(threshold >= 0)) { set_error("amos_flow_fundamental_score_device: invalid argument"); return AMOS_ERR_INVALID; }
+    if (n_hypotheses == 0) return AMOS_OK;
+    hipLaunchKernelGGL(k_fundamental_score, dim3(n_hypotheses), dim3(256), 0, (hipStream_t)stream, d_F, (const FlowPoint *)d_points1_xy, (const FlowPoint *)d_points2_xy, n,
+                       (float)(threshold * threshold), d_err, d_inliers, d_mask);
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
+int amos_flow_pnp_score_device(void *stream, const double *d_Rt, int n_hypotheses, const float *d_object_xyz, const float *d_image_xy, int n, double fx, double fy,
+                               double cx, double cy, double reprojection_error, float *d_err, int32_t *d_inliers, uint8_t *d_mask)
+{
+    if (!d_Rt || !d_object_xyz || !d_image_xy || !d_inliers || n < 0 || n_hypotheses < 0 || !(reprojection_error >= 0)) { set_error("amos_flow_pnp_score_device: invalid argument"); return AMOS_ERR_INVALID; }
+    if (n_hypotheses == 0) return AMOS_OK;
+    hipLaunchKernelGGL(k_pnp_score, dim3(n_hypotheses), dim3(256), 0, (hipStream_t)stream, d_Rt, d_object_xyz, (const FlowPoint *)d_image_xy, n, fx, fy, cx, cy,
+                       (float)(reprojection_error * reprojection_error), d_err, d_inliers, d_mask);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }

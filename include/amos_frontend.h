@@ -573,6 +573,19 @@ typedef struct amos_scene_flow_camera {
 int amos_flow_scene_flow_device(void *stream, const float *d_depth_last, size_t last_stride, const float *d_depth_cur,
                                 size_t cur_stride, const float *d_match_pre_xy, const float *d_match_cur_xy, int n,
                                 const amos_scene_flow_camera *cam, float *d_out);
+/* Hypothesis scoring for the three RANSACs of GetSceneFlowObj (Tracking.cc:927, 945: cv::findFundamentalMat(pre, cur, FM_RANSAC, 0.1, 0.99);
+ * :1006: cv::solvePnPRansac(pre_3d, cur_2d, K, 0, rvec, tvec, false, 500, 0.4, 0.98, inliers, SOLVEPNP_P3P)).  The minimal solvers (7- / 8-point,
+ * P3P), the sampling and the iteration-count update stay with the caller; the device takes what touches every point: the error of every
+ * correspondence under every hypothesis (OpenCV's FMEstimatorCallback / PnPRansacCallback::computeError restated -- symmetric squared epipolar
+ * distance in doubles; squared reprojection error of cv::projectPoints without distortion), the inlier test `err <= (float)(threshold^2)` and
+ * the inlier count per hypothesis.  d_F: n_hypotheses x 9 doubles (row-major 3 x 3); d_Rt: n_hypotheses x 12 doubles (R row-major, then t);
+ * points as float pairs / triples.  Outputs: d_inliers [n_hypotheses]; optional d_err [n_hypotheses][n] float and d_mask
+ * [n_hypotheses][n] uint8 (NULL: not written).  One work-group per hypothesis, no atomics. */
+int amos_flow_fundamental_score_device(void *stream, const double *d_F, int n_hypotheses, const float *d_points1_xy, const float *d_points2_xy,
+                                       int n, double threshold, float *d_err, int32_t *d_inliers, uint8_t *d_mask);
+int amos_flow_pnp_score_device(void *stream, const double *d_Rt, int n_hypotheses, const float *d_object_xyz, const float *d_image_xy, int n,
+                               double fx, double fy, double cx, double cy, double reprojection_error, float *d_err, int32_t *d_inliers,
+                               uint8_t *d_mask);
 
 /* cv::calcOpticalFlowPyrLK(imlast, gray, prepoint, nextpoint, state, err, Size(22, 22), 5, TermCriteria(COUNT | EPS, 20, 0.01))
  * (Tracking.cc:896) on given points: pyramids of both gray frames (pyrDown, REFLECT_101 borders of the window size), Scharr

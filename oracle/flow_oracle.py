@@ -62,3 +62,40 @@ def scene_flow(depth_last, depth_cur, match_pre, match_cur, cx, cy, invfx, invfy
         fx, fz = f32(p[0] - c[0]), f32(p[2] - c[2])
         out[i] = [p[0], p[1], p[2], c[0], c[1], c[2], np.sqrt(f32(f32(fx * fx) + f32(fz * fz)), dtype=f32), 1.0]
     return out
+
+
+def fundamental_errors(F, p1, p2):
+    """OpenCV 4.5 FMEstimatorCallback::computeError (modules/calib3d/src/fundam.cpp) for ONE hypothesis F (3 x 3): the symmetric squared
+    epipolar distance of every correspondence, in doubles left to right, stored as float32 -- what cv::findFundamentalMat's RANSAC
+    (Tracking.cc:927, 945) tests against threshold^2.  Restated from the published source: parity unpinned like the other OpenCV stages."""
+    F = np.asarray(F, np.float64).reshape(9)
+    x1, y1 = p1[:, 0].astype(np.float64), p1[:, 1].astype(np.float64)
+    x2, y2 = p2[:, 0].astype(np.float64), p2[:, 1].astype(np.float64)
+    a = (F[0] * x1 + F[1] * y1) + F[2]
+    b = (F[3] * x1 + F[4] * y1) + F[5]
+    c = (F[6] * x1 + F[7] * y1) + F[8]
+    s2 = 1.0 / (a * a + b * b)
+    d2 = (x2 * a + y2 * b) + c
+    a = (F[0] * x2 + F[3] * y2) + F[6]
+    b = (F[1] * x2 + F[4] * y2) + F[7]
+    c = (F[2] * x2 + F[5] * y2) + F[8]
+    s1 = 1.0 / (a * a + b * b)
+    d1 = (x1 * a + y1 * b) + c
+    return np.maximum((d1 * d1) * s1, (d2 * d2) * s2).astype(np.float32)
+
+
+def pnp_errors(R, t, obj, img, fx, fy, cx, cy):
+    """OpenCV 4.5 PnPRansacCallback::computeError without distortion (cv::solvePnPRansac, Tracking.cc:1006): cv::projectPoints' arithmetic in
+    doubles (X = R x + t left to right, x' = X * (1 / Z), u = x' fx + cx as float32), then the squared distance to the image point in float32."""
+    R = np.asarray(R, np.float64).reshape(3, 3)
+    t = np.asarray(t, np.float64).reshape(3)
+    X, Y, Z = (obj[:, k].astype(np.float64) for k in range(3))
+    xc = ((R[0, 0] * X + R[0, 1] * Y) + R[0, 2] * Z) + t[0]
+    yc = ((R[1, 0] * X + R[1, 1] * Y) + R[1, 2] * Z) + t[1]
+    zc = ((R[2, 0] * X + R[2, 1] * Y) + R[2, 2] * Z) + t[2]
+    with np.errstate(divide="ignore"):
+        iz = np.where(zc != 0.0, 1.0 / zc, 1.0)
+    u = ((xc * iz) * fx + cx).astype(np.float32)
+    v = ((yc * iz) * fy + cy).astype(np.float32)
+    dx, dy = img[:, 0].astype(np.float32) - u, img[:, 1].astype(np.float32) - v
+    return (dx * dx + dy * dy).astype(np.float32)

@@ -87,3 +87,74 @@ def test_scene_flow_vs_numpy(gpu_lib, synth):
     assert len(bad) == 0, (len(bad), np.nonzero((got != want).any(0))[0].tolist(), got[bad[:2]].tolist(), want[bad[:2]].tolist())
     assert got.tobytes() == want.tobytes()
     assert 0.8 < want[:, 7].mean() < 0.95 and want[want[:, 7] > 0, 6].max() > 0.01
+
+
+def test_ransac_hypothesis_scorers_vs_numpy(gpu_lib, synth):
+    """amos_flow_fundamental_score_device / amos_flow_pnp_score_device (the device side of GetSceneFlowObj's three RANSACs: every
+    correspondence's error under every hypothesis, inlier test, inlier count) against oracle/flow_oracle.py: errors bit for bit, masks and
+    counts exact, for 64 hypotheses x 1 000 correspondences incl. exact ones (error 0), gross outliers and a point at depth zero."""
+    import torch
+    import flow_oracle as fo
+    rng = np.random.default_rng(6)
+    st = torch.cuda.current_stream().cuda_stream
+    n, nh = 1000, 64
+    # two views of random 3-D points: a small rotation + translation; correspondences with 0.3 px noise, 10 % gross outliers
+    K = np.array([[535.4, 0, 320.1], [0, 539.2, 247.6], [0, 0, 1]])
+    X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(1.5, 6, n)]
+
+    def rot(rx, ry, rz):
+        cx_, sx, cy_, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+        return np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy_, 0, sy], [0, 1, 0], [-sy, 0, cy_]]) @ np.array([[1, 0, 0], [0, cx_, -sx], [0, sx, cx_]])
+    R0, t0 = rot(0.01, -0.02, 0.005), np.array([0.05, 0.01, -0.02])
+    x1 = (K @ X.T).T
+    x1 = x1[:, :2] / x1[:, 2:]
+    X2 = X @ R0.T + t0
+    x2 = (K @ X2.T).T
+    x2 = x2[:, :2] / x2[:, 2:]
+    p1 = np.ascontiguousarray(x1, np.float32)   # (x1, x2 are transposed views: the device wants [n][2] rows)
+    p2 = np.ascontiguousarray(x2 + rng.normal(0, 0.3, x2.shape), np.float32)
+    p2[::10] += rng.uniform(-60, 60, (len(p2[::10]), 2)).astype(np.float32)
+    tx = np.array([[0, -t0[2], t0[1]], [t0[2], 0, -t0[0]], [-t0[1], t0[0], 0]])
+    Ftrue = np.linalg.inv(K).T @ tx @ R0 @ np.linalg.inv(K)
+    Fs = np.stack([Ftrue * (1 + 0.0) if h == 0 else Ftrue + rng.normal(0, 1e-7 * (h % 5), (3, 3)) for h in range(nh)]).astype(np.float64)
+    d_F, d_p1, d_p2 = torch.from_numpy(Fs.reshape(nh, 9).copy()).cuda(), torch.from_numpy(p1).cuda(), torch.from_numpy(p2).cuda()
+    err = torch.full((nh, n), float("nan"), device="cuda")
+    cnt = torch.full((nh,), -1, dtype=torch.int32, device="cuda")
+    msk = torch.full((nh, n), 7, dtype=torch.uint8, device="cuda")
+    gpu_lib.flow_fundamental_score(st, d_F.data_ptr(), nh, d_p1.data_ptr(), d_p2.data_ptr(), n, 0.1, err.data_ptr(), cnt.data_ptr(), msk.data_ptr())
+    torch.cuda.synchronize()
+    thr2 = np.float32(0.1 * 0.1)
+    for h in range(nh):
+        want = fo.fundamental_errors(Fs[h], p1, p2)
+        assert err[h].cpu().numpy().tobytes() == want.tobytes(), h
+        assert np.array_equal(msk[h].cpu().numpy(), (want <= thr2).astype(np.uint8)) and int(cnt[h]) == int((want <= thr2).sum()), h
+    assert 0 < int(cnt[0]) < n and int(cnt.max()) >= int(cnt[0]) - 50
+    # counts only (no error / mask buffers)
+    cnt2 = torch.full((nh,), -1, dtype=torch.int32, device="cuda")
+    gpu_lib.flow_fundamental_score(st, d_F.data_ptr(), nh, d_p1.data_ptr(), d_p2.data_ptr(), n, 0.1, None, cnt2.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert torch.equal(cnt, cnt2)
+
+    # poses: the true one, perturbed ones, one that puts a point at depth exactly zero
+    obj = X.astype(np.float32)
+    obj[5] = [0.3, 0.2, 0.0]
+    img = p2.copy()
+    Rts = np.zeros((nh, 12))
+    for h in range(nh):
+        Rh = rot(0.01 + 1e-4 * (h % 7), -0.02, 0.005 + 2e-4 * (h % 3))
+        th = t0 + (0 if h == 0 else rng.normal(0, 1e-3, 3))
+        Rts[h, :9], Rts[h, 9:] = Rh.reshape(9), th
+    Rts[1, :9], Rts[1, 9:] = np.eye(3).reshape(9), 0.0   # identity: obj[5] has Z = 0 exactly
+    d_Rt, d_obj, d_img = torch.from_numpy(Rts.copy()).cuda(), torch.from_numpy(obj).cuda(), torch.from_numpy(img).cuda()
+    err.fill_(float("nan")); cnt.fill_(-1); msk.fill_(7)
+    gpu_lib.flow_pnp_score(st, d_Rt.data_ptr(), nh, d_obj.data_ptr(), d_img.data_ptr(), n, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 0.4, err.data_ptr(), cnt.data_ptr(),
+                           msk.data_ptr())
+    torch.cuda.synchronize()
+    thr2 = np.float32(0.4 * 0.4)
+    for h in range(nh):
+        want = fo.pnp_errors(Rts[h, :9], Rts[h, 9:], obj, img, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        assert err[h].cpu().numpy().tobytes() == want.tobytes(), h
+        assert np.array_equal(msk[h].cpu().numpy(), (want <= thr2).astype(np.uint8)) and int(cnt[h]) == int((want <= thr2).sum()), h
+    assert int(cnt[0]) > 100 and int(cnt[1]) < int(cnt[0])
+    with pytest.raises(gpu_lib.AmosError):
+        gpu_lib.flow_pnp_score(st, d_Rt.data_ptr(), nh, d_obj.data_ptr(), d_img.data_ptr(), n, K[0, 0], K[1, 1], K[0, 2], K[1, 2], -1.0, None, cnt.data_ptr(), None)

@@ -45,3 +45,32 @@ def test_scene_flow_identity_pose():
     assert out[1].tolist() == [0] * 8  # z1 == 0
     np.testing.assert_allclose(out[2, :3], [100.5 * 2 * 0.002, 0, 2], rtol=1e-6)
     assert out[2, 6] == 0 and out[2, 7] == 1
+
+
+def test_fundamental_errors_known_answers():
+    """horizontal epipolar lines (pure x translation: F = [t]_x with t = (1, 0, 0)): the symmetric distance is the squared row difference."""
+    F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float64)
+    p1 = np.array([[10, 20], [300, 200.5], [5, 5]], np.float32)
+    p2 = np.array([[50, 23], [10, 200.5], [7, 4]], np.float32)
+    assert fo.fundamental_errors(F, p1, p2).tolist() == [9.0, 0.0, 1.0]
+    # scale invariance of the distance and the float32 result type
+    e = fo.fundamental_errors(3.5 * F, p1, p2)
+    assert e.dtype == np.float32 and np.allclose(e, [9.0, 0.0, 1.0], rtol=1e-6)
+    # a general F: the error is the larger of the two point-to-line squared distances, each computed independently here
+    rng = np.random.default_rng(4)
+    F = rng.normal(size=(3, 3))
+    p1, p2 = rng.uniform(0, 640, (50, 2)).astype(np.float32), rng.uniform(0, 480, (50, 2)).astype(np.float32)
+    h1, h2 = np.c_[p1, np.ones(50)].astype(np.float64), np.c_[p2, np.ones(50)].astype(np.float64)
+    l2, l1 = h1 @ F.T, h2 @ F            # epipolar lines in image 2 of the points of image 1, and the other way round
+    d2 = (l2 * h2).sum(1) ** 2 / (l2[:, 0] ** 2 + l2[:, 1] ** 2)
+    d1 = (l1 * h1).sum(1) ** 2 / (l1[:, 0] ** 2 + l1[:, 1] ** 2)
+    np.testing.assert_allclose(fo.fundamental_errors(F, p1, p2), np.maximum(d1, d2), rtol=1e-5)
+
+
+def test_pnp_errors_known_answers():
+    obj = np.array([[0, 0, 2], [1, 0, 2], [0, 1, 4], [0, 0, 0]], np.float32)
+    R, t = np.eye(3), np.zeros(3)
+    img = np.array([[320, 240], [570, 240], [320, 365], [321, 243]], np.float32)   # fx = fy = 500, principal point (320, 240)
+    assert fo.pnp_errors(R, t, obj, img, 500.0, 500.0, 320.0, 240.0).tolist() == [0.0, 0.0, 0.0, 10.0]   # the last point has Z = 0: projects to the principal point
+    e = fo.pnp_errors(R, np.array([0.01, 0, 0]), obj[:3], img[:3], 500.0, 500.0, 320.0, 240.0)
+    np.testing.assert_allclose(e, [2.5 ** 2, 2.5 ** 2, 1.25 ** 2], rtol=1e-4)   # a 1 cm shift at 2 m / 4 m depth: 2.5 / 1.25 px
