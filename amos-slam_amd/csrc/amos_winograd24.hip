@@ -133,9 +133,15 @@ __global__ __launch_bounds__(256) void k_winograd24_weights(const float *__restr
 // MFMAs and the epilogue; what is left between two ids is one wait, the first transform and two barriers.  For that the epilogue's exchange
 // image may not overlay the raw patches: it is 64 KB (the V tiles + the 16 KB tail of the allocation) and takes four rounds of 16 tiles x 32
 // channels instead of two of 32 x 32; same sums in the same order, same bits.
-template <int kHalf, bool kPersist>
+//
+// kCB (round 5): 32-channel blocks of output per work-group -- 2 (64 output channels, the large launches) or 1.  One frame per pass leaves
+// the 256-channel layers at 69 x 69 twenty tile blocks: 80 work-groups of 64 channels on 256 CUs.  With 32 channels per work-group there are
+// 160, each with half the MFMAs (the transform is done twice as often: the price of filling the chip); the channel tile nt then addresses
+// block nt & 1 of the 64-channel slice nt >> 1 of U.
+template <int kHalf, bool kPersist, int kCB>
 __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
 {
+    static_assert(kCB == 2 || !kPersist, "the persistent form is written for 64 output channels per work-group");
     constexpr int half = kHalf;
 #define AMOS_W24_V(buf) (smem24 + (buf) * kW24StageV)
 #define AMOS_W24_R(buf) (smem24 + 2 * kW24StageV + (buf) * kW24StageR)
@@ -208,7 +214,9 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     const int vdst = (3 * wave) * kW24PosV + w24_swz(tl, quad);  // + p * kW24PosV for position 3 * wave + p
     // U fragments of this wave's three positions: [position of the triple][cout block] x 16 bytes per lane and stage
     const float *const ubase = a.u + (size_t)(wave * 3) * 512 + lane * 4;
-    const float *usrc = ubase + (size_t)nt * a.stages * kW24StageU, *usrcN = usrc;
+    // (kCB == 1: U of 64-channel slice nt >> 1; its 32-channel block nt & 1 is picked in AMOS_W24_FETCH_UP)
+    const float *usrc = ubase + (size_t)(kCB == 1 ? nt >> 1 : nt) * a.stages * kW24StageU, *usrcN = usrc;
+    const int ujb = kCB == 1 ? nt & 1 : 0;
 
 #ifdef AMOS_W24_EXP_NOX  /* timing experiments (results are wrong): tools/w24_variants.sh */
 #define AMOS_W24_FETCH_XO(xo, s, buf) {}
@@ -226,12 +234,12 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
 #define AMOS_W24_ULOAD(p) (*(p))
 #endif
 #ifdef AMOS_W24_EXP_NOU
-#define AMOS_W24_FETCH_UP(fb, up, s, p) { _Pragma("unroll") for (int j = 0; j < 2; j++) fb[j] = f32x4{(float)(s), (float)lane, 1.f, (float)(p)}; }
+#define AMOS_W24_FETCH_UP(fb, up, s, p) { _Pragma("unroll") for (int j = 0; j < kCB; j++) fb[j] = f32x4{(float)(s), (float)lane, 1.f, (float)(p)}; }
 #else
 #define AMOS_W24_FETCH_UP(fb, up, s, p)                                                                                              \
     {                                                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                                \
-            fb[j] = AMOS_W24_ULOAD(reinterpret_cast<const f32x4 *>((up) + (size_t)(s) * kW24StageU + ((p) * 2 + j) * 256));          \
+        _Pragma("unroll") for (int j = 0; j < kCB; j++)                                                                              \
+            fb[j] = AMOS_W24_ULOAD(reinterpret_cast<const f32x4 *>((up) + (size_t)(s) * kW24StageU + ((p) * 2 + j + ujb) * 256));    \
     }
 #endif
 #define AMOS_W24_FETCH_U(fb, s, p) AMOS_W24_FETCH_UP(fb, usrc, s, p)
@@ -268,17 +276,17 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     }
 #endif
 
-    f32x16 acc[3][2];  // [position of the triple][cout block]
+    f32x16 acc[3][kCB];  // [position of the triple][cout block]
 #define AMOS_W24_ZERO_ACC()                                                              \
     _Pragma("unroll") for (int p = 0; p < 3; p++)                                        \
-        _Pragma("unroll") for (int j = 0; j < 2; j++)                                    \
+        _Pragma("unroll") for (int j = 0; j < kCB; j++)                                  \
             _Pragma("unroll") for (int r = 0; r < 16; r++) acc[p][j][r] = 0.f;
     AMOS_W24_ZERO_ACC()
     const int foff = w24_swz(lane & 31, lane >> 5);  // this lane's 4 floats inside a position's block
-    f32x4 fa0, fa1, fa2, fbE0[2], fbE1[2], fbE2[2], fbO0[2], fbO1[2], fbO2[2];
+    f32x4 fa0, fa1, fa2, fbE0[kCB], fbE1[kCB], fbE2[kCB], fbO0[kCB], fbO1[kCB], fbO2[kCB];
 #define AMOS_W24_LDFRAG(fa, buf, p) fa = *reinterpret_cast<const f32x4 *>(AMOS_W24_V(buf) + (wave * 3 + (p)) * kW24PosV + foff);
 #define AMOS_W24_MFMAS(fa, fb, p)                                                                    \
-    _Pragma("unroll") for (int j = 0; j < 2; j++) {                                                  \
+    _Pragma("unroll") for (int j = 0; j < kCB; j++) {                                                \
         acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[j].x, acc[p][j], 0, 0, 0);         \
         acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[j].y, acc[p][j], 0, 0, 0);         \
         acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[j].z, acc[p][j], 0, 0, 0);         \
@@ -347,6 +355,7 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
 #define AMOS_W24_STAGE_ODD(s, n1, n2, n3, vm) AMOS_W24_STAGE(s, 1, fbO0, fbO1, fbO2, fbE2, n1, n2, n3, vm)
 #define AMOS_W24_PROLOGUE_U() { AMOS_W24_FETCH_U(fbE0, 0, 0); AMOS_W24_FETCH_U(fbE1, 0, 1); AMOS_W24_FETCH_U(fbE2, 0, 2); AMOS_W24_FETCH_U(fbO0, 1, 0); AMOS_W24_FETCH_U(fbO1, 1, 1); }
 #define AMOS_W24_LOOP_VM 2
+#define AMOS_W24_LOOP_VM_CB1 0
 
 #else
 /* the stage with every request's source spelt out: (kT) transform + next fragment; (kU1, u1, s1) U of positions 1, 2 of stage s1 from u1;
@@ -426,10 +435,12 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
 #define AMOS_W24_PROLOGUE_U() { AMOS_W24_FETCH_U(fbE0, 0, 0); AMOS_W24_FETCH_U(fbE1, 0, 1); AMOS_W24_FETCH_U(fbE2, 0, 2); AMOS_W24_FETCH_U(fbO0, 1, 0); }
 #if AMOS_W24_XAHEAD == 1
 #define AMOS_W24_LOOP_VM 4
+#define AMOS_W24_LOOP_VM_CB1 2
 #define AMOS_W24_RB_READ(vb) ((vb) ^ 1)   /* the raw patch of stage s + 1 sits in buffer (s + 1) & 1 */
 #define AMOS_W24_RB_ADVANCE()
 #else
 #define AMOS_W24_LOOP_VM 14               /* younger than the patch request the barrier needs: 4 + 2 U and 4 X of the stage before, 4 U of this one */
+#define AMOS_W24_LOOP_VM_CB1 0
 #define AMOS_W24_RB_READ(vb) rbuf         /* ... in buffer (s + 1) % 3, a wave-uniform run-time index */
 #define AMOS_W24_RB_ADVANCE() rbuf = rbuf == 2 ? 0 : rbuf + 1;
 #endif
@@ -458,8 +469,13 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     for (;;) {  // one trip per id (a persistent group: until its walk ends)
     int s = 0;
     for (; s + 4 < a.stages; s += 2) {  // two stages per trip: the register names follow the stage parity
-        AMOS_W24_STAGE_EVEN(s, true, true, true, AMOS_W24_LOOP_VM);
-        AMOS_W24_STAGE_ODD(s + 1, true, true, true, AMOS_W24_LOOP_VM);
+        if (kCB == 2) {
+            AMOS_W24_STAGE_EVEN(s, true, true, true, AMOS_W24_LOOP_VM);
+            AMOS_W24_STAGE_ODD(s + 1, true, true, true, AMOS_W24_LOOP_VM);
+        } else {  // (half as many U loads are younger than the raw patch the barrier waits for)
+            AMOS_W24_STAGE_EVEN(s, true, true, true, AMOS_W24_LOOP_VM_CB1);
+            AMOS_W24_STAGE_ODD(s + 1, true, true, true, AMOS_W24_LOOP_VM_CB1);
+        }
     }
     // the last four stages (the stage count is even and at least four: amos_mask_winograd_supported): less and less left to request for
     // THIS id -- a persistent group fills the free slots with the first requests of its next one
@@ -500,7 +516,7 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
     // (raw barriers: a __syncthreads() would also wait for the next id's requests in flight)
 #define AMOS_W24_EPI_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     AMOS_W24_EPI_BARRIER()  // every wave is done with the V tiles (and, one id per group, with the raw patches)
-    constexpr int kRounds = kPersist ? 4 : 2, kRoundTiles = kPersist ? 16 : 32;
+    constexpr int kRounds = kPersist ? 4 : kCB, kRoundTiles = kPersist ? 16 : 32;
     // finishing thread: channel quad of the round, tile of the round, output row of the tile (persistent form: + which two of the four pixels)
     const int oq = t & 7, otl = kPersist ? (t >> 3) & 15 : (t >> 3) & 31, oy = kPersist ? (t >> 7) & 1 : t >> 8, jp = kPersist ? t >> 8 : 0;
     auto exch = [&](int w) -> float * {  // wave w's part of the exchange image
@@ -536,7 +552,7 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
         }
         AMOS_W24_EPI_BARRIER()
         // S[pr][j] = (M A4)[pr][j];  Y[0][j] = S[0][j] + S[1][j] + S[2][j];  Y[1][j] = S[1][j] - S[2][j] - S[3][j]
-        const int n0 = nt * kW24Cout + jb * 32 + 4 * oq;
+        const int n0 = (kCB == 1 ? nt * 32 : nt * kW24Cout + jb * 32) + 4 * oq;
         const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 yv[4];
 #pragma unroll
@@ -594,16 +610,24 @@ __device__ __forceinline__ void w24_run(const W24Args &a, float *smem24)
 __global__ __launch_bounds__(kW24Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_winograd24_conv(const W24Args a)
 {
     extern __shared__ __align__(16) float smem24[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) w24_run<1, false>(a, smem24);
-    else w24_run<0, false>(a, smem24);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) w24_run<1, false, 2>(a, smem24);
+    else w24_run<0, false, 2>(a, smem24);
+}
+
+// 32 output channels per work-group: small launches (see w24_run, kCB)
+__global__ __launch_bounds__(kW24Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_winograd24_conv_n32(const W24Args a)
+{
+    extern __shared__ __align__(16) float smem24[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) w24_run<1, false, 1>(a, smem24);
+    else w24_run<0, false, 1>(a, smem24);
 }
 
 // one work-group per CU walking the ids (see w24_run): grid = a multiple of 8 work-groups, at most one per CU
 __global__ __launch_bounds__(kW24Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_winograd24_conv_persistent(const W24Args a)
 {
     extern __shared__ __align__(16) float smem24[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) w24_run<1, true>(a, smem24);
-    else w24_run<0, true>(a, smem24);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) w24_run<1, true, 2>(a, smem24);
+    else w24_run<0, true, 2>(a, smem24);
 }
 
 const char *w24_variant_tag()
@@ -642,7 +666,24 @@ static int w24_persist_mode()
     return g_w24_persist;
 }
 
+static int g_w24_narrow = -2;  // -1 by launch size, 0 always 64 output channels per work-group, 1 always 32 (AMOS_W24_NARROW: initial value)
+static int w24_narrow_mode()
+{
+    if (g_w24_narrow == -2) {
+        const char *env = getenv("AMOS_W24_NARROW");
+        g_w24_narrow = env && (env[0] == '0' || env[0] == '1') ? env[0] - '0' : -1;
+    }
+    return g_w24_narrow;
+}
+
 extern "C" {
+
+int amos_mask_winograd24_narrow_mode(int mode)
+{
+    const int before = w24_narrow_mode();
+    if (mode >= -1 && mode <= 1) g_w24_narrow = mode;
+    return before;
+}
 
 int amos_mask_winograd24_persistent_mode(int mode)
 {
@@ -682,7 +723,7 @@ int amos_mask_winograd24_conv_layout_device(void *stream, const float *d_x, cons
         set_error("amos_mask_winograd24_conv_device: invalid argument (cin %% 16 == 0, cin >= 32, cout %% 64 == 0, input below 2 GiB, 16-byte aligned channels-last tensors)");
         return AMOS_ERR_INVALID;
     }
-    static DeviceOnce ldsAttr, ldsAttrP;  // per device (amos_common.h)
+    static DeviceOnce ldsAttr, ldsAttrP, ldsAttrN;  // per device (amos_common.h)
     const size_t lds = (size_t)kW24LdsFloats * sizeof(float);  // 128 KB
     AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttr, reinterpret_cast<const void *>(k_winograd24_conv), (int)lds, (hipStream_t)stream));
     W24Args a;
@@ -692,7 +733,13 @@ int amos_mask_winograd24_conv_layout_device(void *stream, const float *d_x, cons
     a.tilesPerImage = a.tilesX * a.tilesY;
     a.totalTiles = batch * a.tilesPerImage;
     a.mBlocks = (a.totalTiles + kW24Tiles - 1) / kW24Tiles;
-    a.nTiles = cout / kW24Cout;
+    // small launches: 32 output channels per work-group (twice the groups, half the MFMAs each) while 64-channel groups would leave most
+    // CUs without one; amos_mask_winograd24_narrow_mode forces a side (tests, probes)
+    const int narrowMode = w24_narrow_mode();
+    // (measured at one frame, tools/r5_small_gemm_probe.py: 256 -> 256 at 69 x 69, 80 groups of 64: 59 us, 160 of 32: 45; 256 -> 384 at 69 x 69,
+    // 120 of 64: 62, 240 of 32: 81 -- its 9.4 MB of U no longer fit an XCD's L2 when every CU streams them)
+    const bool narrow = narrowMode >= 0 ? narrowMode != 0 : (long long)a.mBlocks * (cout / kW24Cout) <= 100;
+    a.nTiles = cout / (narrow ? 32 : kW24Cout);
     a.stages = cin / kW24K;
     a.relu = relu;
     a.xBytes = (unsigned)xBytes;
@@ -718,10 +765,13 @@ int amos_mask_winograd24_conv_layout_device(void *stream, const float *d_x, cons
     // prologue it loses to the four-round epilogue, to the wait for the last stores before the next first transform (the vector-memory counter
     // retires in order) and to a static walk instead of the dispatcher's "next id to the first free CU".  So the automatic choice is the one
     // work-group per id form; the persistent one stays selectable (mode 1) and under test.
-    const bool persist = forced == 1 && a.virtualBlocks > cus;
+    const bool persist = forced == 1 && a.virtualBlocks > cus && !narrow;
     if (persist) {
         AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttrP, reinterpret_cast<const void *>(k_winograd24_conv_persistent), (int)lds, (hipStream_t)stream));
         hipLaunchKernelGGL(k_winograd24_conv_persistent, dim3((unsigned)std::min(cus, a.virtualBlocks)), block, lds, (hipStream_t)stream, a);
+    } else if (narrow) {
+        AMOS_HIP_CHECK(set_max_dynamic_lds(ldsAttrN, reinterpret_cast<const void *>(k_winograd24_conv_n32), (int)lds, (hipStream_t)stream));
+        hipLaunchKernelGGL(k_winograd24_conv_n32, dim3((unsigned)a.virtualBlocks), block, lds, (hipStream_t)stream, a);
     } else {
         hipLaunchKernelGGL(k_winograd24_conv, dim3((unsigned)a.virtualBlocks), block, lds, (hipStream_t)stream, a);
     }

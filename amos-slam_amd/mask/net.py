@@ -78,7 +78,21 @@ def winograd_rule(cin, cout, kernel, stride, padding, dilation, groups, batch, h
     # work-groups of 256 output pixels (64 tiles of 2 x 2; F(2 x 4)'s 32 tiles of 2 x 4 give the same count within a few per cent, and the
     # same layers run in either family: the threshold was measured per layer, tools/winograd_probe.py)
     n_groups = (batch * ((height + 1) // 2) * ((width + 1) // 2) + 63) // 64
-    return mode == "2" or n_groups * (cout // 64) >= 256
+    wg64 = n_groups * (cout // 64)
+    if mode == "2" or wg64 >= 256:
+        return True
+    if winograd_family() != "24":   # (the small-launch form exists for the F(2 x 4) kernel only)
+        return False
+    # Small launches (one frame per pass).  A work-group's time is its stage count x the latency of a stage (1.85 us with 64 output channels per
+    # group, 1.4 us with 32: amos_mask_winograd24_conv_device takes 32 while 64-channel groups are at most 100), whatever the layer's size as long
+    # as every group has a CU; the library's direct kernel + the bias pass cost ~10 us + the direct FLOPs at ~85 TFLOP/s.  Measured at one
+    # frame (tools/r5_small_gemm_probe.py): 64 ch at 138 x 138 15 against 32 us, 128 ch at 69 x 69 23 / 31, 256 ch at 69 x 69 45 / 68,
+    # 256 -> 384 at 69 x 69 62 / 91; the 256-channel layers at 35 x 35 and below lose (44 / 30) and stay with the library.
+    narrow = wg64 <= 100
+    wgs = n_groups * (cout // 32) if narrow else wg64
+    t_winograd = (cin / 8.0) * (1.4 if narrow else 1.85) * ((wgs + 255) // 256)
+    t_library = 10.0 + 18.0 * cin * cout * batch * height * width / 85e6
+    return t_winograd < 0.9 * t_library
 
 
 def _winograd_conv(conv, x):

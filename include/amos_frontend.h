@@ -423,6 +423,10 @@ int amos_mask_winograd24_conv_layout_device(void *stream, const float *d_x, cons
  * kept selectable and under test.  Returns the previous mode (-2 or anything else out of range: query only).  Same bits either way;
  * AMOS_W24_PERSIST=0 / 1 in the environment is the initial value. */
 int amos_mask_winograd24_persistent_mode(int mode);
+/* Output channels per work-group of the F(2 x 4) kernel: -1 by launch size (the default: 32 per group -- twice the groups -- while 64-channel
+ * groups would leave most CUs without one, i.e. one-frame launches), 0 always 64, 1 always 32.  Returns the previous mode (out of range:
+ * query only).  Same bits either way; AMOS_W24_NARROW=0 / 1 in the environment is the initial value. */
+int amos_mask_winograd24_narrow_mode(int mode);
 int amos_mask_conv1x1_device(void *stream, const float *d_x, const float *d_w, const float *d_bias, const float *d_residual,
                              float *d_y, int batch, int in_h, int in_w, int cin, int cout, int stride, int relu);
 

@@ -209,12 +209,16 @@ def test_winograd_rule(mask, pkg, monkeypatch):
     rule = lambda cin, cout, b, hw, k=(3, 3), s=(1, 1), p=(1, 1): net_mod.winograd_rule(cin, cout, k, s, p, (1, 1), 1, b, hw, hw)
     monkeypatch.delenv("AMOS_MASK_WINOGRAD", raising=False)
     assert rule(256, 256, 32, 138) and rule(256, 384, 32, 69) and rule(64, 64, 32, 138) and rule(512, 512, 32, 18) and rule(256, 256, 1, 138)
-    assert not rule(256, 256, 1, 69)                    # 20 x 4 work-groups: too small a launch for one per CU
+    # one frame per pass: the layers whose stage count x stage latency beats the library's direct kernel + bias pass (32 output channels per
+    # work-group where 64-channel groups would be few) ...
+    assert rule(256, 256, 1, 69) and rule(256, 384, 1, 69) and rule(128, 128, 1, 69) and rule(64, 64, 1, 138)
+    # ... and the ones that stay with the library: 32 or 64 stages of latency for a few GFLOP
+    assert not rule(256, 256, 1, 35) and not rule(256, 384, 1, 35) and not rule(512, 512, 1, 18) and not rule(256, 256, 1, 18) and not rule(256, 256, 1, 9)
     assert not rule(256, 256, 32, 138, s=(2, 2)) and not rule(256, 256, 32, 138, k=(1, 1), p=(0, 0)) and not rule(256, 256, 32, 138, p=(0, 0))
     assert not rule(256, 352, 32, 69) and not rule(24, 64, 32, 138) and not rule(16, 64, 32, 138)   # channel counts the kernel does not take
     assert not rule(2048, 64, 64, 138)                  # input of 2 GiB and more: the buffer descriptor's range
     monkeypatch.setenv("AMOS_MASK_WINOGRAD", "2")
-    assert rule(256, 256, 1, 69) and not rule(256, 352, 1, 69)
+    assert rule(256, 256, 1, 35) and not rule(256, 352, 1, 69)
     monkeypatch.setenv("AMOS_MASK_WINOGRAD", "0")
     assert not rule(256, 256, 32, 138)
     assert pkg.mask_winograd_supported(32, 64) and not pkg.mask_winograd_supported(8, 64)
@@ -633,7 +637,7 @@ def test_winograd_conv3x3_against_float64(mask, gpu_lib, family):
                                         (G4, 24, gpu_lib.mask_winograd24_weights, gpu_lib.mask_winograd24_conv))
     worst = 0.0
     # F(2 x 4): both launch forms (one work-group per id / the persistent walk), forced in turn; every output of the second form must equal the first's
-    forms = (0, 1) if family == "24" else (None,)
+    forms = (0, 1) if family == "24" else (None,)   # (the 32-channel-per-group form is held to the same bound and the same bits further down)
     for b, cin, cout, h, w in ((1, 32, 64, 6, 6), (2, 64, 64, 21, 17), (1, 32, 128, 9, 9), (3, 256, 64, 5, 5), (3, 48, 192, 12, 7), (2, 32, 64, 1, 1),
                                (1, 64, 128, 2, 37), (5, 80, 64, 7, 3), (40, 32, 64, 2, 4), (70, 32, 64, 2, 2), (3, 32, 64, 1, 1), (2, 128, 256, 35, 35), (1, 256, 384, 69, 69),
                                (2, 32, 64, 3, 130), (1, 32, 64, 9, 127), (33, 32, 64, 4, 1),
@@ -688,6 +692,44 @@ def test_winograd_conv3x3_against_float64(mask, gpu_lib, family):
     big, small = torch.empty(32, 64, 69, 69, device="meta"), torch.empty(1, 64, 35, 35, device="meta")
     assert net_mod._winograd_conv(conv, big) and not net_mod._winograd_conv(conv, small)
     assert not net_mod._winograd_conv(torch.nn.Conv2d(64, 128, 3, padding=1, stride=2), big) and not net_mod._winograd_conv(torch.nn.Conv2d(64, 100, 3, padding=1), big)
+
+
+@pytest.mark.gpu
+def test_winograd24_32_channels_per_work_group(mask, gpu_lib):
+    """The F(2 x 4) kernel's small-launch form (32 output channels per work-group: twice the groups, channel tile nt = block nt & 1 of U's
+    64-channel slice nt >> 1) forced on and off: the same bits as the 64-channel form on one-frame and multi-frame shapes, every epilogue
+    combination, cout = 64 (one slice) to 384 (an odd number of 64-slices x 2); and the automatic choice picks it for one-frame launches."""
+    F = torch.nn.functional
+    cl = torch.channels_last
+    torch.manual_seed(23)
+    st = torch.cuda.current_stream().cuda_stream
+    assert gpu_lib.mask_winograd24_narrow_mode() == -1
+    for b, cin, cout, h, w in ((1, 256, 256, 69, 69), (1, 64, 64, 138, 138), (1, 256, 384, 69, 69), (3, 128, 128, 33, 35), (2, 32, 64, 9, 7), (1, 48, 192, 5, 5)):
+        x = torch.randn(b, cin, h, w, device="cuda").contiguous(memory_format=cl)
+        wgt = (torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5).contiguous(memory_format=cl)
+        bias = torch.randn(cout, device="cuda")
+        res = torch.randn(b, cout, h, w, device="cuda").contiguous(memory_format=cl)
+        u = torch.empty(24 * cin * cout, device="cuda")
+        gpu_lib.mask_winograd24_weights(st, wgt.data_ptr(), u.data_ptr(), cin, cout)
+        exact = F.conv2d(x.double(), wgt.double(), None, 1, 1)
+        bound = 1e-5 * F.conv2d(x.double().abs(), wgt.double().abs(), None, 1, 1) + 1e-6
+        for use_bias, use_res, relu in ((True, True, True), (False, False, False), (True, False, True)):
+            ys = {}
+            for mode in (0, 1, -1):
+                gpu_lib.mask_winograd24_narrow_mode(mode)
+                try:
+                    y = torch.full((b, cout, h, w), float("nan"), device="cuda").contiguous(memory_format=cl)
+                    gpu_lib.mask_winograd24_conv(st, x.data_ptr(), u.data_ptr(), bias.data_ptr() if use_bias else None, res.data_ptr() if use_res else None,
+                                                 y.data_ptr(), b, h, w, cin, cout, relu)
+                    torch.cuda.synchronize()
+                finally:
+                    gpu_lib.mask_winograd24_narrow_mode(-1)
+                ys[mode] = y
+            want = exact + (bias.double().view(1, -1, 1, 1) if use_bias else 0) + (res.double() if use_res else 0)
+            if relu:
+                want = want.relu()
+            assert bool(((ys[1].double() - want).abs() <= bound).all()), (b, cin, cout, h, w)
+            assert torch.equal(ys[0], ys[1]) and torch.equal(ys[-1], ys[0]), (b, cin, cout, h, w, use_bias, use_res, relu)
 
 
 @pytest.mark.gpu
@@ -907,7 +949,11 @@ def test_bias_relu_maxpool_kernel_equals_the_torch_ops(mask, gpu_lib):
 def test_fused_head_outputs_equal_the_torch_ops(mask, gpu_lib, monkeypatch):
     """The prediction head's fused output path (amos_mask_head_outputs_device: bias + reshape + concatenation + softmax / tanh in one
     kernel per level) against the torch form on the same weights and pyramid: box regressions bit for bit, class scores to float32
-    rounding of the softmax sum, coefficients within 2 ulp (MIOpen may pick another solver for the two calls, hence allclose too)."""
+    rounding of the softmax sum, coefficients within 2 ulp -- of the same convolution output.  The two forms do not run the same convolution
+    kernels: the fused form convolves with the merged 384-channel layer (Winograd F(2x4) at the 69 x 69 and 35 x 35 levels of this
+    two-frame batch since the round-5 small-launch rule), the torch form with the three separate layers (12 / 243 / 96 channels: library
+    kernels), so the comparison carries the Winograd kernel's float32 bound (5e-7 of the sum of |terms|; 3.2e-6 measured on these layers
+    against float64) on top; the kernel alone is checked bit for bit below."""
     net_mod = importlib.import_module("amos_slam_amd.mask.net")
     torch.manual_seed(16)
     cl = torch.channels_last
@@ -924,8 +970,8 @@ def test_fused_head_outputs_equal_the_torch_ops(mask, gpu_lib, monkeypatch):
         locs, confs, coefs = zip(*(head(p) for p in pyramid))
         want_loc, want_conf, want_coef = torch.cat(locs, 1), torch.softmax(torch.cat(confs, 1), -1), torch.cat(coefs, 1)
     assert loc.shape == want_loc.shape == (2, P, 4) and conf.shape == (2, P, 81) and coef.shape == (2, P, 32)
-    assert torch.allclose(loc, want_loc, rtol=1e-5, atol=1e-6) and torch.allclose(coef, want_coef, rtol=1e-5, atol=1e-6)
-    assert torch.allclose(conf, want_conf, rtol=1e-5, atol=1e-8) and torch.allclose(conf.sum(-1), torch.ones_like(conf[..., 0]), atol=1e-5)
+    assert torch.allclose(loc, want_loc, rtol=1e-5, atol=1e-5) and torch.allclose(coef, want_coef, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(conf, want_conf, rtol=5e-5, atol=1e-8) and torch.allclose(conf.sum(-1), torch.ones_like(conf[..., 0]), atol=1e-5)
     # the kernel alone on one raw tensor: exact for box / coefficient channels
     raw = torch.randn(2, 352, 7, 5, device="cuda").contiguous(memory_format=cl)
     bias = torch.randn(352, device="cuda")
@@ -1132,14 +1178,14 @@ def test_bench_sized_pass_winograd_against_direct_kernels(mask, gpu_lib, monkeyp
         out[mode] = ({k: pred[k] for k in ("loc", "conf", "mask", "proto")}, eng.eval_net_input_batch(x, chunk=fpf))
         del pred, x
         torch.cuda.synchronize()
-    # per forward at 32 frames: 13 bottleneck conv2, the FPN prediction layers and the head's two convolutions at 69 x 69 and 35 x 35 (the
-    # 18 x 18 launches have fewer than 256 work-groups), 4 protonet layers; at 64 frames the 18 x 18 launches qualify too.  Two forwards
-    # in this mode (_forward and eval_net_input_batch)
+    # per forward: 13 bottleneck conv2, the FPN prediction layers and the head's two convolutions at 69 x 69 and 35 x 35, 4 protonet layers,
+    # and the 18 x 18 layers (round 5: launches of fewer than 256 work-groups go by the rule's stage-latency estimate).  Two forwards in this
+    # mode (_forward and eval_net_input_batch)
     base = 2 * (13 + 2 + 4 + 4)
     assert all(c[0] == fpf for c in calls), sorted({c[0] for c in calls})
-    assert (len(calls) == base) if fpf == 32 else (len(calls) > base and len(calls) % 2 == 0), len(calls)
-    if fpf > 32:
-        assert any(c[1] == 18 and c[2] == 18 for c in calls), "the 18 x 18 layers are expected on the Winograd kernel at this launch size"
+    assert len(calls) > base and len(calls) % 2 == 0, len(calls)
+    # (the 18 x 18 layers: 164 work-groups at 32 frames, 324 at 64 -- below / above one per CU; both sides of the rule's small-launch clause)
+    assert any(c[1] == 18 and c[2] == 18 for c in calls), "the 18 x 18 layers are expected on the Winograd kernel at this launch size"
     for k in ("loc", "conf", "mask", "proto"):
         a, b = out["1"][0][k], out["0"][0][k]
         assert bool(torch.isfinite(a).all()) and float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1.0), k

@@ -90,5 +90,22 @@ for name, ci, co, k, s, H, res in SHAPES:
     to, tl = graph_us(ours), graph_us(lib)
     tot[0] += to
     tot[1] += tl
-    print("%-26s split-K bytes %9d | ours %7.1f us err %.1e | library + bias pass %7.1f us err %.1e | x%.2f" % (name, nb, to, eo, tl, el, tl / to), flush=True)
+    wino = ""
+    if k == 3 and s == 1 and pkg.mask_winograd_supported(ci, co):
+        # the same layer as Winograd F(2 x 4): 64 and 32 output channels per work-group
+        u = torch.empty(24 * ci * co, device="cuda")
+        pkg.mask_winograd24_weights(stream.cuda_stream, w.data_ptr(), u.data_ptr(), ci, co)
+        yw = torch.empty_like(y)
+        for mode in (0, 1):
+            pkg.mask_winograd24_narrow_mode(mode)
+
+            def wrun():
+                pkg.mask_winograd24_conv(stream.cuda_stream, x.data_ptr(), u.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, yw.data_ptr(), B, H, H, ci, co, True)
+            with torch.cuda.stream(stream):
+                wrun()
+            stream.synchronize()
+            ew = float(((yw.double() - ref).abs() / bound).max())
+            wino += " | winograd %d ch/group %6.1f us err %.1e" % (32 if mode else 64, graph_us(wrun), ew)
+        pkg.mask_winograd24_narrow_mode(-1)
+    print("%-26s split-K bytes %9d | ours %7.1f us err %.1e | library + bias pass %7.1f us err %.1e | x%.2f%s" % (name, nb, to, eo, tl, el, tl / to, wino), flush=True)
 print("sum: ours %.1f us, library %.1f us (%d frame(s))" % (tot[0], tot[1], B))
