@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_flow_fundamental_score_device", "amos_flow_pnp_score_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_workspace_bytes", "amos_mask_conv_ws_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_corners_create", "amos_corners_destroy", "amos_corners_stream", "amos_corners_good_features_device", "amos_corners_candidate_count", "amos_corners_subpix_device", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_winograd24_weight_floats", "amos_mask_winograd24_weights_device", "amos_mask_winograd24_conv_device", "amos_mask_winograd24_conv_layout_device", "amos_mask_winograd24_persistent_mode", "amos_mask_winograd24_narrow_mode", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_topk_rows_device", "amos_mask_topk_rows_sparse_device", "amos_mask_post_workspace_bytes", "amos_mask_person_masks_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_flow_fundamental_score_device", "amos_flow_pnp_score_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_stem_weight_floats", "amos_mask_stem_weights_device", "amos_mask_stem_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_workspace_bytes", "amos_mask_conv_ws_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_corners_create", "amos_corners_destroy", "amos_corners_stream", "amos_corners_good_features_device", "amos_corners_candidate_count", "amos_corners_subpix_device", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_winograd24_weight_floats", "amos_mask_winograd24_weights_device", "amos_mask_winograd24_conv_device", "amos_mask_winograd24_conv_layout_device", "amos_mask_winograd24_persistent_mode", "amos_mask_winograd24_narrow_mode", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_topk_rows_device", "amos_mask_topk_rows_sparse_device", "amos_mask_post_workspace_bytes", "amos_mask_person_masks_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -467,6 +467,26 @@ def mask_bias_relu_maxpool(stream_ptr, x_ptr, bias_ptr, y_ptr, n, in_h, in_w, ch
     """amos_mask_bias_relu_maxpool_device: max_pool2d(relu(x + bias), 3, 2, 1) of an NHWC float32 tensor in one pass (device pointers)."""
     _check(lib().amos_mask_bias_relu_maxpool_device(C.c_void_p(stream_ptr), C.c_void_p(x_ptr), C.c_void_p(bias_ptr), C.c_void_p(y_ptr), C.c_int(n), C.c_int(in_h),
                                                     C.c_int(in_w), C.c_int(channels)), "amos_mask_bias_relu_maxpool_device")
+
+
+def mask_stem_weight_floats():
+    return int(lib().amos_mask_stem_weight_floats())
+
+
+def mask_stem_weights(stream_ptr, w_ptr, w_strides, packed_ptr):
+    """amos_mask_stem_weights_device: the [64][3][7][7] stem weight (element strides: out channel, in channel, row, column) -> the kernel's layout."""
+    sn, sc, sy, sx = (int(v) for v in w_strides)
+    _check(lib().amos_mask_stem_weights_device(C.c_void_p(stream_ptr), C.c_void_p(w_ptr), C.c_longlong(sn), C.c_longlong(sc), C.c_longlong(sy), C.c_longlong(sx),
+                                               C.c_void_p(packed_ptr)), "amos_mask_stem_weights_device")
+
+
+def mask_stem(stream_ptr, x_ptr, x_strides, packed_ptr, bias_ptr, y_ptr, batch, height, width):
+    """amos_mask_stem_device: conv 7 x 7 / 2 (3 -> 64) + bias + ReLU + max-pool 3 x 3 / 2 in one kernel; x float32 [batch][3][height][width]
+    through its element strides, y channels-last [batch][ph][pw][64] (device pointers)."""
+    sb, sc, sy, sx = (int(v) for v in x_strides)
+    _check(lib().amos_mask_stem_device(C.c_void_p(stream_ptr), C.c_void_p(x_ptr), C.c_longlong(sb), C.c_longlong(sc), C.c_longlong(sy), C.c_longlong(sx),
+                                       C.c_void_p(packed_ptr), C.c_void_p(bias_ptr), C.c_void_p(y_ptr), C.c_int(batch), C.c_int(height), C.c_int(width)),
+           "amos_mask_stem_device")
 
 
 def mask_conv1x1_supported(cin, cout, stride):

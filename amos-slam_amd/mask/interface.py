@@ -9,7 +9,7 @@ import os
 import torch
 
 from .detect import detect, detect_batch
-from .net import YolactR50
+from .net import YolactR50, _stem_eligible, stem_kernel_enabled
 from .post import person_mask, person_mask_batch, person_masks_fused
 from .pre import cxx_marshalling, fast_base_transform, resize_f32_cv
 
@@ -57,6 +57,10 @@ class MaskEngine:
             from .net import prepare_winograd_weights
             with torch.cuda.device(self.device):
                 prepare_winograd_weights(self.net)
+        if self.device.type == "cuda":
+            from .net import prepare_stem_weight
+            with torch.cuda.device(self.device):
+                prepare_stem_weight(self.net)  # the stem's 7 x 7 weight in the layout of amos_mask_stem_device
         return self
 
     def _preprocess_hip(self, frames):
@@ -84,7 +88,8 @@ class MaskEngine:
         return out
 
     def _forward(self, x):
-        if self.channels_last:
+        # (the project's stem kernel reads the input through its strides: no layout copy of the network input for it)
+        if self.channels_last and not (self.conv_dtype is None and x.dtype == torch.float32 and stem_kernel_enabled() and _stem_eligible(self.net.backbone.conv1)):
             x = x.contiguous(memory_format=torch.channels_last)
         if self.conv_dtype is None:
             return self.net(x)

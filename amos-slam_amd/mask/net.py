@@ -141,6 +141,38 @@ def _winograd_weight(conv):
     return cached[1]
 
 
+def stem_kernel_enabled():
+    """AMOS_MASK_STEM=library: the stem as the library's convolution + the project's bias / ReLU / max-pool pass (A/B runs, tests); default: the
+    project's one-kernel stem (amos_mask_stem_device)."""
+    return os.environ.get("AMOS_MASK_STEM", "own") != "library"
+
+
+def _stem_weight(conv):
+    """The stem's 7 x 7 weight in amos_mask_stem_device's layout, made on first use and kept on the module like a Winograd weight (same
+    rules: synchronous, never inside a graph capture; MaskEngine.prepare() makes it up front)."""
+    from .. import mask_stem_weight_floats, mask_stem_weights
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device), tuple(w.stride()))
+    cached = getattr(conv, "_amos_stem", None)
+    if cached is None or cached[0] != key:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the stem's packed weight would be created inside a HIP-graph capture: call MaskEngine.prepare() (or "
+                               "prepare_stem_weight) before capture_graph / frame_session, and again after changing weights")
+        packed = torch.empty(mask_stem_weight_floats(), dtype=torch.float32, device=w.device)
+        stream = torch.cuda.current_stream(w.device)
+        mask_stem_weights(stream.cuda_stream, w.data_ptr(), w.stride(), packed.data_ptr())
+        stream.synchronize()
+        cached = (key, packed)
+        object.__setattr__(conv, "_amos_stem", cached)
+    return cached[1]
+
+
+def _stem_eligible(conv):
+    return (conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.in_channels == 3 and conv.out_channels == 64 and conv.bias is not None and conv.weight.is_cuda
+            and conv.weight.dtype == torch.float32)
+
+
 def prepare_winograd_weights(module):
     """Transforms the weights of every convolution of `module` the Winograd kernel can take (3 x 3, stride 1, pad 1, supported channel
     counts -- whether a launch then USES the kernel still depends on its size, winograd_rule) and waits for them: after this no forward
@@ -153,6 +185,16 @@ def prepare_winograd_weights(module):
         if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
                 and conv.weight.is_cuda and conv.weight.dtype == torch.float32 and mask_winograd_supported(conv.in_channels, conv.out_channels)):
             _winograd_weight(conv)
+            n += 1
+    return n
+
+
+def prepare_stem_weight(module):
+    """Packs the stem weight of every ResNet50Trunk of `module` for amos_mask_stem_device (and waits): after this no forward creates it."""
+    n = 0
+    for m in module.modules():
+        if isinstance(m, ResNet50Trunk) and _stem_eligible(m.conv1) and stem_kernel_enabled():
+            _stem_weight(m.conv1)
             n += 1
     return n
 
@@ -315,7 +357,18 @@ class ResNet50Trunk(nn.Module):
 
     def forward(self, x):
         cl = torch.channels_last
-        if self.conv1.bias is not None and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
+        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and x.dim() == 4 and x.shape[1] == 3 and x.shape[0] <= 65535
+                and _stem_eligible(self.conv1) and stem_kernel_enabled()):
+            # convolution + bias + ReLU + max-pool as ONE kernel of this project: the input through its strides (planar as the pre-processing
+            # writes it, or channels-last), the 275 x 275 x 64 convolution output never in memory
+            from .. import mask_stem
+            b, _, h, w = x.shape
+            ch, cw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            y = torch.empty((b, 64, (ch - 1) // 2 + 1, (cw - 1) // 2 + 1), dtype=torch.float32, device=x.device, memory_format=cl)
+            mask_stem(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.stride(), _stem_weight(self.conv1).data_ptr(), self.conv1.bias.data_ptr(),
+                      y.data_ptr(), b, h, w)
+            x = y
+        elif self.conv1.bias is not None and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
             # raw convolution, then bias + ReLU + max-pool in one pass of a HIP kernel (bit-identical to the separate passes)
             raw = F.conv2d(x, self.conv1.weight, None, self.conv1.stride, self.conv1.padding)
             if raw.is_contiguous(memory_format=cl) and raw.shape[1] % 4 == 0:

@@ -353,6 +353,20 @@ int amos_mask_bias_act_device(void *stream, float *d_y, const float *d_bias, con
 int amos_mask_bias_relu_maxpool_device(void *stream, const float *d_x, const float *d_bias, float *d_y, int n, int in_h, int in_w,
                                        int channels);
 
+/* The whole stem of the backbone (backbone.py:77-80,129-132: conv1 = Conv2d(3, 64, 7, stride 2, padding 3) with bn1 folded into weight and
+ * bias, ReLU, MaxPool2d(3, stride 2, padding 1)) as ONE kernel on the fp32 MFMA units: the 7 x 7 convolution's output stays in registers /
+ * LDS and only the pooled tensor is written.  x is float32 [batch][3][height][width] addressed through ELEMENT strides (frame, channel, row,
+ * column: planar and channels-last inputs alike); y is channels-last [batch][ph][pw][64] with ch = (height - 1) / 2 + 1, ph = (ch - 1) / 2 + 1
+ * (likewise for the width).  d_packed: the weights as amos_mask_stem_weights_device lays them out (amos_mask_stem_weight_floats() floats)
+ * from a [64][3][7][7] tensor addressed through its element strides (out channel, in channel, row, column).  Sums in float32 in the
+ * MFMA's order (the library's convolution sums in another order: results agree to float32 rounding of a 147-term sum, not bit for bit);
+ * bias + ReLU after the maximum, which is bit-identical to before it.  Replaces F.conv2d + amos_mask_bias_relu_maxpool_device. */
+int amos_mask_stem_weight_floats(void);
+int amos_mask_stem_weights_device(void *stream, const float *d_w, long long stride_n, long long stride_c, long long stride_y, long long stride_x,
+                                  float *d_packed);
+int amos_mask_stem_device(void *stream, const float *d_x, long long stride_b, long long stride_c, long long stride_y, long long stride_x,
+                          const float *d_packed, const float *d_bias, float *d_y, int batch, int height, int width);
+
 /* A convolution of the mask network (yolact.py / backbone.py as amos-slam_amd/mask/net.py restates them: the ResNet-50
  * bottlenecks, the FPN, the prototype network, the prediction heads) on channels-last float32 tensors as one fp32 MFMA
  * (implicit) GEMM with the epilogue of amos_mask_bias_act_device fused:

@@ -946,6 +946,123 @@ def test_bias_relu_maxpool_kernel_equals_the_torch_ops(mask, gpu_lib):
 
 
 @pytest.mark.gpu
+def test_stem_kernel_against_float64(mask, gpu_lib):
+    """amos_mask_stem_device (conv 7 x 7 / 2, 3 -> 64, + bias + ReLU + max-pool 3 x 3 / 2 in one kernel) against the same chain in float64:
+    the network's 550 x 550, sizes that leave partial 6 x 23 blocks in both directions, sizes smaller than one block and than the window,
+    planar and channels-last inputs and weights (the entry point takes strides).  Error bound: 4e-7 of the sum of |terms| of the window
+    the maximum came from (float32 summation of 147 products; the library's convolution is inside the same bound).  Then non-finite input:
+    a NaN must reach exactly the pooled pixels whose windows hold it (the kernel's MFMA steps read one float past every window row; the
+    library's convolution does NOT pass this: it spreads the NaN one window further)."""
+    F = torch.nn.functional
+    torch.manual_seed(21)
+    st = torch.cuda.current_stream().cuda_stream
+    cl = torch.channels_last
+    n_pack = gpu_lib.mask_stem_weight_floats()
+    assert n_pack == 2 * 77 * 64
+    for case, (b, h, w) in enumerate(((2, 550, 550), (1, 97, 131), (3, 64, 48), (1, 7, 9), (2, 1, 1), (1, 3, 200), (1, 189, 5), (1, 551, 93))):
+        x = torch.randn(b, 3, h, w, device="cuda") * 2.0 + 0.3
+        wt = torch.randn(64, 3, 7, 7, device="cuda") / 12.0
+        bias = torch.randn(64, device="cuda") * 0.5
+        if case % 2:
+            x = x.contiguous(memory_format=cl)
+            wt = wt.contiguous(memory_format=cl)
+        packed = torch.empty(n_pack, device="cuda")
+        gpu_lib.mask_stem_weights(st, wt.data_ptr(), wt.stride(), packed.data_ptr())
+        ch, cw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        ph, pw = (ch - 1) // 2 + 1, (cw - 1) // 2 + 1
+        got = torch.full((b, 64, ph, pw), 7.0, device="cuda").contiguous(memory_format=cl)
+        gpu_lib.mask_stem(st, x.data_ptr(), x.stride(), packed.data_ptr(), bias.data_ptr(), got.data_ptr(), b, h, w)
+        torch.cuda.synchronize()
+        conv = F.conv2d(x.double(), wt.double(), bias.double(), 2, 3)
+        want = F.max_pool2d(F.relu(conv), 3, stride=2, padding=1)
+        assert want.shape == got.shape, (b, h, w)
+        terms = F.max_pool2d(F.conv2d(x.double().abs(), wt.double().abs(), bias.double().abs(), 2, 3), 3, stride=2, padding=1)  # >= the winning window's
+        err = float(((got.double() - want).abs() / (terms + 1.0)).max())
+        assert err < 4e-7, (b, h, w, err)
+        # and against the float32 chain the kernel replaces (library convolution + the project's bias / ReLU / max-pool pass): same bound
+        lib = F.max_pool2d(F.relu(F.conv2d(x, wt, bias, 2, 3)), 3, stride=2, padding=1)
+        assert float(((lib.double() - want).abs() / (terms + 1.0)).max()) < 4e-7
+    # a NaN in the input: the same pooled pixels as in torch's chain, everything else unchanged
+    x = torch.randn(1, 3, 60, 120, device="cuda")
+    wt = torch.randn(64, 3, 7, 7, device="cuda") / 12.0
+    bias = torch.randn(64, device="cuda")
+    gpu_lib.mask_stem_weights(st, wt.data_ptr(), wt.stride(), packed.data_ptr())
+    clean = torch.empty((1, 64, 15, 30), device="cuda").contiguous(memory_format=cl)
+    gpu_lib.mask_stem(st, x.data_ptr(), x.stride(), packed.data_ptr(), bias.data_ptr(), clean.data_ptr(), 1, 60, 120)
+    for (c, yy, xx) in ((0, 20, 33), (2, 0, 0), (1, 59, 119), (0, 31, 92)):
+        xn = x.clone()
+        xn[0, c, yy, xx] = float("nan")
+        got = torch.empty_like(clean)
+        gpu_lib.mask_stem(st, xn.data_ptr(), xn.stride(), packed.data_ptr(), bias.data_ptr(), got.data_ptr(), 1, 60, 120)
+        torch.cuda.synchronize()
+        # (the float64 chain on the CPU: the GPU library's own float32 convolution spreads the NaN to a neighbouring column / row of windows --
+        # its padded GEMM multiplies it by zero weights -- 768 instead of 576 pooled values for the first case, measured)
+        want_nan = torch.isnan(F.max_pool2d(F.relu(F.conv2d(xn.cpu().double(), wt.cpu().double(), bias.cpu().double(), 2, 3)), 3, stride=2, padding=1)).cuda()
+        cys, cxs = [cy for cy in range(30) if 2 * cy - 3 <= yy <= 2 * cy + 3], [cx for cx in range(60) if 2 * cx - 3 <= xx <= 2 * cx + 3]
+        n_rows = len({py for py in range(15) for cy in cys if 2 * py - 1 <= cy <= 2 * py + 1})
+        n_cols = len({px for px in range(30) for cx in cxs if 2 * px - 1 <= cx <= 2 * px + 1})
+        assert int(want_nan.sum()) == 64 * n_rows * n_cols and torch.equal(torch.isnan(got), want_nan), (c, yy, xx)
+        assert torch.equal(got[~want_nan], clean[~want_nan])
+    with pytest.raises(gpu_lib.AmosError):
+        gpu_lib.mask_stem(st, x.data_ptr(), x.stride(), packed.data_ptr(), bias.data_ptr(), clean.data_ptr(), 0, 60, 120)
+
+
+@pytest.mark.gpu
+def test_trunk_with_the_stem_kernel_equals_the_library_stem(mask, gpu_lib, monkeypatch):
+    """ResNet50Trunk.forward with the project's stem kernel (the default) against AMOS_MASK_STEM=library (library convolution + the bias /
+    ReLU / max-pool kernel) on the same folded weights: the stem output within float32 rounding of a 147-term sum, for a planar input (what the
+    pre-processing writes) and a channels-last one; the packed weight follows an in-place weight change; no packed weight is made inside a
+    graph capture."""
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    torch.manual_seed(22)
+    cl = torch.channels_last
+    trunk = net_mod.ResNet50Trunk().cuda().eval()
+    with torch.no_grad():
+        for m in trunk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
+    trunk.fold_batch_norms()
+    trunk.to(memory_format=cl)
+    x = torch.randn(2, 3, 550, 550, device="cuda")
+    stem_out = {}
+
+    def hook(_, args):
+        stem_out["x"] = args[0]
+
+    h = trunk.layers[0].register_forward_pre_hook(hook)
+    with torch.no_grad():
+        for mode in ("own", "library"):
+            monkeypatch.setenv("AMOS_MASK_STEM", mode)
+            for inp in (x, x.contiguous(memory_format=cl)):
+                trunk(inp)
+                stem_out[(mode, inp.is_contiguous())] = stem_out.pop("x")
+        ref = stem_out[("library", False)]  # (False: the channels-last input, which is not contiguous in torch's default sense)
+        assert ref.shape == (2, 64, 138, 138) and torch.allclose(ref, stem_out[("library", True)], rtol=1e-5, atol=2e-5)
+        for key in (("own", True), ("own", False)):
+            assert stem_out[key].is_contiguous(memory_format=cl)
+            assert torch.allclose(stem_out[key], ref, rtol=1e-5, atol=2e-5), float((stem_out[key] - ref).abs().max())
+        assert torch.equal(stem_out[("own", True)], stem_out[("own", False)])  # the same sums whatever the input layout
+        # an in-place weight change is followed
+        monkeypatch.setenv("AMOS_MASK_STEM", "own")
+        trunk.conv1.weight.mul_(0.5)
+        trunk(x)
+        half = stem_out.pop("x")
+        monkeypatch.setenv("AMOS_MASK_STEM", "library")
+        trunk(x)
+        assert torch.allclose(half, stem_out.pop("x"), rtol=1e-5, atol=2e-5)
+        # a packed weight is never made inside a capture
+        monkeypatch.setenv("AMOS_MASK_STEM", "own")
+        trunk.conv1.weight.mul_(2.0)
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        with pytest.raises(RuntimeError, match="capture"):
+            with torch.cuda.graph(g, stream=s):
+                trunk(x)
+    h.remove()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_fused_head_outputs_equal_the_torch_ops(mask, gpu_lib, monkeypatch):
     """The prediction head's fused output path (amos_mask_head_outputs_device: bias + reshape + concatenation + softmax / tanh in one
     kernel per level) against the torch form on the same weights and pyramid: box regressions bit for bit, class scores to float32

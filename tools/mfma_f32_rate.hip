@@ -3,6 +3,7 @@
 // amos_conv1x1.hip and MIOpen's fp32 convolutions both level off near 130 TFLOP/s.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float v16f __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void k(float *out, int iters)
 {
@@ -18,13 +19,13 @@ __global__ __launch_bounds__(256) void k(float *out, int iters)
     for (int i = 0; i < 16; i++) s += c0[i] + c1[i] + c2[i] + c3[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
-int main()
+int main(int argc, char **argv)
 {
     float *out;
-    const int blocks = 256 * 2;
+    const int blocks = argc > 1 ? atoi(argv[1]) : 256 * 2;  // 512: two waves per SIMD; 256: one (the same wave issues every MFMA of its SIMD)
     hipMalloc(&out, blocks * 256 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int iters : {2000, 20000, 100000, 400000, 400000}) {
+    for (int iters : {2000, 20000, 100000, 400000}) {
         hipEventRecord(e0);
         hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, out, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
