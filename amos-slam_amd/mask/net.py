@@ -389,6 +389,65 @@ class ResNet50Trunk(nn.Module):
         return outs
 
 
+_SIDE_STREAMS = {}
+
+
+class Branches:
+    """Independent parts of a SMALL pass on side streams.  One frame leaves most of the chip idle in every launch after the first stages (the
+    35 x 35 and smaller layers run 5 - 80 work-groups on 256 CUs) while the pass is a chain of ~150 launches; what does not depend on each other
+    -- the prototype network against the prediction head's five levels, the pyramid's three output convolutions -- can run side by side.  Inside a
+    HIP-graph capture the side streams become parallel branches of the graph (mask/interface.py FrameSession).  Same kernels on the same
+    operands: the same bits as the one-stream pass.  Measured on MI355X, one frame, graph replay: 2.11 -> 1.98 - 2.02 ms with ONE side stream
+    (the default: the pyramid's levels 1 - 4 and their heads there, level 0 + its head + the prototype network on the main stream); with two
+    or three side streams 2.23 - 2.27 ms -- every further branch of a HIP graph costs more than it hides (AMOS_MASK_BRANCH_STREAMS).
+
+    Rules kept here: a side stream starts behind everything queued on the main stream so far (`side(i)`, or continues its own work with
+    fork=False); every tensor that crosses streams is held in `keep` until `join()`, so no block returns to an allocator pool while another
+    stream's queued kernels still read it; `join()` puts the main stream behind all side streams."""
+
+    def __init__(self, device, n=1):
+        self.device = device
+        self.main = torch.cuda.current_stream(device)
+        key = (str(device), self.main.cuda_stream)  # side streams belong to ONE main stream: two lanes never meet on (or capture) the same one
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = []
+        while len(_SIDE_STREAMS[key]) < n:
+            _SIDE_STREAMS[key].append(torch.cuda.Stream(device))
+        self.streams = _SIDE_STREAMS[key][:n]
+        self.used = set()
+        self.keep = []
+
+    def side(self, i, fork=True):
+        """Context of side stream i (with fewer streams than roles: i modulo their number; None -> the main stream itself)."""
+        if i is None:
+            return torch.cuda.stream(self.main)
+        i %= len(self.streams)
+        s = self.streams[i]
+        if fork or i not in self.used:
+            s.wait_stream(self.main)
+        self.used.add(i)
+        return torch.cuda.stream(s)
+
+    def hold(self, *tensors):
+        self.keep.extend(tensors)
+
+    def join(self):
+        for i in sorted(self.used):
+            self.main.wait_stream(self.streams[i])
+        self.used.clear()
+        self.keep = []
+
+
+def branches_for(x):
+    """AMOS_MASK_BRANCHES: 0 never, 1 always (on a GPU), default: passes of at most AMOS_MASK_BRANCH_MAX_BATCH (4) frames."""
+    mode = os.environ.get("AMOS_MASK_BRANCHES", "auto")
+    if mode == "0" or not x.is_cuda:
+        return None
+    if mode != "1" and x.shape[0] > int(os.environ.get("AMOS_MASK_BRANCH_MAX_BATCH", "4")):
+        return None
+    return Branches(x.device, int(os.environ.get("AMOS_MASK_BRANCH_STREAMS", "1")))
+
+
 class FeaturePyramid(nn.Module):
     """yolact.py:265-355 with fpn = {256 features, bilinear, 2 conv downsamples, pad, relu on pred layers}."""
 
@@ -398,7 +457,9 @@ class FeaturePyramid(nn.Module):
         self.pred_layers = nn.ModuleList([nn.Conv2d(FPN_FEATURES, FPN_FEATURES, 3, padding=1) for _ in in_channels])
         self.downsample_layers = nn.ModuleList([nn.Conv2d(FPN_FEATURES, FPN_FEATURES, 3, padding=1, stride=2) for _ in range(2)])
 
-    def forward(self, feats):
+    def forward(self, feats, br=None):
+        """br (Branches): the output convolutions of the deeper levels and the two extra levels run on side streams (level 2 + P6 + P7 on side
+        0, level 1 on side 1, level 0 stays on the caller's stream); the caller joins."""
         n = len(feats)
         merged = [None] * n
         top = None
@@ -408,6 +469,19 @@ class FeaturePyramid(nn.Module):
             up = bilinear(top, size=feats[j].shape[2:]) if top is not None else None
             merged[j] = top = conv_bias_act(lat, feats[j], False, residual=up)
         outs = [None] * n
+        if br is not None and n == 3:
+            br.hold(*merged)
+            with br.side(0):
+                outs[2] = conv_bias_act(self.pred_layers[0], merged[2], True)
+                extra = []
+                for down in self.downsample_layers:
+                    extra.append(down(extra[-1] if extra else outs[2]))
+            with br.side(1, fork=len(br.streams) > 1):  # (one side stream: it continues there, no second dependency on the main stream)
+                outs[1] = conv_bias_act(self.pred_layers[1], merged[1], True)
+            outs[0] = conv_bias_act(self.pred_layers[2], merged[0], True)
+            outs += extra
+            br.hold(*outs)
+            return outs
         for k, pred in enumerate(self.pred_layers):
             j = n - 1 - k
             outs[j] = conv_bias_act(pred, merged[j], True)
@@ -447,36 +521,64 @@ class SharedHead(nn.Module):
             object.__setattr__(self, "merged", merged.requires_grad_(False))
         return self
 
-    def fused_outputs(self, pyramid, n_priors):
+    def fused_applies(self, x0):
+        merged = getattr(self, "merged", None)
+        return not (merged is None or not x0.is_cuda or x0.dtype != torch.float32 or torch.is_autocast_enabled() or os.environ.get("AMOS_MASK_FUSED_HEAD", "1") == "0")
+
+    def fused_outputs(self, pyramid, n_priors, br=None, out=None):
         """All levels' outputs, concatenated, softmax / tanh applied: (loc [B, P, 4], conf [B, P, 81], coef [B, P, 32]), or None when the
         fused path does not apply (no merged layer, not float32 channels-last on the GPU).  Per level: the upfeature convolution, the
         merged output convolution WITHOUT its bias, then ONE HIP kernel (amos_mask_head_outputs_device) that adds the bias, takes the
         softmax and the tanh and writes the level's priors into the three concatenated tensors -- instead of a bias pass, three
-        strided reshape copies per level, three concatenations, a softmax and a tanh pass."""
-        merged = getattr(self, "merged", None)
+        strided reshape copies per level, three concatenations, a softmax and a tanh pass.
+        br (Branches): the levels run on the side streams that made their inputs (FeaturePyramid.forward: levels 2 - 4 on side 0, level 1 on
+        side 1) and level 0 on side 2, so the caller's stream is free for the prototype network; `out` = the three tensors, allocated by the
+        caller BEFORE any side stream started (they are written there and read on the caller's stream after its join)."""
         x0 = pyramid[0]
-        if merged is None or not x0.is_cuda or x0.dtype != torch.float32 or torch.is_autocast_enabled() or os.environ.get("AMOS_MASK_FUSED_HEAD", "1") == "0":
+        if not self.fused_applies(x0):
             return None
+        merged = self.merged
         from .. import mask_head_outputs
         b, dev = x0.shape[0], x0.device
         n_anchor = self.bbox_layer.out_channels // 4
-        loc = torch.empty((b, n_priors, 4), dtype=torch.float32, device=dev)
-        conf = torch.empty((b, n_priors, NUM_CLASSES), dtype=torch.float32, device=dev)
-        coef = torch.empty((b, n_priors, MASK_DIM), dtype=torch.float32, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        off = 0
+        if out is None:
+            if br is not None:
+                raise ValueError("fused_outputs: with side streams the caller allocates the outputs")
+            out = self.alloc_outputs(b, n_priors, dev)
+        loc, conf, coef = out
+        offs, off = [], 0
         for x in pyramid:
+            offs.append(off)
+            off += x.shape[2] * x.shape[3] * n_anchor
+        if off != n_priors:
+            raise ValueError("fused_outputs: %d priors written, %d expected" % (off, n_priors))
+
+        def level(i):
+            x = pyramid[i]
             u = conv_bias_act(self.upfeature[0], x, True)
             raw = conv_raw(merged, u)
             if not raw.is_contiguous(memory_format=torch.channels_last):
                 raw = raw.contiguous(memory_format=torch.channels_last)
             cells = raw.shape[2] * raw.shape[3]
-            mask_head_outputs(stream, raw.data_ptr(), merged.bias.data_ptr(), loc.data_ptr(), conf.data_ptr(), coef.data_ptr(), b, cells, raw.shape[1],
-                              n_anchor, NUM_CLASSES, MASK_DIM, n_priors, off)
-            off += cells * n_anchor
-        if off != n_priors:
-            raise ValueError("fused_outputs: %d priors written, %d expected" % (off, n_priors))
+            mask_head_outputs(torch.cuda.current_stream(dev).cuda_stream, raw.data_ptr(), merged.bias.data_ptr(), loc.data_ptr(), conf.data_ptr(), coef.data_ptr(), b,
+                              cells, raw.shape[1], n_anchor, NUM_CLASSES, MASK_DIM, n_priors, offs[i])
+
+        if br is not None and len(pyramid) == 5:
+            with br.side(2 if len(br.streams) >= 3 else None):  # behind the caller's stream: level 0 was made there
+                level(0)
+            with br.side(1, fork=False):
+                level(1)
+            with br.side(0, fork=False):
+                for i in (2, 3, 4):
+                    level(i)
+        else:
+            for i in range(len(pyramid)):
+                level(i)
         return loc, conf, coef
+
+    def alloc_outputs(self, b, n_priors, dev):
+        return (torch.empty((b, n_priors, 4), dtype=torch.float32, device=dev), torch.empty((b, n_priors, NUM_CLASSES), dtype=torch.float32, device=dev),
+                torch.empty((b, n_priors, MASK_DIM), dtype=torch.float32, device=dev))
 
     def forward(self, x):
         b = x.shape[0]
@@ -567,17 +669,38 @@ class YolactR50(nn.Module):
         """x: [B, 3, 550, 550] normalised RGB.  Returns raw network outputs (before Detect):
         loc [B, P, 4], conf [B, P, 81] (softmax), mask [B, P, 32] (tanh), priors [P, 4], proto [B, 138, 138, 32] (ReLU)."""
         feats = self.backbone(x)[1:]
-        pyramid = self.fpn(feats)
-        pn = self.proto_net  # conv, relu, conv, relu, conv, relu, upsample, relu, conv, relu, conv (+ the final ReLU)
-        p = conv_bias_act(pn[4], conv_bias_act(pn[2], conv_bias_act(pn[0], pyramid[0], True), True), True)
-        p = conv_bias_act(pn[10], conv_bias_act(pn[8], bilinear(p, scale_factor=2, relu=True), True), True)  # pn[6] (upsample) + pn[7] (ReLU) in one pass
-        proto = p.permute(0, 2, 3, 1).contiguous()
         head = self.prediction_layers[0]
-        sizes = tuple(tuple(p.shape[2:]) for p in pyramid)
-        key = (sizes, str(x.device))
-        if key not in self._prior_cache:
-            self._prior_cache[key] = build_priors(sizes, x.device)
-        priors = self._prior_cache[key]
+        pn = self.proto_net  # conv, relu, conv, relu, conv, relu, upsample, relu, conv, relu, conv (+ the final ReLU)
+
+        def prototypes(p3):
+            p = conv_bias_act(pn[4], conv_bias_act(pn[2], conv_bias_act(pn[0], p3, True), True), True)
+            p = conv_bias_act(pn[10], conv_bias_act(pn[8], bilinear(p, scale_factor=2, relu=True), True), True)  # pn[6] (upsample) + pn[7] (ReLU) in one pass
+            return p.permute(0, 2, 3, 1).contiguous()
+
+        def priors_of(pyramid):
+            sizes = tuple(tuple(p.shape[2:]) for p in pyramid)
+            key = (sizes, str(x.device))
+            if key not in self._prior_cache:
+                self._prior_cache[key] = build_priors(sizes, x.device)
+            return self._prior_cache[key]
+
+        br = branches_for(x) if head.fused_applies(feats[0]) and len(feats) == 3 else None
+        if br is not None:
+            # a small pass: the pyramid's side levels and the prediction head on side streams, the prototype network on this one (Branches)
+            sizes = [tuple(f.shape[2:]) for f in feats]
+            for _ in range(2):  # the two extra levels: 3 x 3, stride 2, padding 1
+                sizes.append(((sizes[-1][0] - 1) // 2 + 1, (sizes[-1][1] - 1) // 2 + 1))
+            n_priors = sum(h * w for h, w in sizes) * (head.bbox_layer.out_channels // 4)
+            out = head.alloc_outputs(x.shape[0], n_priors, x.device)  # before any side stream starts
+            pyramid = self.fpn(feats, br)
+            priors = priors_of(pyramid)
+            loc, conf, coef = head.fused_outputs(pyramid, priors.shape[0], br, out)
+            proto = prototypes(pyramid[0])
+            br.join()
+            return {"loc": loc, "conf": conf, "mask": coef, "priors": priors, "proto": proto}
+        pyramid = self.fpn(feats)
+        proto = prototypes(pyramid[0])
+        priors = priors_of(pyramid)
         fused = head.fused_outputs(pyramid, priors.shape[0])
         if fused is not None:
             loc, conf, coef = fused

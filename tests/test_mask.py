@@ -1246,6 +1246,57 @@ def test_mask_pass_as_one_hip_graph_equals_the_eager_pass(mask, gpu_lib):
         eng.eval_bgr_graph(frames[:1])
 
 
+@pytest.mark.gpu
+def test_side_stream_branches_give_the_one_stream_pass(mask, gpu_lib, monkeypatch):
+    """A small pass with the pyramid's side levels and the prediction head on side streams (net.Branches; the default up to four frames per
+    pass) against the one-stream pass (AMOS_MASK_BRANCHES=0): the same kernels on the same operands, so the same network outputs (to float32
+    rounding: the library's split-k kernels sum with atomics) and the same person masks -- eager, with one and two frames, and inside the
+    one-frame HIP graph of MaskEngine.frame_session, replayed on several frames.  A pass above the frame limit takes no side stream."""
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    eng = _engine(mask, "cuda:0", "seed0")
+    eng.prepare()
+    frames = torch.from_numpy(np.stack([mask_cases.frame(c) for c in ("seed0", "ref122_w0", "tum_w0")])).cuda()
+    made = []
+    real = net_mod.Branches
+    monkeypatch.setattr(net_mod, "Branches", lambda *a, **k: (made.append(1), real(*a, **k))[1])
+    for n in (1, 2):
+        out = {}
+        for mode in ("0", "auto"):
+            monkeypatch.setenv("AMOS_MASK_BRANCHES", mode)
+            del made[:]
+            x = eng._preprocess_hip(frames[:n])
+            with torch.no_grad():
+                pred = eng._forward(x)
+            torch.cuda.synchronize()
+            assert len(made) == (0 if mode == "0" else 1)
+            out[mode] = ({k: pred[k].clone() for k in ("loc", "conf", "mask", "proto")}, eng.eval_net_input_batch(x, chunk=n).clone())
+        for k in ("loc", "conf", "mask", "proto"):
+            assert out["0"][0][k].shape == out["auto"][0][k].shape
+            assert torch.allclose(out["0"][0][k], out["auto"][0][k], rtol=1e-4, atol=1e-5), (n, k, float((out["0"][0][k] - out["auto"][0][k]).abs().max()))
+        assert torch.equal(out["0"][1], out["auto"][1]), n
+        assert int((out["auto"][1] > 0).sum()) > 0
+    # above the limit: one stream
+    monkeypatch.setenv("AMOS_MASK_BRANCHES", "auto")
+    monkeypatch.setenv("AMOS_MASK_BRANCH_MAX_BATCH", "2")
+    del made[:]
+    with torch.no_grad():
+        eng._forward(eng._preprocess_hip(frames))
+    assert not made
+    monkeypatch.delenv("AMOS_MASK_BRANCH_MAX_BATCH")
+    # the one-frame session: a graph with parallel branches, replayed on three frames, against the eager one-stream masks
+    monkeypatch.setenv("AMOS_MASK_BRANCHES", "0")
+    want = eng.eval_bgr_batch(frames, chunk=1).cpu().numpy()
+    monkeypatch.setenv("AMOS_MASK_BRANCHES", "auto")
+    del made[:]
+    s = eng.frame_session(480, 640)
+    assert made, "the session's capture took no side stream"
+    for rep in range(2):
+        for k in range(3):
+            s.frame_in.numpy()[...] = frames[k].cpu().numpy()
+            assert s.run()
+            assert np.array_equal(s.mask_out.numpy(), want[k]), (rep, k)
+
+
 def _bench_frames_per_forward():
     """Frames per network forward of the headline run: bench.py CONFIGS["c3"] (default_batch frames per step over default_streams lanes)."""
     keep = os.environ.get("GPU_MAX_HW_QUEUES")   # bench.py sets its own default on import: not this process's business
