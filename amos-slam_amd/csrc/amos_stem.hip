@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void k_stem_pack(const float *__restrict__ w, 
 // (Two work-groups share a CU and run their three phases in lock-step -- 1.10 ms per 64 frames of which the multiply phases are 0.80,
 // tools/stem_bench.hip.  Giving every second arrival at a CU a higher wave priority (a counter per CU indexed by the hardware id
 // registers, s_setprio) so that neighbours alternate made it SLOWER, 1.15 ms: the arbiter starves the other group's load / pool
-// instructions too.  Not kept.)
+// instructions too.  Starting the work-groups of the CUs' second slots 3 - 20 us late (so that neighbours are out of phase from the first
+// round on) changed nothing: 1.11 ms.  Neither is kept.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_stem_conv_pool(const StemArgs a)
 {
     extern __shared__ __align__(16) float lds[];
