@@ -444,6 +444,239 @@ __global__ __launch_bounds__(256) void k_topk_rows(const float *__restrict__ x, 
     }
 }
 
+// The same selection with the ROW IN LDS (round 5): rows of up to kTopkLdsMax values -- the 19 248 class scores per row of this network are
+// 77 KB -- are loaded once, as keys, by eight waves (eight 16-byte loads in flight per thread); the sparse attempt, the three histogram
+// passes, the gather and the fill completion then read LDS, four keys per thread and trip, instead of making four more trips through L2 with
+// a memory latency per step.  The gather has no barrier per 256 elements any more: values above the k-th key take their slots by an LDS
+// atomic (any order: sorted below), the first `needEq` values equal to it are ranked by ONE prefix scan over per-thread counts of CONTIGUOUS
+// chunks.  Same results as k_topk_rows.  The work-group owns its CU (89 KB of LDS), so this form serves the launches that leave CUs idle
+// anyway: one frame = 80 rows, dense 76 -> 39 us, sparse (300 live scores) 28 -> 22 us; at 64 frames (5 120 rows) the five-scan kernel's
+// eight rows per CU in flight win 404 against 884 us and keep the launch (launch_topk; tools/r5_topk_probe.py).
+constexpr int kTopkLdsThreads = 512, kTopkLdsMax = 32768;
+__global__ __launch_bounds__(kTopkLdsThreads) void k_topk_rows_lds(const float *__restrict__ x, float *__restrict__ values, long long *__restrict__ indices, int n, int k,
+                                                                  float fill)
+{
+    extern __shared__ __align__(16) unsigned keys[];  // n
+    __shared__ unsigned hist[kTopkBins];
+    __shared__ unsigned part[kTopkLdsThreads];
+    __shared__ unsigned long long sel[256];
+    __shared__ unsigned long long list[kTopkList];
+    __shared__ unsigned sPrefix, sMask, sNeed, sCountAbove, sLive, sBelow, sWave[kTopkLdsThreads / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *row = x + (size_t)blockIdx.x * n;
+    const bool sparse = fill == fill;
+    const unsigned fk = topk_key(fill);
+    if (t == 0) { sLive = 0; sBelow = 0; sPrefix = 0; sMask = 0; sNeed = (unsigned)k; sCountAbove = 0; }
+    __syncthreads();
+    // ---- the row -> LDS as keys; with `fill`, everything above it is also compacted into `list` on the way (one LDS atomic per wave and slot)
+#define AMOS_TOPK_TAKE(have, key, i)                                                                                      \
+    if (collect) {                                                                                                        \
+        const bool up = (have) && (key) > fk;                                                                             \
+        const unsigned long long m = __ballot(up);                                                                        \
+        if (m) {                                                                                                          \
+            unsigned base = 0;                                                                                            \
+            if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&sLive, (unsigned)__popcll(m));                         \
+            base = __shfl(base, (int)__builtin_ctzll(m), 64);                                                             \
+            const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));                                 \
+            if (up && slot < (unsigned)kTopkList) list[slot] = ((unsigned long long)(key) << 32) | (unsigned)(0xffffffffu - (unsigned)(i)); \
+        }                                                                                                                 \
+        if ((have) && (key) < fk) sBelow = 1u;                                                                            \
+    }
+    const bool vec = (n & 3) == 0 && ((uintptr_t)row & 15) == 0;
+    const int nVec = vec ? n : 0;
+    constexpr int kLoads = 8;  // 16-byte loads in flight per thread: the row arrives in two or three memory latencies, not in ten
+    for (int base = 0; base < nVec; base += 4 * kTopkLdsThreads * kLoads) {
+        float4 v[kLoads];
+#pragma unroll
+        for (int j = 0; j < kLoads; j++) {
+            const int i = base + 4 * (j * kTopkLdsThreads + t);
+            v[j] = i < n ? *reinterpret_cast<const float4 *>(row + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < kLoads; j++) {
+            const int i = base + 4 * (j * kTopkLdsThreads + t);
+            const bool have = i < n;
+            const unsigned k0 = topk_key(v[j].x), k1 = topk_key(v[j].y), k2 = topk_key(v[j].z), k3 = topk_key(v[j].w);
+            if (have) *reinterpret_cast<uint4 *>(&keys[i]) = make_uint4(k0, k1, k2, k3);
+            // (a dense row overflows the list early: its waves stop collecting -- the same word for every lane of a wave, so uniform)
+            const bool collect = sparse && *reinterpret_cast<volatile unsigned *>(&sLive) <= (unsigned)kTopkList;
+            AMOS_TOPK_TAKE(have, k0, i)
+            AMOS_TOPK_TAKE(have, k1, i + 1)
+            AMOS_TOPK_TAKE(have, k2, i + 2)
+            AMOS_TOPK_TAKE(have, k3, i + 3)
+        }
+    }
+    for (int i0 = nVec; i0 < n; i0 += kTopkLdsThreads) {
+        const int i = i0 + t;
+        const bool have = i < n;
+        const unsigned key = have ? topk_key(row[i]) : 0u;
+        if (have) keys[i] = key;
+        const bool collect = sparse && *reinterpret_cast<volatile unsigned *>(&sLive) <= (unsigned)kTopkList;
+        AMOS_TOPK_TAKE(have, key, i)
+    }
+#undef AMOS_TOPK_TAKE
+    __syncthreads();
+    const unsigned live = sLive;
+    if (sparse && live <= (unsigned)kTopkList && (live >= (unsigned)k || !sBelow)) {  // uniform: a sparse row -- sort the list, complete with `fill`
+        unsigned n2 = 256;
+        while (n2 < live) n2 <<= 1;
+        for (unsigned i = live + t; i < n2; i += kTopkLdsThreads) list[i] = 0ull;  // padding sorts last
+        __syncthreads();
+        for (unsigned size = 2; size <= n2; size <<= 1)
+            for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+                for (unsigned i = t; i < n2 / 2; i += kTopkLdsThreads) {
+                    const unsigned lo = ((i / stride) * stride * 2) + (i % stride), hi = lo + stride;
+                    const unsigned long long a = list[lo], b = list[hi];
+                    const bool descending = (lo & size) == 0;
+                    if (descending ? a < b : a > b) { list[lo] = b; list[hi] = a; }
+                }
+                __syncthreads();
+            }
+        const unsigned take = live < (unsigned)k ? live : (unsigned)k;
+        if ((unsigned)t < take) {
+            const unsigned long long v = list[t];
+            values[(size_t)blockIdx.x * k + t] = topk_value((unsigned)(v >> 32));
+            indices[(size_t)blockIdx.x * k + t] = (long long)(0xffffffffu - (unsigned)(v & 0xffffffffu));
+        }
+        unsigned have = take;  // uniform.  The rest: `fill` at its first indices (every element that is not live equals `fill` here)
+        for (int i0 = 0; i0 < n && have < (unsigned)k; i0 += kTopkLdsThreads) {
+            const int i = i0 + t;
+            const bool eq = i < n && keys[i] == fk;
+            const unsigned long long m = __ballot(eq);
+            if (lane == 0) sWave[wave] = (unsigned)__popcll(m);
+            __syncthreads();
+            unsigned base = have, total = 0;
+            for (int w = 0; w < kTopkLdsThreads / 64; w++) {
+                const unsigned c = sWave[w];
+                if (w < wave) base += c;
+                total += c;
+            }
+            const unsigned rank = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (eq && rank < (unsigned)k) {
+                values[(size_t)blockIdx.x * k + rank] = fill;
+                indices[(size_t)blockIdx.x * k + rank] = (long long)i;
+            }
+            have += total;
+            __syncthreads();
+        }
+        return;
+    }
+    // ---- radix select of the k-th largest key, from LDS
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; pass++) {
+        const int shift = shifts[pass], bins = 1 << widths[pass];
+        for (int b = t; b < kTopkBins; b += kTopkLdsThreads) hist[b] = 0;
+        __syncthreads();
+        const unsigned prefix = sPrefix, mask = sMask, need = sNeed;
+#define AMOS_TOPK_COUNT(in, bin)                                                                                          \
+        {   /* (a row that is mostly one value: one lane adds the wave's count instead of 64 atomics on one address) */  \
+            const unsigned long long m = __ballot(in);                                                                    \
+            if (m) {                                                                                                      \
+                const unsigned b0 = __builtin_amdgcn_readlane((bin), (int)__builtin_ctzll(m)); /* the first counting lane's bin */ \
+                const bool same = __ballot((in) && (bin) != b0) == 0ull;                                                  \
+                if (same) {                                                                                               \
+                    if (lane == (int)__builtin_ctzll(m)) atomicAdd(&hist[b0], (unsigned)__popcll(m));                     \
+                } else if (in) {                                                                                          \
+                    atomicAdd(&hist[(bin)], 1u);                                                                          \
+                }                                                                                                         \
+            }                                                                                                             \
+        }
+        for (int i0 = 0; i0 < n; i0 += 4 * kTopkLdsThreads) {  // four keys per thread and trip: one 16-byte LDS read, four independent chains
+            const int i = i0 + 4 * t;
+            const uint4 kk = i < n ? *reinterpret_cast<const uint4 *>(&keys[i]) : make_uint4(0u, 0u, 0u, 0u);  // (the array is padded to four)
+            const bool in0 = i < n && (kk.x & mask) == prefix, in1 = i + 1 < n && (kk.y & mask) == prefix;
+            const bool in2 = i + 2 < n && (kk.z & mask) == prefix, in3 = i + 3 < n && (kk.w & mask) == prefix;
+            const unsigned b0_ = (kk.x >> shift) & (bins - 1), b1_ = (kk.y >> shift) & (bins - 1), b2_ = (kk.z >> shift) & (bins - 1), b3_ = (kk.w >> shift) & (bins - 1);
+            AMOS_TOPK_COUNT(in0, b0_)
+            AMOS_TOPK_COUNT(in1, b1_)
+            AMOS_TOPK_COUNT(in2, b2_)
+            AMOS_TOPK_COUNT(in3, b3_)
+        }
+#undef AMOS_TOPK_COUNT
+        __syncthreads();
+        {  // partial sums of 4 bins per thread
+            unsigned p = 0;
+            for (int b = 0; b < kTopkBins / kTopkLdsThreads; b++) p += hist[(kTopkBins / kTopkLdsThreads) * t + b];
+            part[t] = p;
+        }
+        __syncthreads();
+        if (t < 64) {  // wave 0: the bin where the count from the top reaches `need`; lane = bins 32 lane .. 32 lane + 31 = 8 partial sums
+            unsigned q = 0;
+            for (int j = 0; j < kTopkLdsThreads / 64; j++) q += part[(kTopkLdsThreads / 64) * lane + j];
+            unsigned suffix = q;  // inclusive suffix sum over lanes >= lane
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned o = __shfl_down(suffix, d, 64);
+                if (lane + d < 64) suffix += o;
+            }
+            const unsigned above = suffix - q;
+            if (above < need && suffix >= need) {  // exactly one lane
+                unsigned acc = above;
+                int bin = 32 * lane + 31;
+                for (; bin > 32 * lane; bin--) {
+                    const unsigned c = hist[bin];
+                    if (acc + c >= need) break;
+                    acc += c;
+                }
+                sPrefix = prefix | ((unsigned)bin << shift);
+                sMask = mask | ((unsigned)(bins - 1) << shift);
+                sNeed = need - acc;
+            }
+        }
+        __syncthreads();
+    }
+    const unsigned T = sPrefix, needEq = sNeed, nAbove = (unsigned)k - needEq;
+    // ---- gather: every key > T (any order), then the first needEq keys == T in index order
+    for (int i0 = 0; i0 < n; i0 += 4 * kTopkLdsThreads) {
+        const int i = i0 + 4 * t;
+        if (i < n) {
+            const uint4 kk = *reinterpret_cast<const uint4 *>(&keys[i]);
+            const unsigned key[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (i + e < n && key[e] > T) sel[atomicAdd(&sCountAbove, 1u)] = ((unsigned long long)key[e] << 32) | (unsigned)(0xffffffffu - (unsigned)(i + e));
+        }
+    }
+    {
+        const int chunk = (n + kTopkLdsThreads - 1) / kTopkLdsThreads, lo = min(t * chunk, n), hi = min(lo + chunk, n);
+        unsigned cnt = 0;
+        for (int i = lo; i < hi; i++) cnt += keys[i] == T ? 1u : 0u;
+        unsigned incl = cnt;  // inclusive scan over the wave, then the waves' totals
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) sWave[wave] = incl;
+        __syncthreads();
+        unsigned rank = incl - cnt;
+        for (int w = 0; w < wave; w++) rank += sWave[w];
+        for (int i = lo; i < hi && rank < needEq; i++)
+            if (keys[i] == T) {
+                sel[nAbove + rank] = ((unsigned long long)T << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+                rank++;
+            }
+    }
+    if (t >= k && t < 256) sel[t] = 0ull;  // padding sorts last
+    __syncthreads();
+    // ---- bitonic sort of 256 composite keys, descending (the first 256 threads; everybody keeps the barriers)
+    for (int size = 2; size <= 256; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            unsigned long long a = 0, b = 0;
+            if (t < 256) { a = sel[t]; b = sel[t ^ stride]; }
+            __syncthreads();
+            if (t < 256) {
+                const bool descending = (t & size) == 0, lower = (t & stride) == 0;
+                const unsigned long long hi = a > b ? a : b, lo = a > b ? b : a;
+                sel[t] = (descending == lower) ? hi : lo;
+            }
+            __syncthreads();
+        }
+    if (t < k) {
+        const unsigned long long v = sel[t];
+        values[(size_t)blockIdx.x * k + t] = topk_value((unsigned)(v >> 32));
+        indices[(size_t)blockIdx.x * k + t] = (long long)(0xffffffffu - (unsigned)(v & 0xffffffffu));
+    }
+}
+
 
 // ---- the rest of Detect + postprocess + prep_display for the static-shape batch path (mask/detect.py detect_batch, mask/post.py
 // person_mask_batch), fused: PyTorch spends ~75 small launches per pass on these steps (box decoding, two gathers, where / topk / gathers of
@@ -665,6 +898,25 @@ int amos_mask_head_outputs_device(void *stream, const float *d_raw, const float 
     return AMOS_OK;
 }
 
+// rows that fit LDS as keys take k_topk_rows_lds (AMOS_TOPK_LDS=0 in the environment: always the five-scan kernel -- A/B runs)
+static DeviceOnce g_topk_lds_once;
+static int launch_topk(hipStream_t stream, const float *d_x, float *d_values, long long *d_indices, int rows, int n, int k, float fill)
+{
+    static const bool ldsAllowed = [] { const char *e = getenv("AMOS_TOPK_LDS"); return !(e && e[0] == '0'); }();
+    // one row per CU at most: the LDS kernel's work-group owns a CU (89 KB of LDS), so it serves the launches that leave CUs idle anyway -- a
+    // frame or three (80 rows each); the five-scan kernel keeps eight rows per CU in flight and wins every larger launch
+    // (tools/r5_topk_probe.py: 80 dense rows 76 -> 43 us, 5 120 rows 404 against 884)
+    if (ldsAllowed && n <= kTopkLdsMax && rows <= 256) {
+        const int ldsBytes = ((n + 3) & ~3) * (int)sizeof(unsigned);
+        AMOS_HIP_CHECK(set_max_dynamic_lds(g_topk_lds_once, reinterpret_cast<const void *>(k_topk_rows_lds), kTopkLdsMax * (int)sizeof(unsigned), stream));
+        hipLaunchKernelGGL(k_topk_rows_lds, dim3(rows), dim3(kTopkLdsThreads), ldsBytes, stream, d_x, d_values, d_indices, n, k, fill);
+    } else {
+        hipLaunchKernelGGL(k_topk_rows, dim3(rows), dim3(256), 0, stream, d_x, d_values, d_indices, n, k, fill);
+    }
+    AMOS_HIP_CHECK(hipGetLastError());
+    return AMOS_OK;
+}
+
 int amos_mask_topk_rows_device(void *stream, const float *d_x, float *d_values, long long *d_indices, int rows, int n, int k)
 {
     if (!d_x || !d_values || !d_indices || rows < 0 || n < 1 || k < 1 || k > 256 || k > n) {
@@ -672,9 +924,7 @@ int amos_mask_topk_rows_device(void *stream, const float *d_x, float *d_values, 
         return AMOS_ERR_INVALID;
     }
     if (rows == 0) return AMOS_OK;
-    hipLaunchKernelGGL(k_topk_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, d_x, d_values, d_indices, n, k, __builtin_nanf(""));
-    AMOS_HIP_CHECK(hipGetLastError());
-    return AMOS_OK;
+    return launch_topk((hipStream_t)stream, d_x, d_values, d_indices, rows, n, k, __builtin_nanf(""));
 }
 
 int amos_mask_topk_rows_sparse_device(void *stream, const float *d_x, float *d_values, long long *d_indices, int rows, int n, int k, float fill)
@@ -684,9 +934,7 @@ int amos_mask_topk_rows_sparse_device(void *stream, const float *d_x, float *d_v
         return AMOS_ERR_INVALID;
     }
     if (rows == 0) return AMOS_OK;
-    hipLaunchKernelGGL(k_topk_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, d_x, d_values, d_indices, n, k, fill);
-    AMOS_HIP_CHECK(hipGetLastError());
-    return AMOS_OK;
+    return launch_topk((hipStream_t)stream, d_x, d_values, d_indices, rows, n, k, fill);
 }
 
 

@@ -1121,7 +1121,8 @@ def test_topk_rows_kernel_against_torch_topk(mask, gpu_lib):
         torch.cuda.synchronize()
         return v, i
 
-    for rows, n, k in ((64, 19248, 200), (5, 1000, 200), (3, 257, 256), (4, 50, 1), (2, 37, 37)):
+    # (launches of at most 256 rows of at most 32 768 values take the LDS-resident kernel, the others the five-scan kernel: both here)
+    for rows, n, k in ((64, 19248, 200), (5, 1000, 200), (3, 257, 256), (4, 50, 1), (2, 37, 37), (3, 40000, 200), (2, 32768, 256), (2, 32769, 100), (3, 19250, 200), (300, 19248, 200)):
         x = torch.randn(rows, n, device="cuda")
         v, i = run(x, k)
         wv, wi = x.topk(k, dim=1)
@@ -1172,6 +1173,16 @@ def test_topk_rows_kernel_against_torch_topk(mask, gpu_lib):
             gv, gi = run(x, k)
             sv, si = run_sparse(x, k, -1.0)
             assert torch.equal(sv, gv) and torch.equal(si, gi), (real, k)
+    for n in (40000, 32768):   # the same on both sides of the LDS kernel's row limit
+        x = torch.full((3, n), -1.0, device="cuda")
+        pos = torch.stack([torch.randperm(n, device="cuda")[:150] for _ in range(3)])
+        x.scatter_(1, pos, torch.rand(3, 150, device="cuda") * 0.9 + 0.05)
+        x[2, 100:300] = -2.0
+        gv, gi = run(x, 200)
+        sv, si = run_sparse(x, 200, -1.0)
+        wv, _ = x.topk(200, dim=1)
+        assert torch.equal(sv, gv) and torch.equal(si, gi) and torch.equal(gv, wv), n
+        assert gi[0, 150:].tolist() == [j for j in range(n) if x[0, j].item() == -1.0][:50]
     x = torch.randn(4, 3001, device="cuda")   # no fill value anywhere, a row length that is not a multiple of 4
     for fill in (-1.0, 10.0, -10.0):
         gv, gi = run(x, 100)
