@@ -1575,13 +1575,38 @@ __global__ __launch_bounds__(256) void k_morph31(const uint8_t *__restrict__ src
     dst += (size_t)blockIdx.z * dstFrameStride;
     const int neutral = kDilate ? 0 : 255;
     auto pick = [](int a, int b, int c) { return kDilate ? max(a, max(b, c)) : min(a, min(b, c)); };  // v_max3 / v_min3
+    __shared__ int sLo, sHi;
+    if (tid == 0) { sLo = 255; sHi = 0; }
+    __syncthreads();
+    int lo = 255, hi = 0;  // range of the IMAGE pixels under the tile and its 15-pixel border
     for (int idx = tid; idx < kMorphRows * (kMorphTileW + 30); idx += 256) {
         const int r = idx / (kMorphTileW + 30), c = idx - r * (kMorphTileW + 30);
         const int y = y0 - 15 + r, x = x0 - 15 + c;
-        tile[r][c] = (y >= 0 && y < h && x >= 0 && x < w) ? src[(size_t)y * srcStride + x] : (uint8_t)neutral;
+        const bool in = y >= 0 && y < h && x >= 0 && x < w;
+        const int v = in ? src[(size_t)y * srcStride + x] : neutral;
+        tile[r][c] = (uint8_t)v;
+        lo = in ? min(lo, v) : lo;
+        hi = in ? max(hi, v) : hi;
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        lo = min(lo, __shfl_xor(lo, d, 64));
+        hi = max(hi, __shfl_xor(hi, d, 64));
+    }
+    if ((tid & 63) == 0) { atomicMin(&sLo, lo); atomicMax(&sHi, hi); }
     __syncthreads();
     const int lx = tid & 63;
+    // A tile whose whole neighbourhood holds ONE value keeps it (a window's maximum / minimum over equal values; every window contains its own
+    // image pixel, so the border's neutral value never wins): person masks are mostly such tiles -- all background, or all inside a silhouette
+    // -- and they skip the two window phases.
+    if (sLo >= sHi) {
+        const int v0 = sLo;
+        for (int ly = tid >> 6; ly < kMorphTileH; ly += 4) {
+            const int x = x0 + lx, y = y0 + ly;
+            if (x < w && y < h) dst[(size_t)y * stride + x] = (uint8_t)v0;
+        }
+        return;
+    }
     for (int r = tid >> 6; r < kMorphRows; r += 4) {  // phase 2: the nested horizontal windows of (r, lx)
         const uint8_t *c = &tile[r][lx + 15];
         int m = pick(c[0], pick(c[-1], c[1], c[-2]), pick(c[2], c[-3], c[3]));
