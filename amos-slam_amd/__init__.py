@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_flow_fundamental_score_device", "amos_flow_pnp_score_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_stem_weight_floats", "amos_mask_stem_weights_device", "amos_mask_stem_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_workspace_bytes", "amos_mask_conv_ws_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_corners_create", "amos_corners_destroy", "amos_corners_stream", "amos_corners_good_features_device", "amos_corners_candidate_count", "amos_corners_subpix_device", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_winograd24_weight_floats", "amos_mask_winograd24_weights_device", "amos_mask_winograd24_conv_device", "amos_mask_winograd24_conv_layout_device", "amos_mask_winograd24_persistent_mode", "amos_mask_winograd24_narrow_mode", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_topk_rows_device", "amos_mask_topk_rows_sparse_device", "amos_mask_post_workspace_bytes", "amos_mask_person_masks_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_flow_fundamental_score_device", "amos_flow_pnp_score_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_stem_weight_floats", "amos_mask_stem_weights_device", "amos_mask_stem_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_workspace_bytes", "amos_mask_conv_ws_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_corners_create", "amos_corners_destroy", "amos_corners_stream", "amos_corners_good_features_device", "amos_corners_candidate_count", "amos_corners_subpix_device", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_winograd24_weight_floats", "amos_mask_winograd24_weights_device", "amos_mask_winograd24_conv_device", "amos_mask_winograd24_conv_layout_device", "amos_mask_winograd24_persistent_mode", "amos_mask_winograd24_narrow_mode", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_bilinear_x2_mode", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_topk_rows_device", "amos_mask_topk_rows_sparse_device", "amos_mask_post_workspace_bytes", "amos_mask_person_masks_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -487,6 +487,11 @@ def mask_stem(stream_ptr, x_ptr, x_strides, packed_ptr, bias_ptr, y_ptr, batch, 
     _check(lib().amos_mask_stem_device(C.c_void_p(stream_ptr), C.c_void_p(x_ptr), C.c_longlong(sb), C.c_longlong(sc), C.c_longlong(sy), C.c_longlong(sx),
                                        C.c_void_p(packed_ptr), C.c_void_p(bias_ptr), C.c_void_p(y_ptr), C.c_int(batch), C.c_int(height), C.c_int(width)),
            "amos_mask_stem_device")
+
+
+def mask_bilinear_x2_mode(mode=-1):
+    """amos_mask_bilinear_x2_mode: 1 = exact x 2 enlargements take the 2 x 2-outputs-per-thread kernel (default), 0 = never; returns the previous mode."""
+    return int(lib().amos_mask_bilinear_x2_mode(C.c_int(mode)))
 
 
 def mask_conv1x1_supported(cin, cout, stride):

@@ -119,6 +119,69 @@ __global__ __launch_bounds__(256) void k_bias_act(float *__restrict__ y, const f
     }
 }
 
+// The same resize for an exact x 2 enlargement (the prototype network's upsampling step: 256 channels, 69 -> 138, 1.25 GB written per 64
+// frames): a thread makes the 2 x 2 output block around one source pixel from the 3 x 3 source pixels it touches -- 2.25 sixteen-byte
+// reads per output instead of 4 (the one-output-per-thread kernel above moves 10 TB/s from L2 to L1 for this layer and is bound by that).
+// Per output the same taps, weights and order of operations as k_bilinear_nhwc: the same bits.  A block whose two rows (columns) do not
+// share their middle source row (column) -- the first and last ones, where the source index is clamped -- takes its taps one by one.
+// grid = (ceil(ceil(outW / 2) * c4 / 256), ceil(outH / 2), n)
+template <bool kRelu>
+__global__ __launch_bounds__(256) void k_bilinear_nhwc_x2(const float *__restrict__ x, float *__restrict__ y, int inH, int inW, int outH, int outW, int c4,
+                                                         float scaleH, float scaleW)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, bw = (outW + 1) / 2;
+    if (t >= bw * c4) return;
+    const int bx = t / c4, q = t - bx * c4, n = blockIdx.z;
+    int yy[2][2], xx[2][2];
+    float wy[2][2], wx[2][2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        float fy = __fsub_rn(__fmul_rn(scaleH, __fadd_rn((float)(2 * (int)blockIdx.y + e), 0.5f)), 0.5f);
+        float fx = __fsub_rn(__fmul_rn(scaleW, __fadd_rn((float)(2 * bx + e), 0.5f)), 0.5f);
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        yy[e][0] = min((int)fy, inH - 1);  // (only a row / column past the output, never stored, can exceed the source)
+        xx[e][0] = min((int)fx, inW - 1);
+        yy[e][1] = yy[e][0] + (yy[e][0] < inH - 1 ? 1 : 0);
+        xx[e][1] = xx[e][0] + (xx[e][0] < inW - 1 ? 1 : 0);
+        wy[e][1] = __fsub_rn(fy, (float)(int)fy); wy[e][0] = __fsub_rn(1.f, wy[e][1]);
+        wx[e][1] = __fsub_rn(fx, (float)(int)fx); wx[e][0] = __fsub_rn(1.f, wx[e][1]);
+    }
+    const float4 *src = reinterpret_cast<const float4 *>(x) + (size_t)n * inH * inW * c4;
+    auto at = [&](int r, int c) { return src[((size_t)r * inW + c) * c4 + q]; };
+    float4 s[4][4];  // [row tap: a0 a1 b0 b1][column tap: a0 a1 b0 b1]
+    const bool shareY = yy[1][0] == yy[0][1], shareX = xx[1][0] == xx[0][1];
+    const int ry[4] = {yy[0][0], yy[0][1], yy[1][0], yy[1][1]}, cx[4] = {xx[0][0], xx[0][1], xx[1][0], xx[1][1]};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (r == 2 && shareY) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) s[2][c] = s[1][c];
+            continue;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (c == 2 && shareX) s[r][2] = s[r][1];
+            else s[r][c] = at(ry[r], cx[c]);
+        }
+    }
+    float4 *dst = reinterpret_cast<float4 *>(y);
+#pragma unroll
+    for (int ey = 0; ey < 2; ey++)
+#pragma unroll
+        for (int ex = 0; ex < 2; ex++) {
+            const int oy = 2 * (int)blockIdx.y + ey, ox = 2 * bx + ex;
+            if (oy >= outH || ox >= outW) continue;
+            const float hy = wy[ey][0], ly = wy[ey][1], hx = wx[ex][0], lx = wx[ex][1];
+            const float4 a = s[2 * ey][2 * ex], b = s[2 * ey][2 * ex + 1], c = s[2 * ey + 1][2 * ex], d = s[2 * ey + 1][2 * ex + 1];
+            auto mix = [&](float p, float r, float u, float v2) {
+                const float v = __fadd_rn(__fmul_rn(hy, __fadd_rn(__fmul_rn(hx, p), __fmul_rn(lx, r))), __fmul_rn(ly, __fadd_rn(__fmul_rn(hx, u), __fmul_rn(lx, v2))));
+                return kRelu ? (v < 0.f ? 0.f : v) : v;
+            };
+            dst[(((size_t)n * outH + oy) * outW + ox) * c4 + q] = make_float4(mix(a.x, b.x, c.x, d.x), mix(a.y, b.y, c.y, d.y), mix(a.z, b.z, c.z, d.z), mix(a.w, b.w, c.w, d.w));
+        }
+}
+
 // ---- the stem's tail: bias + ReLU + max_pool2d(3, stride 2, padding 1) of the 7 x 7 convolution's raw output in one pass
 // (backbone.py ResNetBackbone.forward: conv1 -> bn1 (folded) -> relu -> maxpool).  relu(x + b) is monotone in x, and rounding is
 // monotone, so max over the window of relu(x_i + b) == relu(max_i(x_i) + b) bit for bit: the kernel takes the maximum of the raw
@@ -404,6 +467,14 @@ int amos_mask_bias_relu_maxpool_device(void *stream, const float *d_x, const flo
 }
 
 
+static std::atomic<int> g_bilinear_x2{1};
+int amos_mask_bilinear_x2_mode(int mode)
+{
+    const int before = g_bilinear_x2.load();
+    if (mode == 0 || mode == 1) g_bilinear_x2.store(mode);
+    return before;
+}
+
 int amos_mask_bilinear_nhwc_act_device(void *stream, const float *d_x, float *d_y, int n, int in_h, int in_w, int out_h, int out_w, int channels,
                                        float scale_h, float scale_w, int relu)
 {
@@ -413,6 +484,13 @@ int amos_mask_bilinear_nhwc_act_device(void *stream, const float *d_x, float *d_
         return AMOS_ERR_INVALID;
     }
     const int c4 = channels / 4;
+    if (g_bilinear_x2 && out_h == 2 * in_h && out_w == 2 * in_w && scale_h == 0.5f && scale_w == 0.5f) {  // an exact x 2 enlargement: 2 x 2 outputs per thread
+        const dim3 grid2(((out_w + 1) / 2 * c4 + 255) / 256, (out_h + 1) / 2, n);
+        if (relu) hipLaunchKernelGGL(k_bilinear_nhwc_x2<true>, grid2, dim3(256), 0, (hipStream_t)stream, d_x, d_y, in_h, in_w, out_h, out_w, c4, scale_h, scale_w);
+        else hipLaunchKernelGGL(k_bilinear_nhwc_x2<false>, grid2, dim3(256), 0, (hipStream_t)stream, d_x, d_y, in_h, in_w, out_h, out_w, c4, scale_h, scale_w);
+        AMOS_HIP_CHECK(hipGetLastError());
+        return AMOS_OK;
+    }
     const dim3 grid((out_w * c4 + 255) / 256, out_h, n), block(256);
     if (relu) hipLaunchKernelGGL(k_bilinear_nhwc<true>, grid, block, 0, (hipStream_t)stream, d_x, d_y, in_h, in_w, out_h, out_w, c4, scale_h, scale_w);
     else hipLaunchKernelGGL(k_bilinear_nhwc<false>, grid, block, 0, (hipStream_t)stream, d_x, d_y, in_h, in_w, out_h, out_w, c4, scale_h, scale_w);

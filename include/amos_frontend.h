@@ -454,6 +454,11 @@ int amos_mask_bilinear_nhwc_device(void *stream, const float *d_x, float *d_y, i
 int amos_mask_bilinear_nhwc_act_device(void *stream, const float *d_x, float *d_y, int n, int in_h, int in_w, int out_h,
                                        int out_w, int channels, float scale_h, float scale_w, int relu);
 
+/* An exact x 2 enlargement (out = 2 x in, scale 0.5: the prototype network's upsampling step) runs a form of the kernel that makes 2 x 2 outputs
+ * per thread from the 3 x 3 source pixels they touch (the same bits, fewer reads).  mode 1: where it applies (default), 0: never (A/B runs,
+ * tests); any other value only reports.  Returns the mode in force before the call. */
+int amos_mask_bilinear_x2_mode(int mode);
+
 /* The suppression term of Fast NMS (layers/functions/detection.py:103-170 fast_nms, layers/box_utils.py jaccard): d_boxes holds
  * n_lists lists of k boxes [x1, y1, x2, y2] sorted by descending score; d_out[list][j] = max over i < j of IoU(box i, box j), 0 for
  * j == 0 -- what `jaccard(boxes, boxes).triu_(diagonal=1).max(dim=1)` yields, in jaccard's float32 arithmetic (bit-identical to

@@ -828,6 +828,20 @@ def test_hip_bilinear_nhwc_equals_torch_interpolate(mask, gpu_lib):
         torch.cuda.synchronize()
         assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
         assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max())), (n, c, h, w, kw)
+    # an exact x 2 enlargement takes the 2 x 2-outputs-per-thread form: the same bits as the one-output form, odd and tiny sources, with and
+    # without the ReLU, a NaN in the source
+    for (n, c, h, w) in ((2, 256, 69, 69), (1, 8, 5, 7), (3, 4, 1, 1), (1, 12, 2, 9), (2, 64, 35, 34)):
+        x = torch.randn(n, c, h, w, device="cuda").contiguous(memory_format=torch.channels_last)
+        if h > 2:
+            x[0, 1, 2, 3] = float("nan")
+        for relu in (False, True):
+            assert gpu_lib.mask_bilinear_x2_mode(1) in (0, 1)
+            a = net_mod.bilinear(x, scale_factor=2, relu=relu)
+            gpu_lib.mask_bilinear_x2_mode(0)
+            b = net_mod.bilinear(x, scale_factor=2, relu=relu)
+            gpu_lib.mask_bilinear_x2_mode(1)
+            torch.cuda.synchronize()
+            assert a.shape == (n, c, 2 * h, 2 * w) and torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), (n, c, h, w, relu)
 
 
 @pytest.mark.gpu
