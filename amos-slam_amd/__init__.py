@@ -32,7 +32,7 @@ EXPORTS = [
     "amos_orb_stream", "amos_orb_timing_enable", "amos_orb_timing_collect", "amos_match_create", "amos_match_destroy", "amos_match_sync", "amos_match_stream",
     "amos_match_distances", "amos_match_list_distances", "amos_match_list_best2", "amos_match_bruteforce_best2",
     "amos_match_bruteforce_best2_batch_device", "amos_match_set_bruteforce_kernel", "amos_slic_center_count", "amos_slic_create", "amos_slic_destroy", "amos_slic_stream",
-    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_flow_fundamental_score_device", "amos_flow_pnp_score_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_stem_weight_floats", "amos_mask_stem_weights_device", "amos_mask_stem_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_workspace_bytes", "amos_mask_conv_ws_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_corners_create", "amos_corners_destroy", "amos_corners_stream", "amos_corners_good_features_device", "amos_corners_candidate_count", "amos_corners_subpix_device", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_winograd24_weight_floats", "amos_mask_winograd24_weights_device", "amos_mask_winograd24_conv_device", "amos_mask_winograd24_conv_layout_device", "amos_mask_winograd24_persistent_mode", "amos_mask_winograd24_narrow_mode", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_bilinear_x2_mode", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_topk_rows_device", "amos_mask_topk_rows_sparse_device", "amos_mask_post_workspace_bytes", "amos_mask_person_masks_device", "amos_orb_detect_color_with_mask_pre_batch_device",
+    "amos_slic_run", "amos_slic_batch_device", "amos_cluster_kmeans_batch_device", "amos_cluster_kmeans", "amos_cluster_bgr2lab_batch_device", "amos_flow_check_device", "amos_flow_epipolar_device", "amos_flow_scene_flow_device", "amos_flow_fundamental_score_device", "amos_flow_pnp_score_device", "amos_lk_create", "amos_lk_destroy", "amos_lk_stream", "amos_lk_levels", "amos_lk_track_device", "amos_mask_pre_create", "amos_mask_pre_destroy", "amos_mask_pre_stream", "amos_mask_preprocess_batch_device", "amos_mask_bias_act_device", "amos_mask_bias_relu_maxpool_device", "amos_mask_stem_weight_floats", "amos_mask_stem_weights_device", "amos_mask_stem_device", "amos_mask_conv1x1_supported", "amos_mask_conv1x1_device", "amos_mask_conv_supported", "amos_mask_conv_device", "amos_mask_conv_workspace_bytes", "amos_mask_conv_ws_device", "amos_mask_conv_tile_mode", "amos_mask_conv_kernel_name", "amos_corners_create", "amos_corners_destroy", "amos_corners_stream", "amos_corners_good_features_device", "amos_corners_candidate_count", "amos_corners_subpix_device", "amos_mask_winograd_supported", "amos_mask_winograd_weight_floats", "amos_mask_winograd_weights_device", "amos_mask_winograd_conv_device", "amos_mask_winograd24_weight_floats", "amos_mask_winograd24_weights_device", "amos_mask_winograd24_conv_device", "amos_mask_winograd24_conv_layout_device", "amos_mask_winograd24_persistent_mode", "amos_mask_winograd24_narrow_mode", "amos_mask_bilinear_nhwc_device", "amos_mask_bilinear_nhwc_act_device", "amos_mask_bilinear_x2_mode", "amos_mask_nms_column_max_device", "amos_mask_class_scores_device", "amos_mask_person_mask_device", "amos_mask_head_outputs_device", "amos_mask_head_outputs_scores_device", "amos_mask_person_masks_scores_device", "amos_mask_topk_rows_device", "amos_mask_topk_rows_sparse_device", "amos_mask_post_workspace_bytes", "amos_mask_person_masks_device", "amos_orb_detect_color_with_mask_pre_batch_device",
 ]
 
 
@@ -615,6 +615,26 @@ def mask_head_outputs(stream_ptr, raw_ptr, bias_ptr, loc_ptr, conf_ptr, coef_ptr
                                                C.c_void_p(coef_ptr), C.c_int(batch), C.c_int(cells), C.c_int(channels_padded), C.c_int(anchors),
                                                C.c_int(n_classes_with_background), C.c_int(mask_dim), C.c_int(n_priors_total), C.c_int(prior_offset)),
            "amos_mask_head_outputs_device")
+
+
+def mask_head_outputs_scores(stream_ptr, raw_ptr, bias_ptr, loc_ptr, conf_ptr, coef_ptr, scores_ptr, threshold, batch, cells, channels_padded, anchors,
+                             n_classes_with_background, mask_dim, n_priors_total, prior_offset):
+    """amos_mask_head_outputs_scores_device: mask_head_outputs + Detect's class scores [batch][classes][n_priors_total] from the same kernel; conf_ptr may be
+    None (the softmax tensor is then not written)."""
+    _check(lib().amos_mask_head_outputs_scores_device(C.c_void_p(stream_ptr), C.c_void_p(raw_ptr), C.c_void_p(bias_ptr), C.c_void_p(loc_ptr), C.c_void_p(conf_ptr),
+                                                      C.c_void_p(coef_ptr), C.c_void_p(scores_ptr), C.c_float(threshold), C.c_int(batch), C.c_int(cells),
+                                                      C.c_int(channels_padded), C.c_int(anchors), C.c_int(n_classes_with_background), C.c_int(mask_dim),
+                                                      C.c_int(n_priors_total), C.c_int(prior_offset)), "amos_mask_head_outputs_scores_device")
+
+
+def mask_person_masks_scores(stream_ptr, loc_ptr, scores_ptr, coef_ptr, priors_ptr, proto_ptr, batch, n_priors, n_classes_with_background, mask_dim, proto_h, proto_w,
+                             out_h, out_w, workspace_ptr, workspace_bytes, masks_ptr, found_ptr):
+    """amos_mask_person_masks_scores_device: mask_person_masks from the class scores mask_head_outputs_scores wrote instead of the softmax tensor."""
+    _check(lib().amos_mask_person_masks_scores_device(C.c_void_p(stream_ptr), C.c_void_p(loc_ptr), C.c_void_p(scores_ptr), C.c_void_p(coef_ptr),
+                                                      C.c_void_p(priors_ptr), C.c_void_p(proto_ptr), C.c_int(batch), C.c_int(n_priors),
+                                                      C.c_int(n_classes_with_background), C.c_int(mask_dim), C.c_int(proto_h), C.c_int(proto_w), C.c_int(out_h),
+                                                      C.c_int(out_w), C.c_void_p(workspace_ptr), C.c_size_t(workspace_bytes), C.c_void_p(masks_ptr),
+                                                      C.c_void_p(found_ptr)), "amos_mask_person_masks_scores_device")
 
 
 def mask_topk_rows(stream_ptr, x_ptr, values_ptr, indices_ptr, rows, n, k):

@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void k_person_mask(const float *__restrict__ m
 // grid = (ceil(cells / kHeadCells), B), block = 256.
 constexpr int kHeadCells = 16;
 __global__ __launch_bounds__(256) void k_head_outputs(const float *__restrict__ raw, const float *__restrict__ bias, float *__restrict__ loc, float *__restrict__ conf,
-                                                     float *__restrict__ coef, int cells, int cpad, int A, int C1, int D, int P, int pOff)
+                                                     float *__restrict__ coef, int cells, int cpad, int A, int C1, int D, int P, int pOff,
+                                                     float *__restrict__ scores, float thresh)
 {
     extern __shared__ float sh[];  // [kHeadCells][cpad]
     const int b = blockIdx.y, c0 = blockIdx.x * kHeadCells, nc = min(kHeadCells, cells - c0);
@@ -187,13 +188,55 @@ __global__ __launch_bounds__(256) void k_head_outputs(const float *__restrict__ 
     __syncthreads();
     const size_t prior0 = (size_t)b * P + pOff + (size_t)c0 * A;  // first prior of this work-group
     AMOS_HEAD_FOREACH(nLoc, loc[prior0 * 4 + e] = sh[cell * cpad + r])
+    AMOS_HEAD_FOREACH(nCoef, coef[prior0 * D + e] = sh[cell * cpad + nLoc + nConf + r])
+    if (!scores) {
+        AMOS_HEAD_FOREACH(nConf, {
+            int a = (int)((float)r * invC1);
+            a -= a * C1 > r ? 1 : 0;
+            a += (a + 1) * C1 <= r ? 1 : 0;
+            conf[prior0 * C1 + e] = sh[cell * cpad + nLoc + r] / sSum[cell * A + a];
+        })
+        return;
+    }
+    // With `scores`: the class scores of Detect as k_class_scores makes them from the softmax output -- [B][C][P], the background column
+    // dropped, -1 for every prior whose best class is not above the threshold -- written here, from the values this group holds, instead of
+    // by a pass that reads the softmax tensor back (and `conf` itself only if the caller still wants it).  The same quotients, the same
+    // comparisons: the same bits.
     AMOS_HEAD_FOREACH(nConf, {
         int a = (int)((float)r * invC1);
         a -= a * C1 > r ? 1 : 0;
         a += (a + 1) * C1 <= r ? 1 : 0;
-        conf[prior0 * C1 + e] = sh[cell * cpad + nLoc + r] / sSum[cell * A + a];
+        float *v = sh + cell * cpad + nLoc + r;
+        *v = *v / sSum[cell * A + a];
     })
-    AMOS_HEAD_FOREACH(nCoef, coef[prior0 * D + e] = sh[cell * cpad + nLoc + nConf + r])
+    __syncthreads();
+    if ((int)threadIdx.x < nc * A) {
+        const int cell = threadIdx.x / A, a = threadIdx.x - cell * A;
+        const float *v = sh + cell * cpad + nLoc + a * C1;
+        float m = v[1];
+        bool nan = m != m;
+        for (int c = 2; c < C1; c++) {
+            const float q = v[c];
+            nan = nan || q != q;
+            m = q > m ? q : m;
+        }
+        sMax[threadIdx.x] = nan ? __builtin_nanf("") : m;  // torch.max propagates a NaN; NaN > thresh is false
+    }
+    __syncthreads();
+    if (conf) AMOS_HEAD_FOREACH(nConf, conf[prior0 * C1 + e] = sh[cell * cpad + nLoc + r])
+    {
+        const int C = C1 - 1, np = nc * A;  // priors of this work-group: consecutive in every class row
+        float *dst = scores + (size_t)b * C * P + pOff + (size_t)c0 * A;
+        int c = (int)threadIdx.x / np, pl = (int)threadIdx.x - c * np;
+        const int stepC = 256 / np, stepP = 256 % np;
+        for (int e = threadIdx.x; e < C * np; e += 256) {
+            const int cell = pl / A, a = pl - cell * A;
+            dst[(size_t)c * P + pl] = sMax[pl] > thresh ? sh[cell * cpad + nLoc + a * C1 + c + 1] : -1.f;
+            c += stepC;
+            pl += stepP;
+            if (pl >= np) { pl -= np; c++; }
+        }
+    }
 #undef AMOS_HEAD_FOREACH
 }
 
@@ -881,19 +924,28 @@ int amos_mask_person_mask_device(void *stream, const float *d_masks, const uint8
 int amos_mask_head_outputs_device(void *stream, const float *d_raw, const float *d_bias, float *d_loc, float *d_conf, float *d_coef, int batch, int cells,
                                   int channels_padded, int anchors, int n_classes_with_background, int mask_dim, int n_priors_total, int prior_offset)
 {
+    if (!d_conf) { set_error("amos_mask_head_outputs_device: invalid argument"); return AMOS_ERR_INVALID; }
+    return amos_mask_head_outputs_scores_device(stream, d_raw, d_bias, d_loc, d_conf, d_coef, nullptr, 0.f, batch, cells, channels_padded, anchors,
+                                                n_classes_with_background, mask_dim, n_priors_total, prior_offset);
+}
+
+int amos_mask_head_outputs_scores_device(void *stream, const float *d_raw, const float *d_bias, float *d_loc, float *d_conf, float *d_coef, float *d_scores,
+                                         float threshold, int batch, int cells, int channels_padded, int anchors, int n_classes_with_background, int mask_dim,
+                                         int n_priors_total, int prior_offset)
+{
     const long long used = (long long)anchors * (4 + n_classes_with_background + mask_dim);
-    if (!d_raw || !d_bias || !d_loc || !d_conf || !d_coef || batch < 0 || cells < 1 || anchors < 1 || n_classes_with_background < 1 || mask_dim < 1 ||
+    if (!d_raw || !d_bias || !d_loc || (!d_conf && !d_scores) || (d_scores && n_classes_with_background < 2) || !d_coef || batch < 0 || cells < 1 || anchors < 1 || n_classes_with_background < 1 || mask_dim < 1 ||
         channels_padded % 4 != 0 || used > channels_padded || channels_padded > 1000 || prior_offset < 0 ||  // 16 x channels floats of LDS
        
         (long long)prior_offset + (long long)cells * anchors > n_priors_total || batch > 65535 || kHeadCells * anchors > 256 ||
         ((uintptr_t)d_raw | (uintptr_t)d_bias) % 16 != 0) {
-        set_error("amos_mask_head_outputs_device: invalid argument");
+        set_error("amos_mask_head_outputs_scores_device: invalid argument");
         return AMOS_ERR_INVALID;
     }
     if (batch == 0) return AMOS_OK;
     hipLaunchKernelGGL(k_head_outputs, dim3((cells + kHeadCells - 1) / kHeadCells, batch), dim3(256), (size_t)kHeadCells * channels_padded * sizeof(float),
                        (hipStream_t)stream, d_raw, d_bias, d_loc, d_conf, d_coef, cells, channels_padded, anchors, n_classes_with_background, mask_dim,
-                       n_priors_total, prior_offset);
+                       n_priors_total, prior_offset, d_scores, threshold);
     AMOS_HIP_CHECK(hipGetLastError());
     return AMOS_OK;
 }
@@ -969,12 +1021,34 @@ size_t amos_mask_post_workspace_bytes(int batch, int n_priors, int n_classes_wit
     return post_layout(batch, n_priors, n_classes_with_background, mask_dim, proto_h, proto_w).total;
 }
 
+static int person_masks(void *stream, const float *d_loc, const float *d_conf, const float *d_scores, const float *d_coef, const float *d_priors, const float *d_proto,
+                        int batch, int n_priors, int n_classes_with_background, int mask_dim, int proto_h, int proto_w, int out_h, int out_w, void *d_workspace,
+                        size_t workspace_bytes, uint8_t *d_masks, uint8_t *d_found);
+
 int amos_mask_person_masks_device(void *stream, const float *d_loc, const float *d_conf, const float *d_coef, const float *d_priors, const float *d_proto,
                                   int batch, int n_priors, int n_classes_with_background, int mask_dim, int proto_h, int proto_w, int out_h, int out_w,
                                   void *d_workspace, size_t workspace_bytes, uint8_t *d_masks, uint8_t *d_found)
 {
+    if (!d_conf) { set_error("amos_mask_person_masks_device: invalid argument"); return AMOS_ERR_INVALID; }
+    return person_masks(stream, d_loc, d_conf, nullptr, d_coef, d_priors, d_proto, batch, n_priors, n_classes_with_background, mask_dim, proto_h, proto_w, out_h, out_w,
+                        d_workspace, workspace_bytes, d_masks, d_found);
+}
+
+int amos_mask_person_masks_scores_device(void *stream, const float *d_loc, const float *d_scores, const float *d_coef, const float *d_priors, const float *d_proto,
+                                         int batch, int n_priors, int n_classes_with_background, int mask_dim, int proto_h, int proto_w, int out_h, int out_w,
+                                         void *d_workspace, size_t workspace_bytes, uint8_t *d_masks, uint8_t *d_found)
+{
+    if (!d_scores) { set_error("amos_mask_person_masks_scores_device: invalid argument"); return AMOS_ERR_INVALID; }
+    return person_masks(stream, d_loc, nullptr, d_scores, d_coef, d_priors, d_proto, batch, n_priors, n_classes_with_background, mask_dim, proto_h, proto_w, out_h, out_w,
+                        d_workspace, workspace_bytes, d_masks, d_found);
+}
+
+static int person_masks(void *stream, const float *d_loc, const float *d_conf, const float *d_scores, const float *d_coef, const float *d_priors, const float *d_proto,
+                        int batch, int n_priors, int n_classes_with_background, int mask_dim, int proto_h, int proto_w, int out_h, int out_w, void *d_workspace,
+                        size_t workspace_bytes, uint8_t *d_masks, uint8_t *d_found)
+{
     const int B = batch, P = n_priors, C1 = n_classes_with_background, C = C1 - 1, D = mask_dim, k = AMOS_MASK_NMS_TOP_K, nd = AMOS_MASK_TOP_K_DISPLAY;
-    if (!d_loc || !d_conf || !d_coef || !d_priors || !d_proto || !d_workspace || !d_masks || !d_found || B < 1 || B > 65535 || P < k || C1 < 2 || C1 > 200 ||
+    if (!d_loc || (!d_conf && !d_scores) || !d_coef || !d_priors || !d_proto || !d_workspace || !d_masks || !d_found || B < 1 || B > 65535 || P < k || C1 < 2 || C1 > 200 ||
         D < 4 || D % 4 != 0 || proto_h < 1 || proto_w < 1 || out_h < 1 || out_w < 1 || (size_t)C * k * 4 > 64 * 1024 ||
         ((uintptr_t)d_loc | (uintptr_t)d_priors | (uintptr_t)d_proto | (uintptr_t)d_coef | (uintptr_t)d_workspace) % 16 != 0) {
         set_error("amos_mask_person_masks_device: invalid argument (16-byte aligned tensors, mask_dim %% 4 == 0, at most %d class lists of %d)", 16384 / k, k);
@@ -984,7 +1058,8 @@ int amos_mask_person_masks_device(void *stream, const float *d_loc, const float 
     if (workspace_bytes < l.total) { set_error("amos_mask_person_masks_device: workspace of %zu bytes, %zu needed", workspace_bytes, l.total); return AMOS_ERR_CAPACITY; }
     uint8_t *ws = (uint8_t *)d_workspace;
     float4 *boxes = (float4 *)(ws + l.boxes);
-    float *cls = (float *)(ws + l.cls), *topv = (float *)(ws + l.topv), *alive = (float *)(ws + l.alive), *selCoef = (float *)(ws + l.selCoef);
+    const float *cls = d_scores ? d_scores : (const float *)(ws + l.cls);
+    float *topv = (float *)(ws + l.topv), *alive = (float *)(ws + l.alive), *selCoef = (float *)(ws + l.selCoef);
     long long *topi = (long long *)(ws + l.topi);
     float4 *selRect = (float4 *)(ws + l.selRect);
     uint8_t *flags = ws + l.flags;
@@ -992,7 +1067,7 @@ int amos_mask_person_masks_device(void *stream, const float *d_loc, const float 
     hipStream_t st = (hipStream_t)stream;
     const int total = B * P;
     hipLaunchKernelGGL(k_decode_boxes, dim3((total + 255) / 256), dim3(256), 0, st, (const float4 *)d_loc, (const float4 *)d_priors, boxes, P, total);
-    int rc = amos_mask_class_scores_device(stream, d_conf, cls, B, P, C1, AMOS_MASK_CONF_THRESH);
+    int rc = d_scores ? AMOS_OK : amos_mask_class_scores_device(stream, d_conf, (float *)(ws + l.cls), B, P, C1, AMOS_MASK_CONF_THRESH);
     if (rc != AMOS_OK) return rc;
     rc = amos_mask_topk_rows_sparse_device(stream, cls, topv, topi, B * C, P, k, -1.f);  // (k_class_scores writes -1 for every prior under the threshold)
     if (rc != AMOS_OK) return rc;

@@ -87,12 +87,20 @@ class MaskEngine:
         cur.wait_event(ev_out)
         return out
 
-    def _forward(self, x):
+    def _masks_of(self, x, width, height):
+        """(masks, found) of a network input: the detector's own pass -- where the fused post-processing will take the outputs, the head's
+        kernel writes Detect's class scores directly and no softmax tensor (YolactR50.forward(scores_only=True); AMOS_MASK_HEAD_SCORES=0: the
+        softmax tensor and the separate class-score pass, A/B runs)."""
+        scores_only = (self.device.type == "cuda" and self.conv_dtype is None and x.dtype == torch.float32
+                       and os.environ.get("AMOS_MASK_HEAD_SCORES", "1") != "0" and os.environ.get("AMOS_MASK_FUSED_POST", "1") != "0")
+        return self._person_masks(self._forward(x, scores_only), width, height)
+
+    def _forward(self, x, scores_only=False):
         # (the project's stem kernel reads the input through its strides: no layout copy of the network input for it)
         if self.channels_last and not (self.conv_dtype is None and x.dtype == torch.float32 and stem_kernel_enabled() and _stem_eligible(self.net.backbone.conv1)):
             x = x.contiguous(memory_format=torch.channels_last)
         if self.conv_dtype is None:
-            return self.net(x)
+            return self.net(x, scores_only) if scores_only else self.net(x)
         with torch.autocast(self.device.type, dtype=self.conv_dtype):
             pred = self.net(x)
         return {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in pred.items()}
@@ -123,6 +131,8 @@ class MaskEngine:
     def _person_masks(pred, width, height):
         """(masks uint8 [B, height, width], found bool [B]) of a forward's outputs: the fused library call on the GPU, the torch ops elsewhere"""
         fused = person_masks_fused(pred, width, height)
+        if fused is None and "conf" not in pred:
+            raise RuntimeError("the pass was run for the fused post-processing (class scores only), which does not apply to its outputs")
         return fused if fused is not None else person_mask_batch(detect_batch(pred), width, height)
 
     @torch.no_grad()
@@ -132,8 +142,7 @@ class MaskEngine:
         B = x.shape[0]
         out = torch.zeros((B, height, width), dtype=torch.uint8, device=self.device)
         for b0 in range(0, B, chunk):
-            pred = self._forward(x[b0:b0 + chunk])
-            masks, _found = self._person_masks(pred, width, height)
+            masks, _found = self._masks_of(x[b0:b0 + chunk], width, height)
             out[b0:b0 + masks.shape[0]] = masks
         return out
 
@@ -149,7 +158,7 @@ class MaskEngine:
         self._g_in = torch.zeros((batch, 3, 550, 550), dtype=torch.float32, device=self.device)
 
         def body():
-            return self._person_masks(self._forward(self._g_in), 640, 480)
+            return self._masks_of(self._g_in, 640, 480)
 
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -208,8 +217,7 @@ class MaskEngine:
                 chw = cxx_marshalling(part)                                      # [b, 3, 640, 480]
                 imgs = resize_f32_cv(chw.permute(0, 2, 3, 1) * 255, 640, 480)    # [b, 480, 640, 3]
                 x = fast_base_transform(imgs)
-            pred = self._forward(x)
-            masks, _found = self._person_masks(pred, 640, 480)                  # eval_image resizes to 640 x 480 whatever came in
+            masks, _found = self._masks_of(x, 640, 480)                         # eval_image resizes to 640 x 480 whatever came in
             out[b0:b0 + part.shape[0]] = masks
         return out
 
@@ -239,7 +247,7 @@ class FrameSession:
 
         def body():
             self._pre.run(self._d_frame.data_ptr(), 1, self._net_in.data_ptr())
-            return engine._person_masks(engine._forward(self._net_in), 640, 480)
+            return engine._masks_of(self._net_in, 640, 480)
 
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.stream):

@@ -19,6 +19,7 @@ import torch.nn.functional as F
 NUM_CLASSES = 81        # 80 COCO classes + background, data/config.py:660
 MASK_DIM = 32           # prototypes, config mask_proto_net last entry
 FPN_FEATURES = 256      # fpn_base.num_features
+CONF_THRESH = 0.05      # Detect's class-confidence threshold (detect.py CONF_THRESH, layers/functions/detection.py:27)
 MAX_SIZE = 550          # yolact_base_config.max_size
 PRED_SCALES = (24, 48, 96, 192, 384)   # one scale per pyramid level
 ASPECT_RATIOS = (1.0, 0.5, 2.0)        # pred_aspect_ratios; anchors are squares (use_square_anchors)
@@ -525,7 +526,7 @@ class SharedHead(nn.Module):
         merged = getattr(self, "merged", None)
         return not (merged is None or not x0.is_cuda or x0.dtype != torch.float32 or torch.is_autocast_enabled() or os.environ.get("AMOS_MASK_FUSED_HEAD", "1") == "0")
 
-    def fused_outputs(self, pyramid, n_priors, br=None, out=None):
+    def fused_outputs(self, pyramid, n_priors, br=None, out=None, scores=None):
         """All levels' outputs, concatenated, softmax / tanh applied: (loc [B, P, 4], conf [B, P, 81], coef [B, P, 32]), or None when the
         fused path does not apply (no merged layer, not float32 channels-last on the GPU).  Per level: the upfeature convolution, the
         merged output convolution WITHOUT its bias, then ONE HIP kernel (amos_mask_head_outputs_device) that adds the bias, takes the
@@ -533,12 +534,14 @@ class SharedHead(nn.Module):
         strided reshape copies per level, three concatenations, a softmax and a tanh pass.
         br (Branches): the levels run on the side streams that made their inputs (FeaturePyramid.forward: levels 2 - 4 on side 0, level 1 on
         side 1) and level 0 on side 2, so the caller's stream is free for the prototype network; `out` = the three tensors, allocated by the
-        caller BEFORE any side stream started (they are written there and read on the caller's stream after its join)."""
+        caller BEFORE any side stream started (they are written there and read on the caller's stream after its join).
+        scores: a [B, classes, P] tensor (alloc_scores) -> Detect's class scores come out of the same kernel (amos_mask_head_outputs_scores_device:
+        what amos_mask_class_scores_device would make of conf, bit for bit); with out[1] None the softmax tensor itself is not written."""
         x0 = pyramid[0]
         if not self.fused_applies(x0):
             return None
         merged = self.merged
-        from .. import mask_head_outputs
+        from .. import mask_head_outputs_scores
         b, dev = x0.shape[0], x0.device
         n_anchor = self.bbox_layer.out_channels // 4
         if out is None:
@@ -560,8 +563,9 @@ class SharedHead(nn.Module):
             if not raw.is_contiguous(memory_format=torch.channels_last):
                 raw = raw.contiguous(memory_format=torch.channels_last)
             cells = raw.shape[2] * raw.shape[3]
-            mask_head_outputs(torch.cuda.current_stream(dev).cuda_stream, raw.data_ptr(), merged.bias.data_ptr(), loc.data_ptr(), conf.data_ptr(), coef.data_ptr(), b,
-                              cells, raw.shape[1], n_anchor, NUM_CLASSES, MASK_DIM, n_priors, offs[i])
+            mask_head_outputs_scores(torch.cuda.current_stream(dev).cuda_stream, raw.data_ptr(), merged.bias.data_ptr(), loc.data_ptr(),
+                                     conf.data_ptr() if conf is not None else None, coef.data_ptr(), scores.data_ptr() if scores is not None else None,
+                                     CONF_THRESH, b, cells, raw.shape[1], n_anchor, NUM_CLASSES, MASK_DIM, n_priors, offs[i])
 
         if br is not None and len(pyramid) == 5:
             with br.side(2 if len(br.streams) >= 3 else None):  # behind the caller's stream: level 0 was made there
@@ -576,9 +580,13 @@ class SharedHead(nn.Module):
                 level(i)
         return loc, conf, coef
 
-    def alloc_outputs(self, b, n_priors, dev):
-        return (torch.empty((b, n_priors, 4), dtype=torch.float32, device=dev), torch.empty((b, n_priors, NUM_CLASSES), dtype=torch.float32, device=dev),
+    def alloc_outputs(self, b, n_priors, dev, conf=True):
+        return (torch.empty((b, n_priors, 4), dtype=torch.float32, device=dev),
+                torch.empty((b, n_priors, NUM_CLASSES), dtype=torch.float32, device=dev) if conf else None,
                 torch.empty((b, n_priors, MASK_DIM), dtype=torch.float32, device=dev))
+
+    def alloc_scores(self, b, n_priors, dev):
+        return torch.empty((b, NUM_CLASSES - 1, n_priors), dtype=torch.float32, device=dev)
 
     def forward(self, x):
         b = x.shape[0]
@@ -618,6 +626,15 @@ def build_priors(conv_sizes, device="cpu"):
                     side = scale * math.sqrt(ar) / MAX_SIZE
                     rows.append((x, y, side, side))
     return torch.tensor(rows, dtype=torch.float32, device=device)
+
+
+def _outputs(loc, conf, cls, coef, priors, proto):
+    out = {"loc": loc, "mask": coef, "priors": priors, "proto": proto}
+    if conf is not None:
+        out["conf"] = conf
+    if cls is not None:
+        out["cls"] = cls
+    return out
 
 
 class YolactR50(nn.Module):
@@ -665,9 +682,11 @@ class YolactR50(nn.Module):
             merged._apply(fn, *args, **kwargs)
         return self
 
-    def forward(self, x):
+    def forward(self, x, scores_only=False):
         """x: [B, 3, 550, 550] normalised RGB.  Returns raw network outputs (before Detect):
-        loc [B, P, 4], conf [B, P, 81] (softmax), mask [B, P, 32] (tanh), priors [P, 4], proto [B, 138, 138, 32] (ReLU)."""
+        loc [B, P, 4], conf [B, P, 81] (softmax), mask [B, P, 32] (tanh), priors [P, 4], proto [B, 138, 138, 32] (ReLU).
+        scores_only (the detector's own passes, where the fused head applies): instead of conf, "cls" [B, 80, P] -- Detect's thresholded,
+        transposed class scores, written by the head's output kernel (fused_outputs); mask/post.py takes either."""
         feats = self.backbone(x)[1:]
         head = self.prediction_layers[0]
         pn = self.proto_net  # conv, relu, conv, relu, conv, relu, upsample, relu, conv, relu, conv (+ the final ReLU)
@@ -691,20 +710,22 @@ class YolactR50(nn.Module):
             for _ in range(2):  # the two extra levels: 3 x 3, stride 2, padding 1
                 sizes.append(((sizes[-1][0] - 1) // 2 + 1, (sizes[-1][1] - 1) // 2 + 1))
             n_priors = sum(h * w for h, w in sizes) * (head.bbox_layer.out_channels // 4)
-            out = head.alloc_outputs(x.shape[0], n_priors, x.device)  # before any side stream starts
+            out = head.alloc_outputs(x.shape[0], n_priors, x.device, conf=not scores_only)  # before any side stream starts
+            cls = head.alloc_scores(x.shape[0], n_priors, x.device) if scores_only else None
             pyramid = self.fpn(feats, br)
             priors = priors_of(pyramid)
-            loc, conf, coef = head.fused_outputs(pyramid, priors.shape[0], br, out)
+            loc, conf, coef = head.fused_outputs(pyramid, priors.shape[0], br, out, cls)
             proto = prototypes(pyramid[0])
             br.join()
-            return {"loc": loc, "conf": conf, "mask": coef, "priors": priors, "proto": proto}
+            return _outputs(loc, conf, cls, coef, priors, proto)
         pyramid = self.fpn(feats)
         proto = prototypes(pyramid[0])
         priors = priors_of(pyramid)
-        fused = head.fused_outputs(pyramid, priors.shape[0])
-        if fused is not None:
-            loc, conf, coef = fused
-            return {"loc": loc, "conf": conf, "mask": coef, "priors": priors, "proto": proto}
+        if head.fused_applies(pyramid[0]):
+            out = head.alloc_outputs(x.shape[0], priors.shape[0], x.device, conf=not scores_only)
+            cls = head.alloc_scores(x.shape[0], priors.shape[0], x.device) if scores_only else None
+            loc, conf, coef = head.fused_outputs(pyramid, priors.shape[0], None, out, cls)
+            return _outputs(loc, conf, cls, coef, priors, proto)
         locs, confs, coefs = zip(*(head(p) for p in pyramid))
         return {"loc": torch.cat(locs, 1), "conf": F.softmax(torch.cat(confs, 1), -1), "mask": torch.cat(coefs, 1),
                 "priors": priors, "proto": proto}

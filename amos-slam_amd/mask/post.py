@@ -96,22 +96,27 @@ def person_masks_fused(pred, w, h):
     arithmetic operation by operation, except the 32-term prototype sums (sequential fused multiply-adds here, a BLAS kernel's order there:
     float32 rounding).  Returns (uint8 [B, h, w], bool [B]) like person_mask_batch, or None where it does not apply (not float32 on a
     GPU): the caller then takes the torch path."""
-    loc, conf, coef, priors, proto = pred["loc"], pred["conf"], pred["mask"], pred["priors"], pred["proto"]
-    if not (loc.is_cuda and all(t.dtype == torch.float32 for t in (loc, conf, coef, priors, proto))) or proto.dim() != 4:
+    loc, coef, priors, proto = pred["loc"], pred["mask"], pred["priors"], pred["proto"]
+    cls = pred.get("cls")          # Detect's class scores [B, classes, P] from the head's own kernel (YolactR50.forward(scores_only=True)) ...
+    conf = pred.get("conf")        # ... or the softmax tensor [B, P, 1 + classes]
+    scores = cls if cls is not None else conf
+    if scores is None or not (loc.is_cuda and all(t.dtype == torch.float32 for t in (loc, scores, coef, priors, proto))) or proto.dim() != 4:
         return None
     import os
     if os.environ.get("AMOS_MASK_FUSED_POST", "1") == "0":   # A/B runs and the tests that compare the two paths
         return None
-    from .. import mask_person_masks, mask_post_workspace_bytes
-    loc, conf, coef, priors, proto = (t.contiguous() for t in (loc, conf, coef, priors, proto))
+    from .. import mask_person_masks, mask_person_masks_scores, mask_post_workspace_bytes
+    loc, scores, coef, priors, proto = (t.contiguous() for t in (loc, scores, coef, priors, proto))
     B, P = loc.shape[:2]
     ph, pw, D = proto.shape[1:]
-    if P < 200 or (conf.shape[2] - 1) * 200 * 4 > 64 * 1024 or D % 4 != 0:
+    c1 = cls.shape[1] + 1 if cls is not None else conf.shape[2]
+    if P < 200 or (c1 - 1) * 200 * 4 > 64 * 1024 or D % 4 != 0:
         return None
-    nbytes = mask_post_workspace_bytes(B, P, conf.shape[2], D, ph, pw)
+    nbytes = mask_post_workspace_bytes(B, P, c1, D, ph, pw)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=loc.device)
     out = torch.empty((B, h, w), dtype=torch.uint8, device=loc.device)
     found = torch.empty(B, dtype=torch.uint8, device=loc.device)
-    mask_person_masks(torch.cuda.current_stream(loc.device).cuda_stream, loc.data_ptr(), conf.data_ptr(), coef.data_ptr(), priors.data_ptr(), proto.data_ptr(),
-                      B, P, conf.shape[2], D, ph, pw, h, w, ws.data_ptr(), nbytes, out.data_ptr(), found.data_ptr())
+    (mask_person_masks_scores if cls is not None else mask_person_masks)(
+        torch.cuda.current_stream(loc.device).cuda_stream, loc.data_ptr(), scores.data_ptr(), coef.data_ptr(), priors.data_ptr(), proto.data_ptr(),
+        B, P, c1, D, ph, pw, h, w, ws.data_ptr(), nbytes, out.data_ptr(), found.data_ptr())
     return out, found.bool()

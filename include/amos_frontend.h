@@ -487,6 +487,12 @@ int amos_mask_person_mask_device(void *stream, const float *d_masks, const uint8
 int amos_mask_head_outputs_device(void *stream, const float *d_raw, const float *d_bias, float *d_loc, float *d_conf, float *d_coef,
                                   int batch, int cells, int channels_padded, int anchors, int n_classes_with_background, int mask_dim,
                                   int n_priors_total, int prior_offset);
+/* The same with Detect's class scores written by the same kernel: d_scores [batch][classes][n_priors_total] (background column dropped, -1 for
+ * every prior whose best class is not above `threshold`) exactly as amos_mask_class_scores_device makes them from d_conf -- one pass over the
+ * softmax tensor saved, and d_conf itself may be NULL when only the detector reads the head (d_scores may be NULL instead: the plain form). */
+int amos_mask_head_outputs_scores_device(void *stream, const float *d_raw, const float *d_bias, float *d_loc, float *d_conf, float *d_coef, float *d_scores,
+                                         float threshold, int batch, int cells, int channels_padded, int anchors, int n_classes_with_background,
+                                         int mask_dim, int n_priors_total, int prior_offset);
 
 /* Row-wise top-k, sorted descending (the per-class `scores.topk(200)` of Fast NMS, layers/functions/detection.py:103-111): d_x
  * [rows][n] -> d_values [rows][k], d_indices [rows][k] (int64, as torch.topk returns them).  Values equal torch.topk's; among equal
@@ -518,6 +524,12 @@ int amos_mask_person_masks_device(void *stream, const float *d_loc, const float 
                                   const float *d_proto, int batch, int n_priors, int n_classes_with_background, int mask_dim, int proto_h,
                                   int proto_w, int out_h, int out_w, void *d_workspace, size_t workspace_bytes, uint8_t *d_masks,
                                   uint8_t *d_found);
+/* The same from the class scores amos_mask_head_outputs_scores_device wrote (d_scores [batch][classes][n_priors], threshold
+ * AMOS_MASK_CONF_THRESH) instead of the softmax tensor: six launches. */
+int amos_mask_person_masks_scores_device(void *stream, const float *d_loc, const float *d_scores, const float *d_coef, const float *d_priors,
+                                         const float *d_proto, int batch, int n_priors, int n_classes_with_background, int mask_dim, int proto_h,
+                                         int proto_w, int out_h, int out_w, void *d_workspace, size_t workspace_bytes, uint8_t *d_masks,
+                                         uint8_t *d_found);
 
 
 /* ---------------------------------------------------------------- SLIC superpixels (8f-2) ---- */

@@ -1119,6 +1119,60 @@ def test_fused_head_outputs_equal_the_torch_ops(mask, gpu_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_head_kernel_writes_the_class_scores_of_detect(mask, gpu_lib, monkeypatch):
+    """amos_mask_head_outputs_scores_device: the prediction head's output kernel also writes Detect's class scores [B][80][P] (background dropped,
+    -1 under the confidence threshold) -- bit for bit what amos_mask_class_scores_device makes of the softmax tensor the same kernel writes; with
+    the softmax output left out the other outputs do not change.  Then the engine: a pass run for the detector (scores only, the default) gives
+    the masks of the pass through the softmax tensor (AMOS_MASK_HEAD_SCORES=0), eager at 1 and 5 frames."""
+    torch.manual_seed(23)
+    st = torch.cuda.current_stream().cuda_stream
+    cl = torch.channels_last
+    for b, h, w, P, off in ((2, 7, 5, 200, 50), (1, 69, 69, 19248, 0), (3, 9, 9, 243, 0)):
+        raw = (torch.randn(b, 384, h, w, device="cuda") * 3).contiguous(memory_format=cl)
+        raw[:, :, 0, :] *= 0.01   # flat class distributions in the first row of cells: nothing above the threshold there
+        bias = torch.randn(384, device="cuda") * 0.01
+        cells = h * w
+        outs = {}
+        for want_conf, want_scores in ((True, True), (False, True), (True, False)):
+            loc, conf, coef = torch.zeros(b, P, 4, device="cuda"), torch.zeros(b, P, 81, device="cuda"), torch.zeros(b, P, 32, device="cuda")
+            cls = torch.full((b, 80, P), 7.0, device="cuda")
+            gpu_lib.mask_head_outputs_scores(st, raw.data_ptr(), bias.data_ptr(), loc.data_ptr(), conf.data_ptr() if want_conf else None, coef.data_ptr(),
+                                             cls.data_ptr() if want_scores else None, 0.05, b, cells, 384, 3, 81, 32, P, off)
+            torch.cuda.synchronize()
+            outs[(want_conf, want_scores)] = (loc, conf, coef, cls)
+        loc, conf, coef, cls = outs[(True, True)]
+        plain = outs[(True, False)]
+        assert torch.equal(loc, plain[0]) and torch.equal(conf, plain[1]) and torch.equal(coef, plain[2])  # the plain form's outputs
+        only = outs[(False, True)]
+        assert torch.equal(only[0], loc) and torch.equal(only[2], coef) and torch.equal(only[3], cls) and float(only[1].abs().max()) == 0
+        n = cells * 3
+        want = torch.full((b, 80, n), float("nan"), device="cuda")
+        gpu_lib.mask_class_scores(st, conf[:, off:off + n].contiguous().data_ptr(), want.data_ptr(), b, n, 81, 0.05)
+        torch.cuda.synchronize()
+        assert torch.equal(cls[:, :, off:off + n], want) and bool((want == -1).any()) and bool((want > 0.05).any())
+        if off:
+            assert bool((cls[:, :, :off] == 7.0).all()) and bool((cls[:, :, off + n:] == 7.0).all())  # nothing outside the level's priors
+    with pytest.raises(gpu_lib.AmosError):
+        gpu_lib.mask_head_outputs_scores(st, raw.data_ptr(), bias.data_ptr(), loc.data_ptr(), None, coef.data_ptr(), None, 0.05, b, cells, 384, 3, 81, 32, P, off)
+    eng = _engine(mask, "cuda:0", "seed0").prepare()
+    frames = torch.from_numpy(np.stack([mask_cases.frame(c) for c in ("seed0", "ref122_w0", "tum_w0", "seed0", "ref122_w0")])).cuda()
+    frames[3:] = frames[3:].flip(2)
+    seen = []
+    real = eng.net.forward
+    monkeypatch.setattr(eng.net, "forward", lambda x, scores_only=False: (seen.append(scores_only), real(x, scores_only))[1])
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AMOS_MASK_HEAD_SCORES", mode)
+        del seen[:]
+        got[mode] = (eng.eval_bgr_batch(frames[:1], chunk=1).clone(), eng.eval_bgr_batch(frames, chunk=5).clone())
+        assert seen == [mode == "1"] * 2
+    assert torch.equal(got["1"][0], got["0"][0]) and torch.equal(got["1"][1], got["0"][1]) and int((got["1"][1] > 0).sum()) > 0
+    with torch.no_grad():
+        pred = eng._forward(eng._preprocess_hip(frames[:2]), True)
+    assert "conf" not in pred and pred["cls"].shape == (2, 80, 19248)
+
+
+@pytest.mark.gpu
 def test_topk_rows_kernel_against_torch_topk(mask, gpu_lib):
     """amos_mask_topk_rows_device against torch.topk(sorted=True): the values bit for bit; the indices point at those values, are unique
     per row, and equal torch's wherever the row's top values are distinct.  Rows of distinct random values, rows that are mostly one
