@@ -200,9 +200,60 @@ def prepare_stem_weight(module):
     return n
 
 
+class Blocked:
+    """A float32 activation in the channel-blocked layout [b][c / 8][h][w][8] (`data`), with its logical NCHW `shape`.  The F(2 x 4) Winograd
+    kernel reads 8 input channels of every pixel of its patch per stage: blocked, those are contiguous whole cache lines used once;
+    channels-last, a quarter of every line four times (amos_mask_winograd24_conv_layout_device; same bits, 1.5 - 3.6 % faster per layer at 64
+    frames).  Only a chain of layers that ALL run on that kernel can hand such a tensor on: the pyramid's level 0 -> the prototype network
+    and level 0's prediction head (YolactR50.forward decides, blocked_chain_for)."""
+    __slots__ = ("data", "shape")
+    is_cuda = True
+    dtype = torch.float32
+
+    def __init__(self, data, shape):
+        self.data, self.shape = data, tuple(shape)
+
+    @property
+    def device(self):
+        return self.data.device
+
+
+def _winograd24_layout(conv, x, bias, residual, relu, out_blocked):
+    """One F(2 x 4) launch with either layout on either side; x: Blocked or a channels-last tensor."""
+    from .. import mask_winograd24_conv_layout
+    in_blocked = isinstance(x, Blocked)
+    b, _, h, w = x.shape
+    dev = x.device
+    if out_blocked:
+        y = Blocked(torch.empty((b, conv.out_channels // 8, h, w, 8), device=dev, dtype=torch.float32), (b, conv.out_channels, h, w))
+    else:
+        y = torch.empty((b, conv.out_channels, h, w), device=dev, dtype=torch.float32, memory_format=torch.channels_last)
+    mask_winograd24_conv_layout(torch.cuda.current_stream(dev).cuda_stream, (x.data if in_blocked else x).data_ptr(), _winograd_weight(conv).data_ptr(),
+                                bias.data_ptr() if bias is not None else None, residual.data_ptr() if residual is not None else None,
+                                (y.data if out_blocked else y).data_ptr(), b, h, w, conv.in_channels, conv.out_channels, relu, in_blocked, out_blocked)
+    return y
+
+
+def blocked_chain_for(p3_in, convs_69, convs_138):
+    """May level 0 of the pyramid (made from p3_in, [b, 256, 69, 69]) travel channel-blocked through the prototype network and its prediction head?
+    Every layer on the way must run on the F(2 x 4) Winograd kernel at this launch size (the wide form: at least 8 frames), float32, on the GPU.
+    AMOS_MASK_BLOCKED_CHAIN=0: never (A/B runs, tests)."""
+    if os.environ.get("AMOS_MASK_BLOCKED_CHAIN", "1") == "0" or winograd_family() != "24" or torch.is_autocast_enabled():
+        return False
+    if not (p3_in.is_cuda and p3_in.dtype == torch.float32 and p3_in.shape[0] >= 8 and p3_in.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    b, _, h, w = p3_in.shape
+    ok = all(c.bias is not None and c.weight.dtype == torch.float32 and c.in_channels % 8 == 0 and c.out_channels % 8 == 0 and
+             winograd_rule(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding, c.dilation, c.groups, b, h, w) for c in convs_69)
+    return ok and all(c.bias is not None and c.weight.dtype == torch.float32 and
+                      winograd_rule(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding, c.dilation, c.groups, b, 2 * h, 2 * w) for c in convs_138)
+
+
 def conv_raw(conv, x):
     """The convolution alone (no bias): Winograd / implicit GEMM of this project where they apply, else the library."""
     cl = torch.channels_last
+    if isinstance(x, Blocked):
+        return _winograd24_layout(conv, x, None, None, False, False)
     if x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and x.is_contiguous(memory_format=cl) and conv.weight.dtype == torch.float32:
         if _winograd_conv(conv, x):
             b, _, h, w = x.shape
@@ -213,12 +264,16 @@ def conv_raw(conv, x):
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
-def conv_bias_act(conv, x, relu, residual=None):
+def conv_bias_act(conv, x, relu, residual=None, out_blocked=False):
     """conv -> + bias -> (+ residual) -> (ReLU).  On the GPU with float32 channels-last activations the bias, the residual
     and the ReLU are ONE in-place pass by a HIP kernel of this project (amos_mask_bias_act_device) behind MIOpen's
     convolution instead of PyTorch's three elementwise passes; the summation order is the same, so are the bits.  The large
     1 x 1 convolutions go to this project's MFMA GEMM with that epilogue fused (_gemm_conv; float32 rounding apart from MIOpen).
-    Anywhere else (CPU tests, autocast) the plain torch ops run."""
+    Anywhere else (CPU tests, autocast) the plain torch ops run.  x Blocked / out_blocked: a link of the channel-blocked chain (Blocked)."""
+    if isinstance(x, Blocked) or out_blocked:
+        if residual is not None:
+            raise ValueError("conv_bias_act: no residual in the channel-blocked chain")
+        return _winograd24_layout(conv, x, conv.bias, None, relu, out_blocked)
     if x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and not torch.is_autocast_enabled():
         cl = torch.channels_last
         if _winograd_conv(conv, x) and x.is_contiguous(memory_format=cl) and conv.weight.dtype == torch.float32 and (residual is None or (
@@ -261,6 +316,18 @@ def bilinear(x, size=None, scale_factor=None, relu=False):
     """F.interpolate(x, mode="bilinear", align_corners=False), then a ReLU when asked.  Float32 channels-last tensors on the GPU
     go through this project's HIP kernel (amos_mask_bilinear_nhwc_act_device: PyTorch's channels-last kernel was 13 % of the mask
     pass); the source index and the weights are computed as PyTorch computes them."""
+    if isinstance(x, Blocked):  # [b][c / 8][h][w][8] is b x c / 8 channels-last images of 8 channels: the same kernel, the same taps
+        n, c, h, w = x.shape
+        if size is not None:
+            oh, ow = int(size[0]), int(size[1])
+            sh, sw = float(torch.tensor(h, dtype=torch.float32) / oh), float(torch.tensor(w, dtype=torch.float32) / ow)
+        else:
+            oh, ow = int(h * scale_factor), int(w * scale_factor)
+            sh = sw = float(torch.tensor(1.0, dtype=torch.float32) / scale_factor)
+        y = Blocked(torch.empty((n, c // 8, oh, ow, 8), dtype=torch.float32, device=x.device), (n, c, oh, ow))
+        from .. import mask_bilinear_nhwc
+        mask_bilinear_nhwc(torch.cuda.current_stream(x.device).cuda_stream, x.data.data_ptr(), y.data.data_ptr(), n * (c // 8), h, w, oh, ow, 8, sh, sw, relu)
+        return y
     if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last):
         n, c, h, w = x.shape
         if size is not None:
@@ -458,8 +525,8 @@ class FeaturePyramid(nn.Module):
         self.pred_layers = nn.ModuleList([nn.Conv2d(FPN_FEATURES, FPN_FEATURES, 3, padding=1) for _ in in_channels])
         self.downsample_layers = nn.ModuleList([nn.Conv2d(FPN_FEATURES, FPN_FEATURES, 3, padding=1, stride=2) for _ in range(2)])
 
-    def forward(self, feats, br=None):
-        """br (Branches): the output convolutions of the deeper levels and the two extra levels run on side streams (level 2 + P6 + P7 on side
+    def forward(self, feats, br=None, p3_blocked=False):
+        """p3_blocked: level 0 leaves channel-blocked (Blocked; YolactR50.forward asked blocked_chain_for).  br (Branches): the output convolutions of the deeper levels and the two extra levels run on side streams (level 2 + P6 + P7 on side
         0, level 1 on side 1, level 0 stays on the caller's stream); the caller joins."""
         n = len(feats)
         merged = [None] * n
@@ -479,13 +546,13 @@ class FeaturePyramid(nn.Module):
                     extra.append(down(extra[-1] if extra else outs[2]))
             with br.side(1, fork=len(br.streams) > 1):  # (one side stream: it continues there, no second dependency on the main stream)
                 outs[1] = conv_bias_act(self.pred_layers[1], merged[1], True)
-            outs[0] = conv_bias_act(self.pred_layers[2], merged[0], True)
+            outs[0] = conv_bias_act(self.pred_layers[2], merged[0], True, out_blocked=p3_blocked)
             outs += extra
             br.hold(*outs)
             return outs
         for k, pred in enumerate(self.pred_layers):
             j = n - 1 - k
-            outs[j] = conv_bias_act(pred, merged[j], True)
+            outs[j] = conv_bias_act(pred, merged[j], True, out_blocked=p3_blocked and j == 0)
         for down in self.downsample_layers:
             outs.append(down(outs[-1]))
         return outs
@@ -558,7 +625,7 @@ class SharedHead(nn.Module):
 
         def level(i):
             x = pyramid[i]
-            u = conv_bias_act(self.upfeature[0], x, True)
+            u = conv_bias_act(self.upfeature[0], x, True, out_blocked=isinstance(x, Blocked))
             raw = conv_raw(merged, u)
             if not raw.is_contiguous(memory_format=torch.channels_last):
                 raw = raw.contiguous(memory_format=torch.channels_last)
@@ -692,7 +759,8 @@ class YolactR50(nn.Module):
         pn = self.proto_net  # conv, relu, conv, relu, conv, relu, upsample, relu, conv, relu, conv (+ the final ReLU)
 
         def prototypes(p3):
-            p = conv_bias_act(pn[4], conv_bias_act(pn[2], conv_bias_act(pn[0], p3, True), True), True)
+            blk = isinstance(p3, Blocked)  # the channel-blocked chain: blocked through the three 69 x 69 layers and the resize, channels-last out of the 138 x 138 layer
+            p = conv_bias_act(pn[4], conv_bias_act(pn[2], conv_bias_act(pn[0], p3, True, out_blocked=blk), True, out_blocked=blk), True, out_blocked=blk)
             p = conv_bias_act(pn[10], conv_bias_act(pn[8], bilinear(p, scale_factor=2, relu=True), True), True)  # pn[6] (upsample) + pn[7] (ReLU) in one pass
             return p.permute(0, 2, 3, 1).contiguous()
 
@@ -703,6 +771,9 @@ class YolactR50(nn.Module):
                 self._prior_cache[key] = build_priors(sizes, x.device)
             return self._prior_cache[key]
 
+        # level 0 of the pyramid channel-blocked through the prototype network and its head, where every layer on the way is an F(2 x 4) launch
+        chain = (len(feats) == 3 and head.fused_applies(feats[0]) and getattr(head, "merged", None) is not None and
+                 blocked_chain_for(feats[0], (self.fpn.pred_layers[2], pn[0], pn[2], pn[4], head.upfeature[0], head.merged), (pn[8],)))
         br = branches_for(x) if head.fused_applies(feats[0]) and len(feats) == 3 else None
         if br is not None:
             # a small pass: the pyramid's side levels and the prediction head on side streams, the prototype network on this one (Branches)
@@ -712,13 +783,13 @@ class YolactR50(nn.Module):
             n_priors = sum(h * w for h, w in sizes) * (head.bbox_layer.out_channels // 4)
             out = head.alloc_outputs(x.shape[0], n_priors, x.device, conf=not scores_only)  # before any side stream starts
             cls = head.alloc_scores(x.shape[0], n_priors, x.device) if scores_only else None
-            pyramid = self.fpn(feats, br)
+            pyramid = self.fpn(feats, br, chain)
             priors = priors_of(pyramid)
             loc, conf, coef = head.fused_outputs(pyramid, priors.shape[0], br, out, cls)
             proto = prototypes(pyramid[0])
             br.join()
             return _outputs(loc, conf, cls, coef, priors, proto)
-        pyramid = self.fpn(feats)
+        pyramid = self.fpn(feats, None, chain)
         proto = prototypes(pyramid[0])
         priors = priors_of(pyramid)
         if head.fused_applies(pyramid[0]):

@@ -38,7 +38,7 @@ def _engine(mask, device, case="seed0"):
 
 def _spy_winograd(gpu_lib, monkeypatch, calls, lo, hi):
     """Records arguments [lo:hi] of every Winograd convolution launch of either family (F(2 x 2): mask_winograd_conv, F(2 x 4): mask_winograd24_conv)."""
-    for name in ("mask_winograd_conv", "mask_winograd24_conv"):
+    for name in ("mask_winograd_conv", "mask_winograd24_conv", "mask_winograd24_conv_layout"):  # (the layout form: the same argument positions)
         real = getattr(gpu_lib, name)
         monkeypatch.setattr(gpu_lib, name, lambda *a, _real=real: (calls.append(a[lo:hi]), _real(*a))[1])
 
@@ -1323,6 +1323,64 @@ def test_mask_pass_as_one_hip_graph_equals_the_eager_pass(mask, gpu_lib):
         assert torch.equal(torch.where(found[:, None, None], masks, torch.zeros_like(masks)), want)
     with pytest.raises(RuntimeError):
         eng.eval_bgr_graph(frames[:1])
+
+
+@pytest.mark.gpu
+def test_channel_blocked_chain_gives_the_channels_last_pass(mask, gpu_lib, monkeypatch):
+    """Level 0 of the pyramid channel-blocked ([b][c / 8][h][w][8]) through the prototype network and its prediction head (passes of at least 8
+    frames where every layer on the way is an F(2 x 4) launch: net.blocked_chain_for) against AMOS_MASK_BLOCKED_CHAIN=0: the same kernels' other
+    layout, the same arithmetic -- the same bits in every network output.  Seven layout launches per pass (pyramid output, three + one
+    prototype layers, the head's two), none at 4 frames (the small-launch form keeps channels-last)."""
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    eng = _engine(mask, "cuda:0", "seed0").prepare()
+    frames = torch.from_numpy(np.stack([mask_cases.frame(c) for c in ("seed0", "ref122_w0", "tum_w0", "blobs7_w1")] * 2)).cuda()
+    frames[4:] = frames[4:].flip(2)
+    calls = []
+    real = gpu_lib.mask_winograd24_conv_layout
+    monkeypatch.setattr(gpu_lib, "mask_winograd24_conv_layout", lambda *a: (calls.append((a[7], a[8], a[12], a[13])), real(*a))[1])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AMOS_MASK_BLOCKED_CHAIN", mode)
+        del calls[:]
+        with torch.no_grad():
+            pred = eng._forward(eng._preprocess_hip(frames))
+        torch.cuda.synchronize()
+        out[mode] = {k: pred[k].clone() for k in ("loc", "conf", "mask", "proto")}
+        if mode == "1":
+            assert sorted(calls) == sorted([(69, 69, False, True), (69, 69, True, True), (69, 69, True, True), (69, 69, True, True), (138, 138, True, False),
+                                            (69, 69, True, True), (69, 69, True, False)]), calls
+        else:
+            assert not calls
+    # (the passes share no bits by themselves: at 8 frames the lateral layers are library split-k kernels that sum with atomics)
+    for k in out["1"]:
+        assert torch.allclose(out["1"][k], out["0"][k], rtol=1e-4, atol=1e-5), k
+    # the chain's layers on ONE fixed input, both layouts: bit for bit
+    net = eng.net
+    pn, head = net.proto_net, net.prediction_layers[0]
+    torch.manual_seed(24)
+    m0 = torch.randn(8, 256, 69, 69, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = {}
+    with torch.no_grad():
+        for blk in (False, True):
+            p3 = net_mod.conv_bias_act(net.fpn.pred_layers[2], m0, True, out_blocked=blk)
+            assert isinstance(p3, net_mod.Blocked) == blk and tuple(p3.shape) == (8, 256, 69, 69)
+            p = p3
+            for j in (0, 2, 4):
+                p = net_mod.conv_bias_act(pn[j], p, True, out_blocked=blk)
+            p = net_mod.bilinear(p, scale_factor=2, relu=True)
+            assert isinstance(p, net_mod.Blocked) == blk and tuple(p.shape) == (8, 256, 138, 138)
+            p = net_mod.conv_bias_act(pn[8], p, True)
+            u = net_mod.conv_bias_act(head.upfeature[0], p3, True, out_blocked=blk)
+            raw = net_mod.conv_raw(head.merged, u)
+            res[blk] = (p, raw)
+    torch.cuda.synchronize()
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert res[True][0].is_contiguous(memory_format=torch.channels_last) and res[True][1].shape == (8, 384, 69, 69)
+    monkeypatch.setenv("AMOS_MASK_BLOCKED_CHAIN", "1")
+    del calls[:]
+    with torch.no_grad():
+        eng._forward(eng._preprocess_hip(frames[:4]))
+    assert not calls
 
 
 @pytest.mark.gpu
