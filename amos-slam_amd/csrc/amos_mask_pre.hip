@@ -124,19 +124,21 @@ __global__ __launch_bounds__(256) void k_bias_act(float *__restrict__ y, const f
 // reads per output instead of 4 (the one-output-per-thread kernel above moves 10 TB/s from L2 to L1 for this layer and is bound by that).
 // Per output the same taps, weights and order of operations as k_bilinear_nhwc: the same bits.  A block whose two rows (columns) do not
 // share their middle source row (column) -- the first and last ones, where the source index is clamped -- takes its taps one by one.
-// grid = (ceil(ceil(outW / 2) * c4 / 256), ceil(outH / 2), n)
+// grid = (ceil(ceil(outH / 2) * ceil(outW / 2) * c4 / 256), 1, n): the blocks of an image are numbered row by row, so a narrow image (the
+// channel-blocked layout is images of 8 channels: 138 threads per block row) still fills its work-groups
 template <bool kRelu>
 __global__ __launch_bounds__(256) void k_bilinear_nhwc_x2(const float *__restrict__ x, float *__restrict__ y, int inH, int inW, int outH, int outW, int c4,
                                                          float scaleH, float scaleW)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x, bw = (outW + 1) / 2;
-    if (t >= bw * c4) return;
-    const int bx = t / c4, q = t - bx * c4, n = blockIdx.z;
+    const int t = blockIdx.x * 256 + threadIdx.x, bw = (outW + 1) / 2, bh = (outH + 1) / 2, perRow = bw * c4;
+    if (t >= bh * perRow) return;
+    const int by = t / perRow, tr = t - by * perRow;
+    const int bx = tr / c4, q = tr - bx * c4, n = blockIdx.z;
     int yy[2][2], xx[2][2];
     float wy[2][2], wx[2][2];
 #pragma unroll
     for (int e = 0; e < 2; e++) {
-        float fy = __fsub_rn(__fmul_rn(scaleH, __fadd_rn((float)(2 * (int)blockIdx.y + e), 0.5f)), 0.5f);
+        float fy = __fsub_rn(__fmul_rn(scaleH, __fadd_rn((float)(2 * by + e), 0.5f)), 0.5f);
         float fx = __fsub_rn(__fmul_rn(scaleW, __fadd_rn((float)(2 * bx + e), 0.5f)), 0.5f);
         fy = fy < 0.f ? 0.f : fy;
         fx = fx < 0.f ? 0.f : fx;
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void k_bilinear_nhwc_x2(const float *__restric
     for (int ey = 0; ey < 2; ey++)
 #pragma unroll
         for (int ex = 0; ex < 2; ex++) {
-            const int oy = 2 * (int)blockIdx.y + ey, ox = 2 * bx + ex;
+            const int oy = 2 * by + ey, ox = 2 * bx + ex;
             if (oy >= outH || ox >= outW) continue;
             const float hy = wy[ey][0], ly = wy[ey][1], hx = wx[ex][0], lx = wx[ex][1];
             const float4 a = s[2 * ey][2 * ex], b = s[2 * ey][2 * ex + 1], c = s[2 * ey + 1][2 * ex], d = s[2 * ey + 1][2 * ex + 1];
@@ -485,7 +487,7 @@ int amos_mask_bilinear_nhwc_act_device(void *stream, const float *d_x, float *d_
     }
     const int c4 = channels / 4;
     if (g_bilinear_x2 && out_h == 2 * in_h && out_w == 2 * in_w && scale_h == 0.5f && scale_w == 0.5f) {  // an exact x 2 enlargement: 2 x 2 outputs per thread
-        const dim3 grid2(((out_w + 1) / 2 * c4 + 255) / 256, (out_h + 1) / 2, n);
+        const dim3 grid2((unsigned)(((long long)((out_h + 1) / 2) * ((out_w + 1) / 2) * c4 + 255) / 256), 1, n);
         if (relu) hipLaunchKernelGGL(k_bilinear_nhwc_x2<true>, grid2, dim3(256), 0, (hipStream_t)stream, d_x, d_y, in_h, in_w, out_h, out_w, c4, scale_h, scale_w);
         else hipLaunchKernelGGL(k_bilinear_nhwc_x2<false>, grid2, dim3(256), 0, (hipStream_t)stream, d_x, d_y, in_h, in_w, out_h, out_w, c4, scale_h, scale_w);
         AMOS_HIP_CHECK(hipGetLastError());
