@@ -308,6 +308,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         if (t == 0) atomicExch(&a.counters[tile], 0u);  // for the next launch
     }
     const float4 bv = a.bias ? *reinterpret_cast<const float4 *>(a.bias + n0) : float4{0.f, 0.f, 0.f, 0.f};
+    // (round 5, tools/gemm_bench.hip: a work-group ALONE on a CU keeps 88 - 97 % of the two-group rate on the compute-bound layers -- one wave per
+    // SIMD nearly fills the MFMA pipe in the main loop -- and spends 10 of its 24 us per tile outside the main loop on 256 -> 1024 + residual at
+    // 35 x 35.  Requesting the whole residual tile, 16 loads per thread, before the accumulators' trip through LDS was SLOWER, 410 -> 422 us on
+    // that layer and 658 -> 686 on 64 -> 256 at 138 x 138: 64 KB of requests in one burst delay the stage fetches of the CU's other group.)
     constexpr int kBatch = 8;  // residual loads in flight per thread
 #pragma unroll
     for (int p0 = 0; p0 < kPasses; p0 += kBatch) {
