@@ -311,7 +311,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     // (round 5, tools/gemm_bench.hip: a work-group ALONE on a CU keeps 88 - 97 % of the two-group rate on the compute-bound layers -- one wave per
     // SIMD nearly fills the MFMA pipe in the main loop -- and spends 10 of its 24 us per tile outside the main loop on 256 -> 1024 + residual at
     // 35 x 35.  Requesting the whole residual tile, 16 loads per thread, before the accumulators' trip through LDS was SLOWER, 410 -> 422 us on
-    // that layer and 658 -> 686 on 64 -> 256 at 138 x 138: 64 KB of requests in one burst delay the stage fetches of the CU's other group.)
+    // that layer and 658 -> 686 on 64 -> 256 at 138 x 138: 64 KB of requests in one burst delay the stage fetches of the CU's other group;
+    // requesting it in two halves during the last two stages of the main loop, which issue no stage fetch: 412 / 653, no change.  What a tile
+    // costs outside its main loop is the epilogue's write of the 64 KB tile: M 78 400, N 1 024 at k = 32 / 64 / 256 takes 127 / 168 / 384 us --
+    // 37 us per stage, 89 % of the pipe, on top of 90 us that no k amortises and the CU's second group does not hide.)
     constexpr int kBatch = 8;  // residual loads in flight per thread
 #pragma unroll
     for (int p0 = 0; p0 < kPasses; p0 += kBatch) {

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void k_stem_pack(const float *__restrict__ w, 
 // tools/stem_bench.hip.  Giving every second arrival at a CU a higher wave priority (a counter per CU indexed by the hardware id
 // registers, s_setprio) so that neighbours alternate made it SLOWER, 1.15 ms: the arbiter starves the other group's load / pool
 // instructions too.  Starting the work-groups of the CUs' second slots 3 - 20 us late (so that neighbours are out of phase from the first
-// round on) changed nothing: 1.11 ms.  Neither is kept.)
+// round on -- the groups of ids 256 .. 511, or whichever group finds another one resident on its CU by a per-CU counter) changed nothing: 1.10 -
+// 1.11 ms.  Neither is kept.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_stem_conv_pool(const StemArgs a)
 {
     extern __shared__ __align__(16) float lds[];
