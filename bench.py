@@ -293,11 +293,11 @@ def count_network_flops(torch, engine, batch, frames_per_forward):
         return out
 
     F.conv2d = counting
-    keep = {k: os.environ.get(k) for k in ("AMOS_MASK_CONV1X1", "AMOS_MASK_CONV3X3", "AMOS_MASK_WINOGRAD")}
+    keep = {k: os.environ.get(k) for k in ("AMOS_MASK_CONV1X1", "AMOS_MASK_CONV3X3", "AMOS_MASK_WINOGRAD", "AMOS_MASK_STEM")}
     rule_mode = keep["AMOS_MASK_WINOGRAD"] or "1"
     try:
-        for k in keep:  # for this one forward every layer goes through F.conv2d
-            os.environ[k] = "0"
+        for k in keep:  # for this one forward every layer goes through F.conv2d (the stem too: its one-kernel form never calls it)
+            os.environ[k] = "library" if k == "AMOS_MASK_STEM" else "0"
         with torch.no_grad():
             engine._forward(torch.zeros((batch, 3, 550, 550), device=engine.device))
     finally:

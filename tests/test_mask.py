@@ -1122,8 +1122,8 @@ def test_fused_head_outputs_equal_the_torch_ops(mask, gpu_lib, monkeypatch):
 def test_head_kernel_writes_the_class_scores_of_detect(mask, gpu_lib, monkeypatch):
     """amos_mask_head_outputs_scores_device: the prediction head's output kernel also writes Detect's class scores [B][80][P] (background dropped,
     -1 under the confidence threshold) -- bit for bit what amos_mask_class_scores_device makes of the softmax tensor the same kernel writes; with
-    the softmax output left out the other outputs do not change.  Then the engine: a pass run for the detector (scores only, the default) gives
-    the masks of the pass through the softmax tensor (AMOS_MASK_HEAD_SCORES=0), eager at 1 and 5 frames."""
+    the softmax output left out the other outputs do not change.  Then the engine: a pass run for the detector with scores only
+    (AMOS_MASK_HEAD_SCORES=1) gives the masks of the pass through the softmax tensor (the default), eager at 1 and 5 frames."""
     torch.manual_seed(23)
     st = torch.cuda.current_stream().cuda_stream
     cl = torch.channels_last
