@@ -335,9 +335,19 @@ def conv_kernel_roofline(torch, amos, dev, frames):
         u = torch.empty((24 if f24 else 16) * cin * cout, device=dev)
         make_u(stream.cuda_stream, w.data_ptr(), u.data_ptr(), cin, cout)
 
-        def launch():
-            conv(stream.cuda_stream, x.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, True)
-        name = "amos::k_winograd24_conv" if f24 else "amos::k_winograd_conv"
+        # the pass hands this layer its input channel-blocked ([b][c / 8][h][w][8], net.Blocked) where the chain applies (F(2 x 4), 8+ frames,
+        # AMOS_MASK_BLOCKED_CHAIN not 0): measured in that form then
+        blocked_in = f24 and frames >= 8 and os.environ.get("AMOS_MASK_BLOCKED_CHAIN", "1") != "0"
+        if blocked_in:
+            xb = x.permute(0, 2, 3, 1).reshape(frames, hw, hw, cin // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
+            del x
+
+            def launch():
+                amos.mask_winograd24_conv_layout(stream.cuda_stream, xb.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, True, True, False)
+        else:
+            def launch():
+                conv(stream.cuda_stream, x.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), frames, hw, hw, cin, cout, True)
+        name = ("amos::k_winograd24_conv, channel-blocked input" if blocked_in else "amos::k_winograd24_conv") if f24 else "amos::k_winograd_conv"
         # as executed: 2 x positions x tiles x cin x cout (tiles of 2 x 4 outputs, 24 positions; or of 2 x 2 outputs, 16 positions)
         flops = (2.0 * 24 * frames * ((hw + 1) // 2) * ((hw + 3) // 4) * cin * cout) if f24 else (2.0 * 16 * frames * ((hw + 1) // 2) ** 2 * cin * cout)
     else:
