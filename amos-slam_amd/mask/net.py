@@ -507,11 +507,13 @@ class Branches:
 
 
 def branches_for(x):
-    """AMOS_MASK_BRANCHES: 0 never, 1 always (on a GPU), default: passes of at most AMOS_MASK_BRANCH_MAX_BATCH (4) frames."""
+    """AMOS_MASK_BRANCHES: 0 never, 1 always (on a GPU), default: passes of at most AMOS_MASK_BRANCH_MAX_BATCH (16) frames -- measured as one
+    HIP graph (tools/r5_small_batch_branches.py): 1 frame 2.11 -> 1.98 ms, 2 frames 3.00 -> 2.78, 4 frames 4.39 -> 4.12, 8 frames 6.93 -> 6.62,
+    16 frames 11.73 -> 11.48; at the bench's 64 frames per pass the side stream changes nothing (1 545 / 1 543 frames/s)."""
     mode = os.environ.get("AMOS_MASK_BRANCHES", "auto")
     if mode == "0" or not x.is_cuda:
         return None
-    if mode != "1" and x.shape[0] > int(os.environ.get("AMOS_MASK_BRANCH_MAX_BATCH", "4")):
+    if mode != "1" and x.shape[0] > int(os.environ.get("AMOS_MASK_BRANCH_MAX_BATCH", "16")):
         return None
     return Branches(x.device, int(os.environ.get("AMOS_MASK_BRANCH_STREAMS", "1")))
 

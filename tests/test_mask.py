@@ -1385,7 +1385,7 @@ def test_channel_blocked_chain_gives_the_channels_last_pass(mask, gpu_lib, monke
 
 @pytest.mark.gpu
 def test_side_stream_branches_give_the_one_stream_pass(mask, gpu_lib, monkeypatch):
-    """A small pass with the pyramid's side levels and the prediction head on side streams (net.Branches; the default up to four frames per
+    """A small pass with the pyramid's side levels and the prediction head on side streams (net.Branches; the default up to 16 frames per
     pass) against the one-stream pass (AMOS_MASK_BRANCHES=0): the same kernels on the same operands, so the same network outputs (to float32
     rounding: the library's split-k kernels sum with atomics) and the same person masks -- eager, with one and two frames, and inside the
     one-frame HIP graph of MaskEngine.frame_session, replayed on several frames.  A pass above the frame limit takes no side stream."""
