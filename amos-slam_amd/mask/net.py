@@ -316,26 +316,23 @@ def bilinear(x, size=None, scale_factor=None, relu=False):
     """F.interpolate(x, mode="bilinear", align_corners=False), then a ReLU when asked.  Float32 channels-last tensors on the GPU
     go through this project's HIP kernel (amos_mask_bilinear_nhwc_act_device: PyTorch's channels-last kernel was 13 % of the mask
     pass); the source index and the weights are computed as PyTorch computes them."""
-    if isinstance(x, Blocked):  # [b][c / 8][h][w][8] is b x c / 8 channels-last images of 8 channels: the same kernel, the same taps
-        n, c, h, w = x.shape
+    def geometry(h, w):  # output size and PyTorch's area_pixel_compute_scale, in float32 as PyTorch computes it
         if size is not None:
             oh, ow = int(size[0]), int(size[1])
-            sh, sw = float(torch.tensor(h, dtype=torch.float32) / oh), float(torch.tensor(w, dtype=torch.float32) / ow)
-        else:
-            oh, ow = int(h * scale_factor), int(w * scale_factor)
-            sh = sw = float(torch.tensor(1.0, dtype=torch.float32) / scale_factor)
+            return oh, ow, float(torch.tensor(h, dtype=torch.float32) / oh), float(torch.tensor(w, dtype=torch.float32) / ow)
+        s = float(torch.tensor(1.0, dtype=torch.float32) / scale_factor)
+        return int(h * scale_factor), int(w * scale_factor), s, s
+
+    if isinstance(x, Blocked):  # [b][c / 8][h][w][8] is b x c / 8 channels-last images of 8 channels: the same kernel, the same taps
+        n, c, h, w = x.shape
+        oh, ow, sh, sw = geometry(h, w)
         y = Blocked(torch.empty((n, c // 8, oh, ow, 8), dtype=torch.float32, device=x.device), (n, c, oh, ow))
         from .. import mask_bilinear_nhwc
         mask_bilinear_nhwc(torch.cuda.current_stream(x.device).cuda_stream, x.data.data_ptr(), y.data.data_ptr(), n * (c // 8), h, w, oh, ow, 8, sh, sw, relu)
         return y
     if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last):
         n, c, h, w = x.shape
-        if size is not None:
-            oh, ow = int(size[0]), int(size[1])
-            sh, sw = float(torch.tensor(h, dtype=torch.float32) / oh), float(torch.tensor(w, dtype=torch.float32) / ow)
-        else:
-            oh, ow = int(h * scale_factor), int(w * scale_factor)
-            sh = sw = float(torch.tensor(1.0, dtype=torch.float32) / scale_factor)
+        oh, ow, sh, sw = geometry(h, w)
         y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         from .. import mask_bilinear_nhwc
         mask_bilinear_nhwc(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), y.data_ptr(), n, h, w, oh, ow, c, sh, sw, relu)
@@ -478,6 +475,8 @@ class Branches:
         self.main = torch.cuda.current_stream(device)
         key = (str(device), self.main.cuda_stream)  # side streams belong to ONE main stream: two lanes never meet on (or capture) the same one
         if key not in _SIDE_STREAMS:
+            if len(_SIDE_STREAMS) >= 64:  # (a host that keeps making main streams: do not keep a side stream for every one ever seen)
+                _SIDE_STREAMS.clear()
             _SIDE_STREAMS[key] = []
         while len(_SIDE_STREAMS[key]) < n:
             _SIDE_STREAMS[key].append(torch.cuda.Stream(device))
