@@ -202,6 +202,38 @@ def test_static_shape_batch_post_equals_reference_order_post(mask):
     assert not bool(f0_[0]) and int(m0.sum()) == 0
 
 
+def test_small_pass_and_layout_rules_on_the_host(mask, pkg, monkeypatch):
+    """Host logic of round 5's dispatch helpers (mask/net.py): no side streams, no channel-blocked chain and no one-kernel stem for tensors that are
+    not float32 on a GPU; the environment switches; the engine's CPU passes never ask for class scores only."""
+    net_mod = importlib.import_module("amos_slam_amd.mask.net")
+    x = torch.zeros(1, 3, 550, 550)
+    for mode in ("auto", "1", "0"):
+        monkeypatch.setenv("AMOS_MASK_BRANCHES", mode)
+        assert net_mod.branches_for(x) is None   # a CPU tensor: never
+    monkeypatch.delenv("AMOS_MASK_BRANCHES")
+    head = net_mod.SharedHead()
+    p3 = torch.zeros(8, 256, 69, 69).contiguous(memory_format=torch.channels_last)
+    convs = [torch.nn.Conv2d(256, 256, 3, padding=1) for _ in range(2)]
+    assert net_mod.blocked_chain_for(p3, convs, convs[:1]) is False
+    monkeypatch.setenv("AMOS_MASK_BLOCKED_CHAIN", "0")
+    assert net_mod.blocked_chain_for(p3, convs, convs[:1]) is False
+    assert head.fused_applies(p3) is False and not net_mod._stem_eligible(torch.nn.Conv2d(3, 64, 7, stride=2, padding=3))
+    monkeypatch.setenv("AMOS_MASK_STEM", "library")
+    assert not net_mod.stem_kernel_enabled()
+    monkeypatch.delenv("AMOS_MASK_STEM")
+    assert net_mod.stem_kernel_enabled()
+    b = net_mod.Blocked(torch.zeros(2, 4, 5, 6, 8), (2, 32, 5, 6))
+    assert b.shape == (2, 32, 5, 6) and b.dtype == torch.float32 and b.device.type == "cpu"
+    eng = mask.MaskEngine(device="cpu", seed=1)
+    seen = []
+    real = eng.net.forward
+    monkeypatch.setattr(eng.net, "forward", lambda x, scores_only=False: (seen.append(scores_only), real(x, scores_only))[1])
+    monkeypatch.setenv("AMOS_MASK_HEAD_SCORES", "1")
+    with torch.no_grad():
+        eng._masks_of(torch.zeros(1, 3, 550, 550), 640, 480)
+    assert seen == [False]
+
+
 def test_winograd_rule(mask, pkg, monkeypatch):
     """Which convolutions go to the Winograd kernel (mask/net.py winograd_rule; bench.py counts the executed FLOPs with the same function):
     3 x 3 / stride 1 / pad 1, cin % 16 == 0 from 32 up, cout % 64 == 0, at least 256 work-groups of 64 tiles x 64 channels.  Host logic only."""
